@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+
+from mvfnet_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_cache = {}
+
+
+def golden(name):
+    if name not in _cache:
+        _cache[name] = np.load(os.path.join(GOLDEN, name))
+    return _cache[name]
+
+
+def rel_err(a, ref):
+    """max|a-ref| / max|ref| -- tolerances are relative to each tensor's scale."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    d = float(np.abs(a - ref).max()) if a.size else 0.0
+    s = float(np.abs(ref).max()) if ref.size else 0.0
+    return d / max(s, 1e-30) if s > 0 else d
+
+
+def mvf_case_params(name, C, alpha, mode, share, use_hs, planes, net_kind):
+    """The synth state_dict of one MVF golden case, keyed like the reference module's state_dict."""
+    cs = int(C * alpha)
+    shapes = {}
+    if net_kind == "conv":
+        shapes["net.weight"] = (planes, C, 1, 1)
+    if cs:
+        shapes["shift_conv.weight"] = (cs, 1, 3, 1, 1)
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            shapes["bn." + k] = (cs,)
+        shapes["bn.num_batches_tracked"] = ()
+        if not share:
+            if mode in ("TH", "THW"):
+                shapes["h_conv.weight"] = (cs, 1, 1, 3, 1)
+            if mode == "THW":
+                shapes["w_conv.weight"] = (cs, 1, 1, 1, 3)
+    pre = "mvf/%s/" % name
+    vals = synth.synth_state_dict({pre + k: v for k, v in shapes.items()})
+    return {k: vals[pre + k] for k in shapes}
