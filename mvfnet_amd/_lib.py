@@ -1,0 +1,69 @@
+"""ctypes binding of libmvfnet_hip.so (the C ABI in include/mvfnet_hip.h).
+
+The library is built in-tree by `python -m mvfnet_amd.build` (or __graft_entry__.build()).
+There is NO fallback: if the shared object is missing or fails to load, importing this module
+raises, and every op in mvfnet_amd.ops raises with it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvfnet_hip.so")
+
+MVF_F32, MVF_BF16 = 0, 1
+MVF_NCHW, MVF_NHWC = 0, 1
+VIEW_T, VIEW_H, VIEW_W = 1, 2, 4
+MODE_BITS = {"T": 1, "TH": 3, "THW": 7}
+ERRNAMES = {-1: "MVF_EINVAL", -2: "MVF_ESHAPE", -3: "MVF_EWS", -4: "MVF_EHIP", -5: "MVF_EUNSUPPORTED"}
+
+
+class MvfDesc(C.Structure):
+    _fields_ = [("nt", C.c_int32), ("c", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("n_segment", C.c_int32),
+                ("cs", C.c_int32), ("mode", C.c_int32), ("layout", C.c_int32), ("dtype", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("dtype", C.c_int32), ("relu", C.c_int32), ("split_c", C.c_int32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "mvfnet_amd: %s not found. Build it with `python -m mvfnet_amd.build` (needs hipcc, "
+            "--offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, fp, sz, i32, f32 = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    dp = C.POINTER(MvfDesc)
+    lib.mvf_abi_version.restype = i32
+    lib.mvf_last_error.restype = C.c_char_p
+    lib.mvf_fwd_infer.restype = i32
+    lib.mvf_fwd_infer.argtypes = [dp, vp, vp, fp, fp, fp, fp, fp, vp]
+    lib.mvf_fwd_train_workspace_bytes.restype = sz
+    lib.mvf_fwd_train_workspace_bytes.argtypes = [dp]
+    lib.mvf_fwd_train.restype = i32
+    lib.mvf_fwd_train.argtypes = [dp, vp, vp, fp, fp, fp, fp, fp, f32, f32, fp, fp, fp, fp, vp, sz, vp]
+    lib.mvf_bwd_workspace_bytes.restype = sz
+    lib.mvf_bwd_workspace_bytes.argtypes = [dp]
+    lib.mvf_bwd.restype = i32
+    lib.mvf_bwd.argtypes = [dp, vp, vp, fp, fp, fp, fp, fp, fp, fp, i32, vp, fp, fp, fp, fp, fp, vp, sz, vp]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.mvf_last_error().decode("utf-8", "replace")
+        raise RuntimeError("%s failed: %s (%s)" % (what or "libmvfnet_hip", ERRNAMES.get(rc, rc), msg))
+
+
+def declared_symbols():
+    """Every function name declared in include/mvfnet_hip.h (parsed; used by the symbol-export test)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "mvfnet_hip.h")
+    txt = open(hdr).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:mvf|mvfnet)_[a-z0-9_]+)\s*\(", txt)))

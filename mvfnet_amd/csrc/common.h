@@ -1,0 +1,78 @@
+// Shared host/device helpers for libmvfnet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "mvfnet_hip.h"
+
+void mvf_set_error(const char* fmt, ...);
+
+#define MVF_HIP_OK(call)                                                                        \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            mvf_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return MVF_EHIP;                                                                    \
+        }                                                                                       \
+    } while (0)
+
+#define MVF_REQUIRE(cond, code, ...)    \
+    do {                                \
+        if (!(cond)) {                  \
+            mvf_set_error(__VA_ARGS__); \
+            return (code);              \
+        }                               \
+    } while (0)
+
+#define MVF_LAUNCH_CHECK()                                                              \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) {                                                        \
+            mvf_set_error("%s:%d: launch -> %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return MVF_EHIP;                                                            \
+        }                                                                               \
+    } while (0)
+
+// ---- storage types ---------------------------------------------------------------------------
+struct bf16_t {
+    uint16_t v;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(p->v); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+
+// 4-element vector access (16 B for f32, 8 B for bf16); pointer must be aligned to the vector size
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                       __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    uint2 r;
+    r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+}
+
+__device__ __forceinline__ float hswish_f(float u) { return u * fminf(fmaxf(u + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f); }
+// d/du [u * relu6(u+3)/6]; relu6' = 0 at the kinks (torch hardtanh_backward uses strict inequalities)
+__device__ __forceinline__ float hswish_grad_f(float u) {
+    float r6 = fminf(fmaxf(u + 3.0f, 0.0f), 6.0f);
+    float inner = (u > -3.0f && u < 3.0f) ? 1.0f : 0.0f;
+    return r6 * (1.0f / 6.0f) + u * inner * (1.0f / 6.0f);
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
