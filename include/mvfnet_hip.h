@@ -61,6 +61,14 @@ int mvf_fwd_infer(const mvf_desc_t* d, const void* x, void* out,
                   const float* w_t, const float* w_h, const float* w_w,
                   const float* bn_scale, const float* bn_shift, void* stream);
 
+/* Engine variant (MVF_NHWC only): writes ONLY the cs slice, compactly, to out_slice (nt, h, w, cs).  The wrapped
+ * 1x1 conv then reads channels [0, cs) from it and the rest from x (mvf_conv_desc_t.split_c): the pass-through
+ * channels are never copied and x stays intact for the residual branch (replaces cat + transpose + contiguous,
+ * MVF.py:135-137). */
+int mvf_fwd_infer_slice(const mvf_desc_t* d, const void* x, void* out_slice,
+                        const float* w_t, const float* w_h, const float* w_w,
+                        const float* bn_scale, const float* bn_shift, void* stream);
+
 /* Training forward: BatchNorm3d with batch statistics over (n,t,h,w) (biased variance), running-stat
  * update (momentum, unbiased variance; torch defaults used at MVF.py:69), then hard-swish.
  * save_mean / save_invstd (fp32 [cs]) are outputs kept for mvf_bwd.  running_* may be NULL. */
@@ -82,6 +90,54 @@ int mvf_bwd(const mvf_desc_t* d, const void* g, const void* x,
             const float* gamma, const float* beta, const float* mean, const float* invstd, int training,
             void* dx, float* dw_t, float* dw_h, float* dw_w, float* dgamma, float* dbeta,
             void* ws, size_t ws_bytes, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Conv / BN / ReLU stack of the backbone (codes/models/backbones/resnet.py:208-244 Bottleneck.forward,
+ * :479-494 ResNet.forward) as implicit-GEMM on the matrix cores.  Activations are channels-last
+ * (N, H, W, C); weights are pre-packed [cout][kh][kw][cin] in the activation dtype with the eval-mode
+ * BatchNorm scale folded in (mvf_pack_conv_weight), the BN shift arrives as `bias`.
+ *   y = act( conv(x, w) + bias [+ residual] )
+ * replaces nn.Conv2d -> BatchNorm2d(eval) -> [+= identity] -> ReLU  (resnet.py:213-242).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n, h, w;          /* input: images, height, width                                        */
+    int32_t cin, cout;        /* channels contracted per tap / output channels                       */
+    int32_t kh, kw, stride, pad;
+    int32_t ho, wo;           /* output height / width (validated against the formula)               */
+    int32_t x_pix_stride;     /* elements between consecutive input pixels (>= cin; = C of x)        */
+    int32_t dtype;            /* MVF_F32 | MVF_BF16 (storage of x, w, residual, y)                   */
+    int32_t relu;             /* apply ReLU in the epilogue                                          */
+    int32_t split_c;          /* 0, or: channels [0, split_c) are read from x2 instead of x (the    */
+    int32_t x2_pix_stride;    /*   compact MVF slice, pitch x2_pix_stride); 1x1 convs only           */
+} mvf_conv_desc_t;
+
+int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
+                        const float* bias, const void* residual, void* y, void* stream);
+
+/* w_oihw fp32 (cout, cin, kh, kw) [x scale[cout]] -> packed [cout][kh][kw_pad][cin_pad] in `dtype`
+ * (zero padded; kw_pad >= kw, cin_pad >= cin).  bias_out[co] = shift[co] (copied) when given.
+ * scale/shift = folded eval BatchNorm2d: scale = gamma/sqrt(var+eps), shift = beta - mean*scale. */
+int mvf_pack_conv_weight(const float* w_oihw, int cout, int cin, int kh, int kw, int kw_pad, int cin_pad,
+                         const float* scale, void* w_packed, int dtype, void* stream);
+/* scale = gamma/sqrt(var+eps), shift = beta - mean*scale  (resnet eval BN, norm.py:59 eps) */
+int mvf_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
+                float* scale, float* shift, void* stream);
+
+/* Stem input: (n,3,h,w) fp32 NCHW -> zero-padded channels-last (n, h+2*pad, wp, 4) in `dtype`
+ * (wp >= w + 2*pad + 2) so that the 7x7/2 stem (resnet.py:424-425,481) becomes 7 K-chunks of 8 px x 4 ch. */
+int mvf_stem_prep(const float* x_nchw, int n, int c, int h, int w, int pad, int wp, void* out, int dtype, void* stream);
+
+/* MaxPool2d(3, stride 2, pad 1) on NHWC (resnet.py:431,484). */
+int mvf_maxpool3x3s2_nhwc(const void* x, int n, int h, int w, int c, void* y, int dtype, void* stream);
+
+/* Head (codes/models/heads/tsn_clshead.py:71-117): per clip, mean over (T,H,W) of the NHWC features
+ * (AdaptiveAvgPool2d + consensus mean are both linear, so they commute with the FC; the fcn_testing
+ * branch :99-117 is the same expression), then new_fc.  feat (clips*T, H, W, c) -> scores (clips, classes). */
+int mvf_head_pool_fc(const void* feat, int clips, int t, int hw, int c, const float* fc_w, const float* fc_b,
+                     int classes, float* pooled_ws, float* scores, int dtype, void* stream);
+/* average_clip (codes/models/recognizers/base.py:43-74): kind 0 = None (copy), 1 = 'score', 2 = 'prob'. */
+int mvf_average_clip(const float* scores, int clips, int classes, int kind, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,8 @@ class MvfDesc(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-                ("dtype", C.c_int32), ("relu", C.c_int32), ("split_c", C.c_int32)]
+                ("ho", C.c_int32), ("wo", C.c_int32), ("x_pix_stride", C.c_int32),
+                ("dtype", C.c_int32), ("relu", C.c_int32), ("split_c", C.c_int32), ("x2_pix_stride", C.c_int32)]
 
 
 def _load():
@@ -48,6 +49,23 @@ def _load():
     lib.mvf_bwd_workspace_bytes.argtypes = [dp]
     lib.mvf_bwd.restype = i32
     lib.mvf_bwd.argtypes = [dp, vp, vp, fp, fp, fp, fp, fp, fp, fp, i32, vp, fp, fp, fp, fp, fp, vp, sz, vp]
+    lib.mvf_fwd_infer_slice.restype = i32
+    lib.mvf_fwd_infer_slice.argtypes = [dp, vp, vp, fp, fp, fp, fp, fp, vp]
+    cp = C.POINTER(ConvDesc)
+    lib.mvf_conv2d_nhwc_fwd.restype = i32
+    lib.mvf_conv2d_nhwc_fwd.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp]
+    lib.mvf_pack_conv_weight.restype = i32
+    lib.mvf_pack_conv_weight.argtypes = [fp, i32, i32, i32, i32, i32, i32, fp, vp, i32, vp]
+    lib.mvf_bn_fold.restype = i32
+    lib.mvf_bn_fold.argtypes = [fp, fp, fp, fp, f32, i32, fp, fp, vp]
+    lib.mvf_stem_prep.restype = i32
+    lib.mvf_stem_prep.argtypes = [fp, i32, i32, i32, i32, i32, i32, vp, i32, vp]
+    lib.mvf_maxpool3x3s2_nhwc.restype = i32
+    lib.mvf_maxpool3x3s2_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp]
+    lib.mvf_head_pool_fc.restype = i32
+    lib.mvf_head_pool_fc.argtypes = [vp, i32, i32, i32, i32, fp, fp, i32, fp, fp, i32, vp]
+    lib.mvf_average_clip.restype = i32
+    lib.mvf_average_clip.argtypes = [fp, i32, i32, i32, fp, vp]
     return lib
 
 

@@ -1,0 +1,357 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores, channels-last, fused bias/residual/ReLU epilogue.
+//
+//   Y[m][co] = act( sum_{kh,kw,ci} X[img][oh*s+kh-p][ow*s+kw-p][ci] * Wp[co][kh][kw][ci] + bias[co] (+ R[m][co]) )
+//   m = (img, oh, ow) flattened, GEMM M = N*Ho*Wo, N = Cout, K = KH*KW*Cin.
+//
+// Replaces nn.Conv2d -> BatchNorm2d(eval, folded into Wp/bias) -> (+= identity) -> ReLU of the reference's
+// Bottleneck (codes/models/backbones/resnet.py:208-244) and stem (:481-483).
+//
+// Design (gfx950, wave64):
+//  * K is walked in chunks of 128 BYTES per row (32 fp32 / 64 bf16 channels of ONE tap), so every A row of a
+//    chunk is one contiguous, 128-B aligned run of the NHWC tensor and every B row one run of the packed
+//    weights: global loads are 16 B per lane, 8 lanes per row -> whole cache lines.
+//  * LDS tiles are row-major [rows][128 B + 16 B pad] (144 B pitch): the global->LDS store is a plain
+//    ds_write_b128 (no transpose) and the MFMA operand fetch is ONE ds_read_b128 per lane at
+//    (row = lane&31, 16-B unit = 2*kstep + lane>>5): with the 144-B pitch each 16-lane service group of
+//    ds_read_b128 hits 16 distinct 16-B slots of the 256-B bank row -> conflict-free (checked by hand
+//    against the lane groups in MI355X_MICROARCH.md, LDS table).
+//  * fp32: v_mfma_f32_32x32x2_f32 -- one 16-B unit per lane feeds FOUR MFMAs (k-pairs (j, j+4) of the 8
+//    channels the two half-waves hold); exact fp32 (an fmaf chain), 157 TF/s peak.
+//    bf16: v_mfma_f32_32x32x16_bf16 -- one 16-B unit (8 bf16) per lane feeds ONE MFMA; fp32 accumulate.
+//    The byte-level data path is identical for both types.
+//  * 256 threads = 4 waves; block tile 128 x 128 (2x2 waves, each 2x2 MFMA tiles of 32x32) or 128 x 64
+//    (4x1 waves, each 1x2) for Cout = 64.  Register-staged double buffering: chunk k+1 is loaded from
+//    global into VGPRs before the MFMAs of chunk k and written to the other LDS buffer after them; one
+//    barrier per chunk.
+//  * XCD-aware tile order: the 8 XCDs get contiguous ranges of (m-tile, n-tile) pairs with n fastest, so the
+//    n-tiles that re-read one A row panel run on the same XCD and hit its L2.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kPitch = 144;          // LDS row pitch in bytes (128 B data + 16 B pad)
+constexpr int kBM = 128;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvArgs {
+    const char* x;
+    const char* x2;
+    const char* w;
+    const char* res;
+    const float* bias;
+    char* y;
+    int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int xps, split_c, x2ps, relu;
+    int M;
+    int cpt;       // chunks per tap = ceil(Cin*esz / 128)
+    int nchunks;   // KH*KW*cpt
+    long wK;       // packed weight row length in elements
+    int tiles_m, tiles_n;
+};
+
+template <typename ET>
+struct TT;
+template <>
+struct TT<float> {
+    static constexpr int ESZ = 4, UE = 4, CE = 32;   // element size, elements per 16-B unit, per 128-B chunk
+};
+template <>
+struct TT<bf16_t> {
+    static constexpr int ESZ = 2, UE = 8, CE = 64;
+};
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+    // bijective remap: XCD x (= bid % 8) owns the contiguous logical range starting at base(x)
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <typename ET, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(BM == kBM, "BM must be 128");
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int ESZ = TT<ET>::ESZ, UE = TT<ET>::UE, CE = TT<ET>::CE;
+    constexpr int A_ROWS_PT = BM / 32;      // rows per thread in the A loader (256 thr = 32 rows x 8 units)
+    constexpr int B_ROWS_PT = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                                   // [2][BM][kPitch]
+    char* Bs = smem + 2 * BM * kPitch;                 // [2][BN][kPitch]
+
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tn_i = tile % a.tiles_n, tm_i = tile / a.tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = tid >> 3, q = tid & 7;            // loader: row-in-32, 16-B unit within the 128-B chunk
+
+    // ---- per-thread loader state (rows are fixed for the whole K loop) ----
+    int a_pix0[A_ROWS_PT], a_ih0[A_ROWS_PT], a_iw0[A_ROWS_PT];
+#pragma unroll
+    for (int i = 0; i < A_ROWS_PT; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < a.M) {
+            const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+            a_ih0[i] = oh * a.stride - a.pad;
+            a_iw0[i] = ow * a.stride - a.pad;
+            a_pix0[i] = (img * a.H + a_ih0[i]) * a.W + a_iw0[i];
+        } else {
+            a_ih0[i] = -100000;   // never in bounds
+            a_iw0[i] = -100000;
+            a_pix0[i] = 0;
+        }
+    }
+    const char* b_ptr[B_ROWS_PT];
+    bool b_ok[B_ROWS_PT];
+#pragma unroll
+    for (int i = 0; i < B_ROWS_PT; ++i) {
+        const int co = n0 + lrow + 32 * i;
+        b_ok[i] = co < a.Cout;
+        b_ptr[i] = a.w + ((long)(b_ok[i] ? co : 0) * a.wK + q * UE) * ESZ;
+    }
+
+    uint4 ra[A_ROWS_PT], rb[B_ROWS_PT];
+    int kh = 0, kw = 0, cc = 0;          // position of the NEXT chunk to load
+
+    auto load_chunk = [&]() {
+        const int ci = cc * CE + q * UE;                       // first channel of this thread's unit
+        const bool cok = ci < a.Cin;
+        const bool from2 = (a.split_c > 0) && (cc * CE < a.split_c);
+        const char* xb = from2 ? a.x2 : a.x;
+        const int ps = from2 ? a.x2ps : a.xps;
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PT; ++i) {
+            const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+            const bool ok = cok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const long pix = (long)a_pix0[i] + kh * a.W + kw;
+                ra[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
+            }
+        }
+        const long koff = ((long)(kh * a.KW + kw) * a.Cin + cc * CE) * ESZ;
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PT; ++i) {
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (b_ok[i] && cok) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + koff);
+        }
+        if (++cc == a.cpt) {
+            cc = 0;
+            if (++kw == a.KW) {
+                kw = 0;
+                ++kh;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        char* ad = As + buf * BM * kPitch + lrow * kPitch + q * 16;
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PT; ++i) *reinterpret_cast<uint4*>(ad + 32 * i * kPitch) = ra[i];
+        char* bd = Bs + buf * BN * kPitch + lrow * kPitch + q * 16;
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PT; ++i) *reinterpret_cast<uint4*>(bd + 32 * i * kPitch) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_chunk();
+    store_chunk(0);
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * kPitch + (lane >> 5) * 16;
+    for (int kc = 0; kc < a.nchunks; ++kc) {
+        const int buf = kc & 1;
+        const bool more = kc + 1 < a.nchunks;
+        if (more) load_chunk();
+        const char* Ab = As + buf * BM * kPitch + (wm * TM * 32) * kPitch + frag_off;
+        const char* Bb = Bs + buf * BN * kPitch + (wn * TN * 32) * kPitch + frag_off;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(Ab + i * 32 * kPitch + ks * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bb + j * 32 * kPitch + ks * 32);
+            if constexpr (ESZ == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float av = __uint_as_float(e == 0 ? fa[i].x : e == 1 ? fa[i].y : e == 2 ? fa[i].z : fa[i].w);
+                            const float bv = __uint_as_float(e == 0 ? fb[j].x : e == 1 ? fb[j].y : e == 2 ? fb[j].z : fb[j].w);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        bf16x8 av, bv;
+                        __builtin_memcpy(&av, &fa[i], 16);
+                        __builtin_memcpy(&bv, &fb[j], 16);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    ET* y = reinterpret_cast<ET*>(a.y);
+    const ET* res = reinterpret_cast<const ET*>(a.res);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (col >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rbase + (r & 3) + 8 * (r >> 2);
+                if (m < a.M) {
+                    const long o = (long)m * a.Cout + col;
+                    float v = acc[i][j][r] + bv;
+                    if (res) v += ldf(res + o);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    stf(y + o, v);
+                }
+            }
+        }
+    }
+}
+
+template <typename ET>
+__global__ void pack_weight_kernel(const float* w, int cout, int cin, int kh, int kw, int kwp, int cinp,
+                                   const float* scale, ET* out) {
+    const long total = (long)cout * kh * kwp * cinp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int ci = (int)(t % cinp); t /= cinp;
+        const int x = (int)(t % kwp); t /= kwp;
+        const int yk = (int)(t % kh); t /= kh;
+        const int co = (int)t;
+        float v = 0.f;
+        if (ci < cin && x < kw) {
+            v = w[(((long)co * cin + ci) * kh + yk) * kw + x];
+            if (scale) v *= scale[co];
+        }
+        stf(out + i, v);
+    }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                               int c, float* scale, float* shift) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float s = gamma[i] / sqrtf(var[i] + eps);
+    scale[i] = s;
+    shift[i] = beta[i] - mean[i] * s;
+}
+
+template <typename ET, int WM, int WN, int TM, int TN>
+int launch_conv(const ConvArgs& a0, hipStream_t st) {
+    ConvArgs a = a0;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * kPitch;
+    auto kern = conv_igemm_kernel<ET, WM, WN, TM, TN>;
+    static bool attr_done = false;   // per instantiation; idempotent, so a benign race at worst
+    if (!attr_done) {
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(kThreads), lds, st, a);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
+                        const float* bias, const void* residual, void* y, void* stream) {
+    MVF_REQUIRE(d && x && w_packed && y, MVF_EINVAL, "conv2d: NULL argument");
+    MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
+    MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
+                    d->stride > 0 && d->pad >= 0, MVF_ESHAPE, "conv2d: bad dims");
+    const int ho = (d->h + 2 * d->pad - d->kh) / d->stride + 1, wo = (d->w + 2 * d->pad - d->kw) / d->stride + 1;
+    MVF_REQUIRE(d->ho > 0 && d->wo > 0 && d->ho <= ho && d->wo <= wo, MVF_ESHAPE,
+                "conv2d: ho,wo = %d,%d inconsistent with input %dx%d k%dx%d s%d p%d (max %d,%d)", d->ho, d->wo, d->h,
+                d->w, d->kh, d->kw, d->stride, d->pad, ho, wo);
+    const int ue = d->dtype == MVF_F32 ? 4 : 8, ce = ue * 8, esz = d->dtype == MVF_F32 ? 4 : 2;
+    MVF_REQUIRE(d->cin % ue == 0 && d->x_pix_stride % ue == 0 && d->x_pix_stride > 0, MVF_ESHAPE,
+                "conv2d: cin=%d and x_pix_stride=%d must be multiples of %d (16-byte units)", d->cin, d->x_pix_stride, ue);
+    MVF_REQUIRE(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)(x2 ? x2 : x)) % 16 == 0, MVF_EINVAL, "conv2d: pointers must be 16-byte aligned");
+    if (d->split_c) {
+        MVF_REQUIRE(x2 && d->kh == 1 && d->kw == 1 && d->split_c % ce == 0 && d->split_c <= d->cin && d->x2_pix_stride % ue == 0 && d->x2_pix_stride >= d->split_c,
+                    MVF_EINVAL, "conv2d: split_c=%d needs x2, a 1x1 kernel and a multiple of %d channels", d->split_c, ce);
+    }
+    MVF_REQUIRE((long)d->n * d->ho * d->wo < (1L << 31) && (long)d->n * d->h * d->w < (1L << 31), MVF_ESHAPE, "conv2d: too many pixels");
+    ConvArgs a = {};
+    a.x = (const char*)x; a.x2 = (const char*)x2; a.w = (const char*)w_packed; a.res = (const char*)residual;
+    a.bias = bias; a.y = (char*)y;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw;
+    a.stride = d->stride; a.pad = d->pad; a.Ho = d->ho; a.Wo = d->wo; a.xps = d->x_pix_stride;
+    a.split_c = d->split_c; a.x2ps = d->x2_pix_stride; a.relu = d->relu;
+    a.M = d->n * d->ho * d->wo;
+    a.cpt = (d->cin + ce - 1) / ce;
+    a.nchunks = d->kh * d->kw * a.cpt;
+    a.wK = (long)d->kh * d->kw * d->cin;
+    (void)esz;
+    hipStream_t st = (hipStream_t)stream;
+    const bool narrow = d->cout <= 64;
+    if (d->dtype == MVF_F32) {
+        if (narrow) return launch_conv<float, 4, 1, 1, 2>(a, st);
+        return launch_conv<float, 2, 2, 2, 2>(a, st);
+    }
+    if (narrow) return launch_conv<bf16_t, 4, 1, 1, 2>(a, st);
+    return launch_conv<bf16_t, 2, 2, 2, 2>(a, st);
+}
+
+int mvf_pack_conv_weight(const float* w_oihw, int cout, int cin, int kh, int kw, int kw_pad, int cin_pad,
+                         const float* scale, void* w_packed, int dtype, void* stream) {
+    MVF_REQUIRE(w_oihw && w_packed && cout > 0 && cin > 0 && kh > 0 && kw > 0 && kw_pad >= kw && cin_pad >= cin,
+                MVF_EINVAL, "pack_conv_weight: bad argument");
+    const long total = (long)cout * kh * kw_pad * cin_pad;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, kh, kw, kw_pad, cin_pad, scale, (float*)w_packed);
+    else if (dtype == MVF_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, kh, kw, kw_pad, cin_pad, scale, (bf16_t*)w_packed);
+    else {
+        mvf_set_error("pack_conv_weight: bad dtype %d", dtype);
+        return MVF_EINVAL;
+    }
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
+                float* scale, float* shift, void* stream) {
+    MVF_REQUIRE(gamma && beta && mean && var && scale && shift && c > 0, MVF_EINVAL, "bn_fold: bad argument");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, c, scale, shift);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+}  // extern "C"

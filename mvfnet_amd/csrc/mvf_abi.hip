@@ -28,6 +28,8 @@ size_t mvf_nhwc_ws_fwd_train(const mvf_desc_t* d);
 size_t mvf_nhwc_ws_bwd(const mvf_desc_t* d);
 int mvf_nhwc_fwd_infer(const mvf_desc_t*, const void*, void*, const float*, const float*, const float*, const float*,
                        const float*, hipStream_t);
+int mvf_nhwc_fwd_infer_impl(const mvf_desc_t*, const void*, void*, int, const float*, const float*, const float*,
+                            const float*, const float*, hipStream_t);
 int mvf_nhwc_fwd_train(const mvf_desc_t*, const void*, void*, const float*, const float*, const float*, const float*,
                        const float*, float, float, float*, float*, float*, float*, void*, hipStream_t);
 int mvf_nhwc_bwd(const mvf_desc_t*, const void*, const void*, const float*, const float*, const float*, const float*,
@@ -65,6 +67,18 @@ int mvf_fwd_infer(const mvf_desc_t* d, const void* x, void* out, const float* w_
     hipStream_t st = (hipStream_t)stream;
     if (d->layout == MVF_NCHW) return mvf_nchw_fwd_infer(d, x, out, w_t, w_h, w_w, bn_scale, bn_shift, st);
     return mvf_nhwc_fwd_infer(d, x, out, w_t, w_h, w_w, bn_scale, bn_shift, st);
+}
+
+int mvf_fwd_infer_slice(const mvf_desc_t* d, const void* x, void* out_slice, const float* w_t, const float* w_h,
+                        const float* w_w, const float* bn_scale, const float* bn_shift, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    MVF_REQUIRE(d->layout == MVF_NHWC, MVF_EUNSUPPORTED, "mvf_fwd_infer_slice: NHWC only");
+    MVF_REQUIRE(x && out_slice && w_t, MVF_EINVAL, "mvf_fwd_infer_slice: NULL x/out/w_t");
+    MVF_REQUIRE(!(d->mode & MVF_VIEW_H) || w_h, MVF_EINVAL, "mvf_fwd_infer_slice: mode has H view but w_h is NULL");
+    MVF_REQUIRE(!(d->mode & MVF_VIEW_W) || w_w, MVF_EINVAL, "mvf_fwd_infer_slice: mode has W view but w_w is NULL");
+    MVF_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), MVF_EINVAL, "mvf_fwd_infer_slice: bn_scale/bn_shift must both be set or both NULL");
+    return mvf_nhwc_fwd_infer_impl(d, x, out_slice, d->cs, w_t, w_h, w_w, bn_scale, bn_shift, (hipStream_t)stream);
 }
 
 size_t mvf_fwd_train_workspace_bytes(const mvf_desc_t* d) {

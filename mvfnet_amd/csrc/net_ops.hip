@@ -1,0 +1,179 @@
+// Bandwidth-bound companions of the conv stack: stem input re-layout, max-pool, TSN head, clip averaging.
+#include <algorithm>
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+// (n,c<=4,h,w) fp32 NCHW -> zero-padded NHWC4: out[n][ih+pad][iw+pad][0..3]; lanes run along w (coalesced reads
+// of each colour plane, 16-B/8-B stores).
+template <typename ET>
+__global__ void stem_prep_kernel(const float* x, int n, int c, int h, int w, int pad, int hp, int wp, ET* out) {
+    const long total = (long)n * hp * wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % wp);
+        const long t = i / wp;
+        const int yo = (int)(t % hp);
+        const int img = (int)(t / hp);
+        const int ih = yo - pad, iw = xo - pad;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ih >= 0 && ih < h && iw >= 0 && iw < w) {
+            for (int k = 0; k < c; ++k) v[k] = x[(((long)img * c + k) * h + ih) * w + iw];
+        }
+        st4(out + i * 4, make_float4(v[0], v[1], v[2], v[3]));
+    }
+}
+
+// MaxPool2d(3, 2, 1) NHWC; thread = (output pixel, 4 channels)
+template <typename ET>
+__global__ void maxpool_kernel(const ET* x, int n, int h, int w, int c, int ho, int wo, ET* y) {
+    const int c4 = c >> 2;
+    const long total = (long)n * ho * wo * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % c4);
+        long t = i / c4;
+        const int ow = (int)(t % wo); t /= wo;
+        const int oh = (int)(t % ho);
+        const int img = (int)(t / ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ih = oh * 2 - 1 + dy;
+            if (ih < 0 || ih >= h) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iw = ow * 2 - 1 + dx;
+                if (iw < 0 || iw >= w) continue;
+                float4 v = ld4(x + (((long)img * h + ih) * w + iw) * c + cq * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        st4(y + (((long)img * ho + oh) * wo + ow) * c + cq * 4, m);
+    }
+}
+
+// pooled[clip][ch] = mean over the clip's T*HW feature rows; lanes along channels (coalesced rows)
+template <typename ET>
+__global__ void head_pool_kernel(const ET* feat, int rows_per_clip, int c, float* pooled) {
+    const int clip = blockIdx.y;
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const ET* p = feat + (long)clip * rows_per_clip * c + ch;
+    float s = 0.f;
+    for (int r = 0; r < rows_per_clip; ++r) s += ldf(p + (long)r * c);
+    pooled[(long)clip * c + ch] = s / (float)rows_per_clip;
+}
+
+// scores[clip][k] = b[k] + pooled[clip] . W[k]; one wave per (clip, class)
+__global__ void head_fc_kernel(const float* pooled, const float* w, const float* b, int clips, int c, int classes,
+                               float* scores) {
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (gw >= clips * classes) return;
+    const int clip = gw / classes, k = gw - clip * classes;
+    const float* p = pooled + (long)clip * c;
+    const float* wr = w + (long)k * c;
+    float s = 0.f;
+    for (int i = lane; i < c; i += 64) s += p[i] * wr[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) scores[gw] = s + (b ? b[k] : 0.f);
+}
+
+// average_clip: kind 1 = mean of scores over clips, kind 2 = mean of softmax(scores) over clips; one block
+__global__ void average_clip_kernel(const float* scores, int clips, int classes, int kind, float* out) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < classes; k += blockDim.x) out[k] = 0.f;
+    __syncthreads();
+    for (int cl = 0; cl < clips; ++cl) {
+        const float* s = scores + (long)cl * classes;
+        float mx = -INFINITY, den = 1.f;
+        if (kind == 2) {
+            for (int k = tid; k < classes; k += blockDim.x) mx = fmaxf(mx, s[k]);
+            red[tid] = mx;
+            __syncthreads();
+            for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+                if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+                __syncthreads();
+            }
+            mx = red[0];
+            __syncthreads();
+            float e = 0.f;
+            for (int k = tid; k < classes; k += blockDim.x) e += expf(s[k] - mx);
+            red[tid] = e;
+            __syncthreads();
+            for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+                if (tid < o) red[tid] += red[tid + o];
+                __syncthreads();
+            }
+            den = red[0];
+            __syncthreads();
+        }
+        for (int k = tid; k < classes; k += blockDim.x) {
+            const float v = kind == 2 ? expf(s[k] - mx) / den : s[k];
+            out[k] += v;
+        }
+    }
+    for (int k = tid; k < classes; k += blockDim.x) out[k] = out[k] / (float)clips;
+}
+
+inline int grid_for(long total, int per_block = 256, int cap = 256 * 32) {
+    return (int)std::min<long>((total + per_block - 1) / per_block, cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvf_stem_prep(const float* x_nchw, int n, int c, int h, int w, int pad, int wp, void* out, int dtype, void* stream) {
+    MVF_REQUIRE(x_nchw && out && n > 0 && c > 0 && c <= 4 && h > 0 && w > 0 && pad >= 0 && wp >= w + 2 * pad, MVF_EINVAL, "stem_prep: bad argument");
+    const int hp = h + 2 * pad;
+    const long total = (long)n * hp * wp;
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(stem_prep_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, n, c, h, w, pad, hp, wp, (float*)out);
+    else
+        hipLaunchKernelGGL(stem_prep_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, n, c, h, w, pad, hp, wp, (bf16_t*)out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_maxpool3x3s2_nhwc(const void* x, int n, int h, int w, int c, void* y, int dtype, void* stream) {
+    MVF_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool: bad argument (c %% 4 != 0?)");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long total = (long)n * ho * wo * (c / 4);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, h, w, c, ho, wo, (float*)y);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, n, h, w, c, ho, wo, (bf16_t*)y);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_head_pool_fc(const void* feat, int clips, int t, int hw, int c, const float* fc_w, const float* fc_b, int classes,
+                     float* pooled_ws, float* scores, int dtype, void* stream) {
+    MVF_REQUIRE(feat && fc_w && pooled_ws && scores && clips > 0 && t > 0 && hw > 0 && c > 0 && classes > 0, MVF_EINVAL, "head_pool_fc: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g((c + 255) / 256, clips);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(head_pool_kernel<float>, g, dim3(256), 0, st, (const float*)feat, t * hw, c, pooled_ws);
+    else
+        hipLaunchKernelGGL(head_pool_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)feat, t * hw, c, pooled_ws);
+    MVF_LAUNCH_CHECK();
+    const long waves = (long)clips * classes;
+    hipLaunchKernelGGL(head_fc_kernel, dim3((int)((waves * 64 + 255) / 256)), dim3(256), 0, st, pooled_ws, fc_w, fc_b, clips, c, classes, scores);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_average_clip(const float* scores, int clips, int classes, int kind, float* out, void* stream) {
+    MVF_REQUIRE(scores && out && clips > 0 && classes > 0 && kind >= 0 && kind <= 2, MVF_EINVAL, "average_clip: bad argument");
+    if (kind == 0) {
+        MVF_HIP_OK(hipMemcpyAsync(out, scores, sizeof(float) * clips * classes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return MVF_OK;
+    }
+    hipLaunchKernelGGL(average_clip_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scores, clips, classes, kind, out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+"""Recognizer2D -- the mmaction-style model API of the reference, MI355X-native.
+
+Mirror of `codes/models/recognizers/base.py` (BaseRecognizer :11-82) and `recognizer2d.py` (Recognizer2D :8-179):
+built by `build_recognizer(cfg.model, train_cfg, test_cfg)`, children `backbone` / `cls_head` (same state_dict
+prefixes), MVF inserted from `module_cfg`, `forward(img_group, label, return_loss=True, return_numpy=True)`.
+"""
+import torch
+import torch.nn as nn
+
+from ..builder import RECOGNIZERS, build_backbone, build_head
+
+
+@RECOGNIZERS.register_module
+class Recognizer2D(nn.Module):
+    def __init__(self, modality="RGB", backbone=None, cls_head=None, fcn_testing=False, module_cfg=None,
+                 nonlocal_cfg=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        if modality != "RGB":
+            raise NotImplementedError("only modality='RGB' is built (the MVFNet configs)")
+        if nonlocal_cfg:
+            raise NotImplementedError("non-local blocks are out of scope")
+        if backbone is None or backbone.get("type") != "ResNet":
+            raise NotImplementedError("Recognizer2D: backbone type 'ResNet' is the one built here")
+        self.fp16_enabled = False
+        self.backbone = build_backbone(backbone)
+        self.cls_head = build_head(cls_head) if cls_head is not None else None
+        self.init_weights()
+        self.fcn_testing, self.modality = fcn_testing, modality
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.module_cfg = dict(module_cfg) if module_cfg else module_cfg
+        self.in_channels = 3
+        if self.module_cfg:
+            # reference recognizer2d.py:45-59: weights are initialised/loaded BEFORE the MVF wrappers exist
+            self.module_name = self.module_cfg.pop("type")
+            if self.module_name != "MVF":
+                raise NotImplementedError("module_cfg type %r: only 'MVF' is built" % self.module_name)
+            from ..modules.MVF import make_multi_view_fusion
+            make_multi_view_fusion(self.backbone, **self.module_cfg)
+            self.backbone.invalidate_engine()
+
+    @property
+    def with_cls_head(self):
+        return self.cls_head is not None
+
+    def init_weights(self):
+        self.backbone.init_weights()
+        if self.with_cls_head:
+            self.cls_head.init_weights()
+
+    def extract_feat(self, img_group):
+        return self.backbone(img_group)
+
+    def average_clip(self, cls_score):
+        """reference base.py:43-74."""
+        if self.test_cfg is None:
+            self.test_cfg = dict(average_clips=None)
+        if "average_clips" not in self.test_cfg:
+            raise KeyError('"average_clips" must defined in test_cfg\'s keys')
+        return self.cls_head.engine().average(cls_score, self.test_cfg["average_clips"])
+
+    def forward(self, img_group, label=None, return_loss=True, return_numpy=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img_group, label, **kwargs)
+        return self.forward_test(img_group, return_numpy, **kwargs)
+
+    def forward_train(self, imgs, labels, **kwargs):
+        raise NotImplementedError("mvfnet_amd: forward_train (batch-stat BN conv stack, loss, backward) is not built yet; "
+                                  "the eval/inference path and the MVF module's own forward/backward are.")
+
+    def forward_test(self, imgs, return_numpy=True, **kwargs):
+        """imgs [B, clips*crops*T, 3, H, W] -> (1 | clips, num_classes) (reference recognizer2d.py:151-179)."""
+        if not imgs.is_cuda:
+            raise RuntimeError("Recognizer2D: mvfnet_amd runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
+        with torch.no_grad():
+            x = imgs.reshape((-1, self.in_channels) + tuple(imgs.shape[3:]))
+            feat = self.extract_feat(x)                                   # (B*frames, 2048, h, w), channels-last
+            if self.with_cls_head:
+                num_seg = self.module_cfg["n_segment"] if self.module_cfg else x.shape[0] // imgs.shape[0]
+                # with fcn_testing the reference reshapes to (clips, C, T, h, w) and runs a 1x1x1 conv + mean; the head
+                # kernel computes the same mean-then-FC directly from the channels-last features
+                cls_score = self.cls_head(feat, num_seg)
+                cls_score = self.average_clip(cls_score)
+            else:
+                cls_score = feat
+        return cls_score.cpu().numpy() if return_numpy else cls_score

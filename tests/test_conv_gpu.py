@@ -1,0 +1,128 @@
+"""GPU parity of the implicit-GEMM conv + fused epilogue and the small network ops against the CPU oracle
+(torch.nn.functional on CPU -- the same ATen arithmetic the reference calls)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+# (n, h, w, cin, cout, k, stride, pad)
+CONV_CASES = [
+    (2, 14, 14, 64, 64, 1, 1, 0),       # narrow tile (Cout 64)
+    (3, 9, 7, 128, 256, 1, 1, 0),       # M tail (189 rows)
+    (2, 14, 14, 256, 512, 1, 2, 0),     # downsample 1x1 stride 2
+    (2, 12, 12, 64, 64, 3, 1, 1),       # 3x3
+    (2, 13, 11, 128, 128, 3, 2, 1),     # 3x3 stride 2, odd sizes
+    (1, 7, 7, 512, 2048, 1, 1, 0),      # many n tiles
+    (2, 8, 8, 48, 96, 3, 1, 1),         # cin not a multiple of the chunk, cout not a multiple of the tile
+    (4, 7, 7, 2048, 512, 1, 1, 0),      # long K
+]
+
+
+def _run_conv(x_nhwc, w_oihw, scale, bias, residual, relu, stride, pad, dtype, x2=None, split_c=0):
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    dt = _lib.MVF_F32 if dtype == torch.float32 else _lib.MVF_BF16
+    n, h, w, cin = x_nhwc.shape
+    cout, _, kh, kw = w_oihw.shape
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    wp = torch.empty(cout, kh, kw, cin, dtype=dtype, device="cuda")
+    check(lib.mvf_pack_conv_weight(p(w_oihw), cout, cin, kh, kw, kw, cin, p(scale), p(wp), dt, None))
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty(n, ho, wo, cout, dtype=dtype, device="cuda")
+    d = _lib.ConvDesc(n, h, w, cin, cout, kh, kw, stride, pad, ho, wo, cin, dt, int(relu), split_c, split_c)
+    check(lib.mvf_conv2d_nhwc_fwd(C.byref(d), p(x_nhwc), p(x2), p(wp), p(bias), p(residual), p(y), None))
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "n%d_%dx%d_c%d_o%d_k%d_s%d" % c[:7])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "bias_res_relu"])
+def test_conv_igemm_vs_oracle(case, dtype, epi):
+    n, h, w, cin, cout, k, stride, pad = case
+    if dtype == torch.bfloat16 and cin % 8:
+        pytest.skip("bf16 needs cin % 8 == 0")
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.2 if epi != "plain" else None
+    ref = F.conv2d(x, wgt * scale.view(-1, 1, 1, 1), bias, stride=stride, padding=pad)
+    res = torch.randn(ref.shape, generator=g) if epi == "bias_res_relu" else None
+    if res is not None:
+        ref = ref + res
+    if epi != "plain":
+        ref = F.relu(ref)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().to(dtype)
+    rg = res.permute(0, 2, 3, 1).contiguous().cuda().to(dtype) if res is not None else None
+    y = _run_conv(xg, wgt.cuda(), scale.cuda(), bias.cuda() if bias is not None else None, rg, epi != "plain", stride, pad, dtype)
+    got = y.float().cpu().permute(0, 3, 1, 2).numpy()
+    tol = 2e-5 if dtype == torch.float32 else 1e-2          # north_star: 1e-3 fp32 / 1e-2 bf16
+    assert rel_err(got, ref.numpy()) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_conv_split_a_operand(dtype):
+    """1x1 conv reading channels [0,Cs) from the compact MVF slice buffer and the rest from x."""
+    g = torch.Generator().manual_seed(7)
+    n, h, w, cin, cout, cs = 2, 7, 7, 256, 128, 64
+    x = torch.randn(n, h, w, cin, generator=g)
+    sl = torch.randn(n, h, w, cs, generator=g)
+    wgt = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    xin = x.clone()
+    xin[..., :cs] = sl
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), wgt)
+    y = _run_conv(x.cuda().to(dtype), wgt.cuda(), None, None, None, False, 1, 0, dtype, x2=sl.cuda().to(dtype), split_c=cs)
+    assert rel_err(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < (2e-5 if dtype == torch.float32 else 1e-2)
+
+
+def test_conv_full_size_linearity_and_oracle_rows():
+    """BASELINE C2 size (layer3 MVF.net: 256 images x 14x14, 1024 -> 256): full-tensor properties + oracle on a slice."""
+    torch.manual_seed(3)
+    n, h, w, cin, cout = 256, 14, 14, 1024, 256
+    x1 = torch.randn(n, h, w, cin, device="cuda")
+    x2 = torch.randn(n, h, w, cin, device="cuda")
+    wgt = torch.randn(cout, cin, 1, 1, device="cuda") * (2.0 / cin) ** 0.5
+    y1 = _run_conv(x1, wgt, None, None, None, False, 1, 0, torch.float32)
+    y2 = _run_conv(x2, wgt, None, None, None, False, 1, 0, torch.float32)
+    y12 = _run_conv(x1 + 2 * x2, wgt, None, None, None, False, 1, 0, torch.float32)
+    lin = (y1 + 2 * y2 - y12).abs().max() / y12.abs().max()
+    assert float(lin) < 1e-5                                      # linearity in the input
+    ref = F.conv2d(x1[:2].cpu().permute(0, 3, 1, 2), wgt.cpu())    # oracle on 2 images
+    assert rel_err(y1[:2].cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < 2e-5
+    ref = F.conv2d(x1[-1:].cpu().permute(0, 3, 1, 2), wgt.cpu())   # ... and on the last image (tail tiles)
+    assert rel_err(y1[-1:].cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < 2e-5
+
+
+def test_stem_maxpool_head_ops_vs_oracle():
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    g = torch.Generator().manual_seed(11)
+    # max-pool (odd and even sizes)
+    for (n, h, w, c) in [(2, 9, 11, 8), (1, 112, 112, 64)]:
+        x = torch.randn(n, c, h, w, generator=g)
+        ref = F.max_pool2d(x, 3, 2, 1)
+        y = torch.empty(n, ref.shape[2], ref.shape[3], c, device="cuda")
+        check(lib.mvf_maxpool3x3s2_nhwc(p(x.permute(0, 2, 3, 1).contiguous().cuda()), n, h, w, c, p(y), 0, None))
+        assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)
+    # head: avgpool + fc + segment mean, then clip averaging
+    clips, T, hw, c, classes = 6, 4, 9, 64, 10
+    feat = torch.randn(clips * T, c, 3, 3, generator=g)
+    fw, fb = torch.randn(classes, c, generator=g) * 0.1, torch.randn(classes, generator=g)
+    ref = F.linear(F.adaptive_avg_pool2d(feat, 1).flatten(1), fw, fb).reshape(clips, T, classes).mean(1)
+    pooled = torch.empty(clips, c, device="cuda")
+    out = torch.empty(clips, classes, device="cuda")
+    check(lib.mvf_head_pool_fc(p(feat.permute(0, 2, 3, 1).contiguous().cuda()), clips, T, hw, c, p(fw.cuda()), p(fb.cuda()),
+                               classes, p(pooled), p(out), 0, None))
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
+    for kind, fn in ((1, lambda s: s.mean(0, keepdim=True)), (2, lambda s: F.softmax(s, 1).mean(0, keepdim=True))):
+        avg = torch.empty(1, classes, device="cuda")
+        check(lib.mvf_average_clip(p(out), clips, classes, kind, p(avg), None))
+        assert rel_err(avg.cpu().numpy(), fn(ref).numpy()) < 1e-5
