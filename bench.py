@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- MVFNet-R50 8x8 hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--clips B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic clips already resident in HBM:
+BASELINE.json configs[1] -- MVFNet-ResNet50 8x8, 32 clips of 8 x 3 x 224 x 224 per GPU, fp32, eval BatchNorm,
+forward only (Recognizer2D.forward_test -> HIP engine).  Clips are independent units, so N GPUs run N
+replicas of the weights on N disjoint batches with no data-path collective ("weak" scaling); the timed region is
+bracketed by barrier + synchronize and the MAX over ranks is reported.
+
+The JSON line also carries
+  roofline      the dominant kernel (implicit-GEMM conv): algorithmic FLOP of the conv launches of one step divided
+                by their summed HIP-event durations (measured live, on the launch stream), vs the dense MFMA peak
+  cpu_baseline  the CPU restatement (oracle/net_torch.py, kind "port") timed on this box's host cores on a bounded
+                sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks (fp32-in / bf16)
+T_FRAMES, SIZE = 8, 224
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--clips", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def build_model(depth, dtype):
+    import mvfnet_amd
+    from mvfnet_amd import synth
+    m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(depth, T_FRAMES), None, dict(average_clips=None))
+    sd = m.state_dict()
+    pre = "r%d/" % depth
+    vals = synth.synth_state_dict({pre + k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(vals[pre + k]) for k in sd}, strict=True)
+    m.backbone.engine_dtype = torch.float32 if dtype == "f32" else torch.bfloat16
+    return m.cuda().eval()
+
+
+def conv_roofline(model, imgs, dtype, reps=3):
+    """Per-launch HIP-event timing of every implicit-GEMM conv launch of one step (instrumented passes, outside
+    the timed region).  Events are recorded on torch's current stream, which is the stream the C ABI launches on."""
+    from mvfnet_amd import engine as E
+    records = []
+    orig = E._Conv.run
+
+    def timed(self, x, n, h, w, c_total, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(self, x, n, h, w, c_total, **kw)
+        e1.record()
+        y, ho, wo = out
+        k_alg = 147 if self.kw == 1 and self.cin == 32 and self.kh == 7 else self.kh * self.kw * self.cin
+        records.append((e0, e1, 2.0 * n * ho * wo * self.cout * k_alg))
+        return out
+
+    E._Conv.run = timed
+    try:
+        tot_ms, tot_flop, launches = 0.0, 0.0, 0
+        for _ in range(reps):
+            del records[:]
+            model(imgs, None, return_loss=False, return_numpy=False)
+            torch.cuda.synchronize()
+            tot_ms += sum(a.elapsed_time(b) for a, b, _ in records)
+            tot_flop += sum(f for _, _, f in records)
+            launches += len(records)
+    finally:
+        E._Conv.run = orig
+    achieved = tot_flop / (tot_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[dtype]
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "pmc_conv_bytes_per_launch.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dtype)
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "launches_per_step": launches // reps,
+            "avg_launch_us": round(tot_ms * 1e3 / launches, 2), "flop_per_launch": round(tot_flop / launches),
+            "conv_ms_per_step": round(tot_ms / reps, 3)}
+
+
+def cpu_baseline(depth, seconds):
+    """The CPU restatement of the same graph (oracle/net_torch.py), all host cores, bounded sample."""
+    from mvfnet_amd import synth
+    from mvfnet_amd.arch import state_dict_shapes
+    from oracle import net_torch
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    shp = state_dict_shapes(depth)
+    pre = "r%d/" % depth
+    vals = synth.synth_state_dict({pre + k: v for k, v in shp.items()})
+    sd = {k: torch.from_numpy(vals[pre + k]) for k in shp}
+    clips = 4
+    imgs = torch.from_numpy(synth.synth_clip_batch(clips, T_FRAMES, SIZE, SIZE, seed=7))
+    with torch.no_grad():
+        net_torch.forward_test(imgs, sd, depth, T_FRAMES, None)          # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            net_torch.forward_test(imgs, sd, depth, T_FRAMES, None)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > seconds or n >= 50:
+                break
+    return {"value": round(clips * n / el, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "%d x %d clips of %dx3x%dx%d, fp32 eval forward, torch CPU %d threads, %.1f s" % (
+                n, clips, T_FRAMES, SIZE, SIZE, cores, el)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    model = build_model(args.depth, args.dtype)
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    imgs = torch.randn(args.clips, T_FRAMES, 3, SIZE, SIZE, device="cuda", generator=gen)
+
+    def step():
+        return model(imgs, None, return_loss=False, return_numpy=False)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if dist is not None:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        from mvfnet_amd.arch import conv_macs_per_image
+        ms = el / args.steps * 1e3
+        value = world * args.clips * args.steps / el
+        flop_clip = 2.0 * conv_macs_per_image(args.depth, SIZE) * T_FRAMES
+        res = {
+            "metric": "clips/sec (fwd) MVFNet-R%d 8x8 224^2" % args.depth,
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: MVFNet-ResNet%d 8x8, %d clips/GPU of 8x3x224x224, %s, "
+                                   "eval-BN forward through the HIP engine (stem+16 bottlenecks+9 MVF+head)" % (
+                                       args.depth, args.clips, "fp32" if args.dtype == "f32" else "bf16"),
+                       "clips_per_gpu": args.clips, "frames_per_clip": T_FRAMES, "parallelism": "replicas x%d (clips sharded, no collective)" % world},
+            "model_tflops": round(value * flop_clip / 1e12, 2),
+            "note": "BASELINE.json's metric is quoted as fwd+bwd; this round measures the forward configuration (configs[1]) "
+                    "-- the training-mode conv stack/backward is not built yet",
+        }
+        res["roofline"] = conv_roofline(model, imgs, args.dtype)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

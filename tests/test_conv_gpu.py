@@ -110,7 +110,8 @@ def test_stem_maxpool_head_ops_vs_oracle():
         x = torch.randn(n, c, h, w, generator=g)
         ref = F.max_pool2d(x, 3, 2, 1)
         y = torch.empty(n, ref.shape[2], ref.shape[3], c, device="cuda")
-        check(lib.mvf_maxpool3x3s2_nhwc(p(x.permute(0, 2, 3, 1).contiguous().cuda()), n, h, w, c, p(y), 0, None))
+        xg = x.permute(0, 2, 3, 1).contiguous().cuda()           # keep alive: p() only takes the address
+        check(lib.mvf_maxpool3x3s2_nhwc(p(xg), n, h, w, c, p(y), 0, None))
         assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)
     # head: avgpool + fc + segment mean, then clip averaging
     clips, T, hw, c, classes = 6, 4, 9, 64, 10
@@ -119,8 +120,8 @@ def test_stem_maxpool_head_ops_vs_oracle():
     ref = F.linear(F.adaptive_avg_pool2d(feat, 1).flatten(1), fw, fb).reshape(clips, T, classes).mean(1)
     pooled = torch.empty(clips, c, device="cuda")
     out = torch.empty(clips, classes, device="cuda")
-    check(lib.mvf_head_pool_fc(p(feat.permute(0, 2, 3, 1).contiguous().cuda()), clips, T, hw, c, p(fw.cuda()), p(fb.cuda()),
-                               classes, p(pooled), p(out), 0, None))
+    fg, fwg, fbg = feat.permute(0, 2, 3, 1).contiguous().cuda(), fw.cuda(), fb.cuda()
+    check(lib.mvf_head_pool_fc(p(fg), clips, T, hw, c, p(fwg), p(fbg), classes, p(pooled), p(out), 0, None))
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-5
     for kind, fn in ((1, lambda s: s.mean(0, keepdim=True)), (2, lambda s: F.softmax(s, 1).mean(0, keepdim=True))):
         avg = torch.empty(1, classes, device="cuda")
