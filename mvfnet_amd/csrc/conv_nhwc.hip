@@ -299,8 +299,12 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
                 "conv2d: ho,wo = %d,%d inconsistent with input %dx%d k%dx%d s%d p%d (max %d,%d)", d->ho, d->wo, d->h,
                 d->w, d->kh, d->kw, d->stride, d->pad, ho, wo);
     const int ue = d->dtype == MVF_F32 ? 4 : 8, ce = ue * 8, esz = d->dtype == MVF_F32 ? 4 : 2;
-    MVF_REQUIRE(d->cin % ue == 0 && d->x_pix_stride % ue == 0 && d->x_pix_stride > 0, MVF_ESHAPE,
-                "conv2d: cin=%d and x_pix_stride=%d must be multiples of %d (16-byte units)", d->cin, d->x_pix_stride, ue);
+    // every row of a K chunk must start on a 16-byte boundary: pixel pitch a multiple of the unit, or (stem view of the
+    // padded NHWC4 input) an even pixel pitch walked two pixels at a time over an even-width image
+    const bool pitch_ok = d->x_pix_stride > 0 && (d->x_pix_stride % ue == 0 ||
+                          ((d->x_pix_stride * 2) % ue == 0 && d->stride % 2 == 0 && d->kw == 1 && d->pad == 0 && d->w % 2 == 0));
+    MVF_REQUIRE(d->cin % ue == 0 && pitch_ok, MVF_ESHAPE,
+                "conv2d: cin=%d / x_pix_stride=%d do not give 16-byte aligned K chunks (unit = %d elements)", d->cin, d->x_pix_stride, ue);
     MVF_REQUIRE(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)(x2 ? x2 : x)) % 16 == 0, MVF_EINVAL, "conv2d: pointers must be 16-byte aligned");
     if (d->split_c) {
         MVF_REQUIRE(x2 && d->kh == 1 && d->kw == 1 && d->split_c % ce == 0 && d->split_c <= d->cin && d->x2_pix_stride % ue == 0 && d->x2_pix_stride >= d->split_c,
