@@ -111,7 +111,7 @@ def conv_roofline(model, imgs, dtype, reps=3, per_layer=False):
             "conv_ms_per_step": round(tot_ms / reps, 3)}
 
 
-def cpu_baseline(depth, seconds):
+def cpu_baseline(depth, seconds, gpu_clips=32):
     """The CPU restatement of the same graph (oracle/net_torch.py), all host cores, bounded sample."""
     from mvfnet_amd import synth
     from mvfnet_amd.arch import state_dict_shapes
@@ -125,7 +125,7 @@ def cpu_baseline(depth, seconds):
     imgs = torch.from_numpy(synth.synth_clip_batch(clips, T_FRAMES, SIZE, SIZE, seed=7))
     # oneDNN/OpenMP with one thread per hardware thread (256 here) thrashes; try a few team sizes, keep the best
     best = None
-    cands = sorted(set(t for t in (16, 32, 64, 128) if t <= cores) or {cores})
+    cands = sorted(set(t for t in (8, 16, 32, 64) if t <= cores) or {cores})
     with torch.no_grad():
         for thr in cands:
             torch.set_num_threads(thr)
@@ -147,7 +147,23 @@ def cpu_baseline(depth, seconds):
     if best is None:
         return {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "sample": "no thread count finished in %.0f s" % seconds}
     rate, thr, n, el = best
-    return {"value": round(rate, 2), "unit": "clips/s", "cores": thr, "kind": "port", "host_hw_threads": cores,
+    eager = None
+    try:   # same restatement executed by PyTorch-ROCm eager (MIOpen/rocBLAS) on this GPU: the ">= 1.5x" comparator
+        gsd = {k: v.cuda() for k, v in sd.items()}
+        gim = torch.randn(gpu_clips, T_FRAMES, 3, SIZE, SIZE, device="cuda")
+        torch.backends.cudnn.benchmark = True
+        with torch.no_grad():
+            for _ in range(3):
+                net_torch.forward_test(gim, gsd, depth, T_FRAMES, None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                net_torch.forward_test(gim, gsd, depth, T_FRAMES, None)
+            torch.cuda.synchronize()
+            eager = round(gpu_clips * 5 / (time.perf_counter() - t0), 2)
+    except Exception as e:   # comparator only
+        eager = "failed: %s" % str(e)[:80]
+    return {"torch_eager_gpu_clips_per_s": eager, "value": round(rate, 2), "unit": "clips/s", "cores": thr, "kind": "port", "host_hw_threads": cores,
             "sample": "%d x %d clips of %dx3x%dx%d, fp32 eval forward, torch CPU (oneDNN) %d threads (best of %s), %.1f s" % (
                 n, clips, T_FRAMES, SIZE, SIZE, thr, cands, el)}
 
@@ -216,7 +232,7 @@ def main():
         }
         res["roofline"] = conv_roofline(model, imgs, args.dtype, per_layer=args.per_layer)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds, args.clips)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

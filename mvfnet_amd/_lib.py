@@ -7,6 +7,8 @@ raises, and every op in mvfnet_amd.ops raises with it.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: torch bundles its own libamdhip64; ours must resolve to that same runtime
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvfnet_hip.so")
 

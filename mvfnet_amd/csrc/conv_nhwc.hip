@@ -212,27 +212,49 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    ET* y = reinterpret_cast<ET*>(a.y);
-    const ET* res = reinterpret_cast<const ET*>(a.res);
+    // ---- epilogue ----------------------------------------------------------------------------------------
+    // The 32x32 MFMA C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) gives each lane single
+    // floats of 16 different rows: stored directly that is 64 dword stores (and 64 dword residual loads) per wave.
+    // Instead the block tile is transposed through LDS (the A/B buffers are dead after the last barrier) and
+    // written out row-wise, 16 B (f32) / 8 B (bf16) per lane: whole 512-B / 256-B row segments per 32 lanes, and
+    // the residual is read the same way.
+    constexpr int CP = BN * 4 + 16;                      // C-tile pitch in bytes
+    static_assert(BM * CP <= 2 * (BM + BN) * kPitch, "C tile must fit in the A/B LDS buffers");
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (col >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[col] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int rbase = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = rbase + (r & 3) + 8 * (r >> 2);
-                if (m < a.M) {
-                    const long o = (long)m * a.Cout + col;
-                    float v = acc[i][j][r] + bv;
-                    if (res) v += ldf(res + o);
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    stf(y + o, v);
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = (wn * TN + j) * 32 + (lane & 31);
+                *reinterpret_cast<float*>(smem + row * CP + col * 4) = acc[i][j][r];
+            }
+    __syncthreads();
+    constexpr int TPR = BN / 4, RPP = kThreads / TPR;   // threads per row, rows per pass
+    const int cq = tid % TPR, r0 = tid / TPR;
+    const int col = n0 + cq * 4;
+    if (col < a.Cout) {                                  // Cout % 4 == 0 (checked on the host)
+        ET* y = reinterpret_cast<ET*>(a.y);
+        const ET* res = reinterpret_cast<const ET*>(a.res);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + col);
+#pragma unroll 4
+        for (int ps = 0; ps < BM / RPP; ++ps) {
+            const int row = r0 + ps * RPP;
+            const int m = m0 + row;
+            if (m < a.M) {
+                float4 v = *reinterpret_cast<const float4*>(smem + row * CP + cq * 16);
+                const long o = (long)m * a.Cout + col;
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (res) {
+                    const float4 rv = ld4(res + o);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                 }
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                st4(y + o, v);
             }
         }
     }
@@ -310,6 +332,8 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
         MVF_REQUIRE(x2 && d->kh == 1 && d->kw == 1 && d->split_c % ce == 0 && d->split_c <= d->cin && d->x2_pix_stride % ue == 0 && d->x2_pix_stride >= d->split_c,
                     MVF_EINVAL, "conv2d: split_c=%d needs x2, a 1x1 kernel and a multiple of %d channels", d->split_c, ce);
     }
+    MVF_REQUIRE(d->cout % 4 == 0 && ((uintptr_t)y | (uintptr_t)(residual ? residual : y) | (uintptr_t)(bias ? (const void*)bias : y)) % 16 == 0, MVF_ESHAPE,
+                "conv2d: cout=%d must be a multiple of 4 and y/residual/bias 16-byte aligned (row-wise vector epilogue)", d->cout);
     MVF_REQUIRE((long)d->n * d->ho * d->wo < (1L << 31) && (long)d->n * d->h * d->w < (1L << 31), MVF_ESHAPE, "conv2d: too many pixels");
     ConvArgs a = {};
     a.x = (const char*)x; a.x2 = (const char*)x2; a.w = (const char*)w_packed; a.res = (const char*)residual;
