@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--streams", type=int, default=2, help="independent clip-group launch chains (HIP streams)")
     ap.add_argument("--per-layer", action="store_true", help="print a per-conv-launch timing table to stderr")
     return ap.parse_args()
 
@@ -186,6 +187,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     model = build_model(args.depth, args.dtype)
+    model.backbone.engine().streams = args.streams
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     imgs = torch.randn(args.clips, T_FRAMES, 3, SIZE, SIZE, device="cuda", generator=gen)
 

@@ -170,11 +170,51 @@ class BackboneEngine(object):
             k += len(getattr(resnet, name))
             self.stage_ends.append(k)
 
-    def forward(self, x_nchw, stages=None):
-        """x_nchw: (NT, 3, H, W) fp32 contiguous on the GPU -> features (NT, h, w, 2048) channels-last buffer."""
+    def forward(self, x_nchw, stages=None, n_segment=None):
+        """x_nchw: (NT, 3, H, W) fp32 contiguous on the GPU -> features (NT, h, w, 2048) channels-last buffer.
+
+        With `self.streams` > 1 (and no stage capture) the batch is cut into that many groups of whole clips, each
+        run as an independent launch chain on its own HIP stream: clips are independent units in eval mode, and
+        two chains in flight let one chain's kernels fill the CUs another chain's last (partial) wave of tiles
+        leaves idle."""
         if not x_nchw.is_cuda or x_nchw.dtype != torch.float32:
             raise RuntimeError("engine input must be a float32 GPU tensor (got %s on %s)" % (x_nchw.dtype, x_nchw.device))
         x_nchw = x_nchw.contiguous()
+        ns = getattr(self, "streams", 1)
+        T = n_segment or self._n_segment()
+        clips = x_nchw.shape[0] // max(T, 1)
+        if ns > 1 and stages is None and clips >= 2 * ns and x_nchw.shape[0] % T == 0:
+            return self._forward_multi(x_nchw, ns, T)
+        return self._forward_one(x_nchw, stages)
+
+    def _n_segment(self):
+        for b in self.blocks:
+            if b.mvf is not None:
+                return b.mvf.T
+        return 1
+
+    def _forward_multi(self, x, ns, T):
+        cur = torch.cuda.current_stream()
+        if not hasattr(self, "_pool") or len(self._pool) != ns:
+            self._pool = [torch.cuda.Stream() for _ in range(ns)]
+        clips = x.shape[0] // T
+        per = (clips + ns - 1) // ns
+        outs, parts = [], []
+        for i, st in enumerate(self._pool):
+            lo, hi = i * per * T, min((i + 1) * per, clips) * T
+            if lo >= hi:
+                continue
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                y = self._forward_one(x[lo:hi], None)
+                y.record_stream(cur)
+            parts.append((st, y))
+        for st, y in parts:
+            cur.wait_stream(st)
+            outs.append(y)
+        return torch.cat(outs, 0)
+
+    def _forward_one(self, x_nchw, stages=None):
         nt, cin, h, w = x_nchw.shape
         pad = self.stem.stem_pad
         hp, wp = h + 2 * pad, (w + 2 * pad + 2 + 1) // 2 * 2
