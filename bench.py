@@ -73,8 +73,13 @@ def conv_roofline(model, imgs, dtype, reps=3, per_layer=False):
         e1.record()
         y, ho, wo = out
         k_alg = 147 if self.kw == 1 and self.cin == 32 and self.kh == 7 else self.kh * self.kw * self.cin
+        esz = 4 if dtype == "f32" else 2
+        st = kw.get("stride") or self.stride
+        in_px = n * ho * wo if (self.kh == 1 and self.kw == 1 and st > 1) else n * h * w
+        nbytes = esz * (in_px * (c_total if self.kw == 1 and self.cin == 32 and self.kh == 7 else self.cin)
+                        + n * ho * wo * self.cout * (2 if kw.get("residual") is not None else 1) + self.wp.numel())
         records.append((e0, e1, 2.0 * n * ho * wo * self.cout * k_alg,
-                        "M%d N%d K%d k%dx%d s%d" % (n * ho * wo, self.cout, k_alg, self.kh, self.kw, kw.get("stride") or self.stride)))
+                        "M%d N%d K%d k%dx%d s%d" % (n * ho * wo, self.cout, k_alg, self.kh, self.kw, st), nbytes))
         return out
 
     E._Conv.run = timed
@@ -87,6 +92,7 @@ def conv_roofline(model, imgs, dtype, reps=3, per_layer=False):
             tot_ms += sum(r[0].elapsed_time(r[1]) for r in records)
             tot_flop += sum(r[2] for r in records)
             launches += len(records)
+            tot_bytes = sum(r[4] for r in records)
         if per_layer:
             agg = {}
             for r in records:
@@ -107,7 +113,8 @@ def conv_roofline(model, imgs, dtype, reps=3, per_layer=False):
         except Exception:
             traffic = None
     return {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "launches_per_step": launches // reps,
+            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "alg_bytes_per_launch": round(tot_bytes / (launches // reps)), "launches_per_step": launches // reps,
             "avg_launch_us": round(tot_ms * 1e3 / launches, 2), "flop_per_launch": round(tot_flop / launches),
             "conv_ms_per_step": round(tot_ms / reps, 3)}
 

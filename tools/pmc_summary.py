@@ -25,7 +25,7 @@ def main():
                 if not (kn and cn and cv):
                     continue
                 for row in rd:
-                    name = row[kn].split("(")[0]
+                    name = row[kn].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
                     a = acc[name][row[cn]]
                     a[0] += float(row[cv])
                     a[1] += 1
