@@ -110,6 +110,8 @@ typedef struct {
     int32_t relu;             /* apply ReLU in the epilogue                                          */
     int32_t split_c;          /* 0, or: channels [0, split_c) are read from x2 instead of x (the    */
     int32_t x2_pix_stride;    /*   compact MVF slice, pitch x2_pix_stride); 1x1 convs only           */
+    int32_t in_dil;           /* 0/1, or s > 1: x is read as if zero-upsampled by s (data-gradient of a       */
+                              /*   stride-s conv: y = dgrad needs stride == 1 here; ho,wo up to (h-1)*s+1+... ) */
 } mvf_conv_desc_t;
 
 int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
@@ -138,6 +140,69 @@ int mvf_head_pool_fc(const void* feat, int clips, int t, int hw, int c, const fl
                      int classes, float* pooled_ws, float* scores, int dtype, void* stream);
 /* average_clip (codes/models/recognizers/base.py:43-74): kind 0 = None (copy), 1 = 'score', 2 = 'prob'. */
 int mvf_average_clip(const float* scores, int clips, int classes, int kind, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training step (fp32 this round).  Mirrors, in order: Bottleneck.forward with batch-statistics BatchNorm2d
+ * (codes/models/backbones/resnet.py:208-244; torch defaults momentum 0.1, eps from norm.py:59), its autograd
+ * backward, TSNClsHead.forward + BaseHead.loss (heads/tsn_clshead.py:71-98, heads/base.py:40-45) and
+ * DistOptimizerHook.after_train_iter (core/dist_utils.py:61-67: backward, all-reduce/world, clip_grad_norm_(40),
+ * SGD-nesterov step; optimizer cfg mvf_kinetics400_2d_rgb_r50_dense.py:152-154).
+ * All tensors are channels-last matrices [m][c] (m = n*h*w), c % 4 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+size_t mvf_bn_workspace_bytes(long m, int c);
+/* batch mean / biased var of z over m -> save_mean, save_invstd, scale = gamma*invstd, shift = beta - mean*scale;
+ * running_mean/var updated in place (unbiased var).  Shifted single-pass sums (shift = old running_mean). */
+int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
+                       float* shift, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* out = act(z*scale + shift [+ residual | + residual*rscale + rshift]); act: 0 none, 1 ReLU, 2 hard-swish */
+int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
+                 const float* rscale, const float* rshift, int act, void* out, int dtype, void* stream);
+/* gm = g * act'(.) ; dbeta = sum gm ; dgamma = sum gm * xhat.  mask_mode: 0 none, 1 ReLU via ymask > 0 (ymask = the
+ * forward output), 2 ReLU via scale*z+shift > 0, 3 hard-swish'(scale*z+shift).  g rows are g_pitch apart (>= c).
+ * gm_out (optional, pitch c) receives gm. */
+int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* mean,
+                      const float* invstd, const float* scale, const float* shift, int mask_mode, void* gm_out,
+                      float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* dz = gamma*invstd*(gm - dbeta/m - xhat*dgamma/m), gm recomputed from g with mask_mode 0 / 2 / 3 */
+int mvf_bn_bwd_apply(const void* g, int g_pitch, const void* z, long m, int c, const float* gamma, const float* mean,
+                     const float* invstd, const float* scale, const float* shift, const float* dgamma,
+                     const float* dbeta, int mask_mode, void* dz, int dtype, void* stream);
+/* stem: y = maxpool3x3/2(relu(z*scale+shift)) and its backward w.r.t. relu(bn(z)) (resnet.py:482-484) */
+int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,
+                            int dtype, void* stream);
+int mvf_maxpool_bn_relu_bwd(const void* z, const void* g, int n, int h, int w, int c, const float* scale,
+                            const float* shift, void* ga, int dtype, void* stream);
+/* head: avg-pool per frame -> new_fc -> mean over the clip's t frames -> cross-entropy (mean over clips).
+ * pooled (clips*t, c), scores (clips, classes), dscores = dloss/dscores, loss_part (clips), loss (1): all fp32. */
+int mvf_head_train_fwd(const void* feat, int clips, int t, int hw, int c, const float* fc_w, const float* fc_b, int classes,
+                       const long long* labels, const float* drop_mask /* (clips*t, c) pre-scaled keep mask or NULL */,
+                       float* pooled, float* scores, float* dscores, float* loss_part, float* loss, int dtype, void* stream);
+int mvf_head_train_bwd(const float* dscores, const float* pooled, const float* fc_w, const float* drop_mask, int clips, int t,
+                       int hw, int c, int classes, float* dfc_w, float* dfc_b, float* dpool_ws /* clips*c */, void* dfeat, int dtype,
+                       void* stream);
+/* conv weight gradient dw_oihw (cout, cin_real, kh, kw_real) fp32; d describes the FORWARD conv (x dims, ho/wo = dz dims).
+ * kw_packed*cin_packed == d->kw*d->cin; they differ from (kw_real, cin_real) only for the stem view (8x4 vs 7x3). */
+size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d);
+int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real,
+                          int cin_real, int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes,
+                          void* stream);
+/* data gradient = mvf_conv2d_nhwc_fwd on dz with these weights: packed[ci][kh'][kw'][co] = w[co][ci][KH-1-kh'][KW-1-kw'],
+ * pad' = k-1-pad, stride 1, in_dil = forward stride */
+int mvf_pack_conv_weight_dgrad(const float* w_oihw, int cout, int cin, int kh, int kw, void* w_packed, int dtype,
+                               void* stream);
+/* MVF training primitives, channels-last (the engine composes MVF fwd/bwd from these + the BN calls above) */
+int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t,
+                     const float* w_h, const float* w_w, const float* scale, const float* shift, int flip, void* stream);
+size_t mvf_nhwc_tapgrad_workspace_bytes(const mvf_desc_t* d);
+int mvf_nhwc_tapgrad(const mvf_desc_t* d, const void* x, int x_c, const void* dy, int dy_c, float* dw_t, float* dw_h,
+                     float* dw_w, void* ws, size_t ws_bytes, void* stream);
+/* clip_grad_norm_(max_norm) on grad_scale*grads, then torch.optim.SGD(nesterov) on flat fp32 buffers.
+ * norm_out[0] = total norm, norm_out[1] = clip coefficient. */
+size_t mvf_sgd_workspace_bytes(long n);
+int mvf_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, long n, float grad_scale, float max_norm,
+                          float lr, float momentum, float weight_decay, int first_step, float* norm_out, void* ws,
+                          size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

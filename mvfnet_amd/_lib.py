@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("ho", C.c_int32), ("wo", C.c_int32), ("x_pix_stride", C.c_int32),
-                ("dtype", C.c_int32), ("relu", C.c_int32), ("split_c", C.c_int32), ("x2_pix_stride", C.c_int32)]
+                ("dtype", C.c_int32), ("relu", C.c_int32), ("split_c", C.c_int32), ("x2_pix_stride", C.c_int32), ("in_dil", C.c_int32)]
 
 
 def _load():
@@ -68,6 +68,41 @@ def _load():
     lib.mvf_head_pool_fc.argtypes = [vp, i32, i32, i32, i32, fp, fp, i32, fp, fp, i32, vp]
     lib.mvf_average_clip.restype = i32
     lib.mvf_average_clip.argtypes = [fp, i32, i32, i32, fp, vp]
+    i64, ll = C.c_long, C.c_void_p
+    lib.mvf_bn_workspace_bytes.restype = sz
+    lib.mvf_bn_workspace_bytes.argtypes = [i64, i32]
+    lib.mvf_bn_train_stats.restype = i32
+    lib.mvf_bn_train_stats.argtypes = [vp, i64, i32, fp, fp, f32, f32, fp, fp, fp, fp, fp, fp, vp, sz, i32, vp]
+    lib.mvf_bn_apply.restype = i32
+    lib.mvf_bn_apply.argtypes = [vp, i64, i32, fp, fp, vp, fp, fp, i32, vp, i32, vp]
+    lib.mvf_bn_bwd_reduce.restype = i32
+    lib.mvf_bn_bwd_reduce.argtypes = [vp, i32, vp, vp, i64, i32, fp, fp, fp, fp, i32, vp, fp, fp, vp, sz, i32, vp]
+    lib.mvf_bn_bwd_apply.restype = i32
+    lib.mvf_bn_bwd_apply.argtypes = [vp, i32, vp, i64, i32, fp, fp, fp, fp, fp, fp, fp, i32, vp, i32, vp]
+    lib.mvf_maxpool_bn_relu_fwd.restype = i32
+    lib.mvf_maxpool_bn_relu_fwd.argtypes = [vp, i32, i32, i32, i32, fp, fp, vp, i32, vp]
+    lib.mvf_maxpool_bn_relu_bwd.restype = i32
+    lib.mvf_maxpool_bn_relu_bwd.argtypes = [vp, vp, i32, i32, i32, i32, fp, fp, vp, i32, vp]
+    lib.mvf_head_train_fwd.restype = i32
+    lib.mvf_head_train_fwd.argtypes = [vp, i32, i32, i32, i32, fp, fp, i32, ll, fp, fp, fp, fp, fp, fp, i32, vp]
+    lib.mvf_head_train_bwd.restype = i32
+    lib.mvf_head_train_bwd.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, fp, fp, fp, vp, i32, vp]
+    lib.mvf_conv2d_wgrad_workspace_bytes.restype = sz
+    lib.mvf_conv2d_wgrad_workspace_bytes.argtypes = [cp]
+    lib.mvf_conv2d_nhwc_wgrad.restype = i32
+    lib.mvf_conv2d_nhwc_wgrad.argtypes = [cp, vp, vp, vp, i32, i32, i32, i32, fp, vp, sz, vp]
+    lib.mvf_pack_conv_weight_dgrad.restype = i32
+    lib.mvf_pack_conv_weight_dgrad.argtypes = [fp, i32, i32, i32, i32, vp, i32, vp]
+    lib.mvf_nhwc_stencil.restype = i32
+    lib.mvf_nhwc_stencil.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, fp, fp, i32, vp]
+    lib.mvf_nhwc_tapgrad_workspace_bytes.restype = sz
+    lib.mvf_nhwc_tapgrad_workspace_bytes.argtypes = [dp]
+    lib.mvf_nhwc_tapgrad.restype = i32
+    lib.mvf_nhwc_tapgrad.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, vp, sz, vp]
+    lib.mvf_sgd_workspace_bytes.restype = sz
+    lib.mvf_sgd_workspace_bytes.argtypes = [i64]
+    lib.mvf_sgd_nesterov_step.restype = i32
+    lib.mvf_sgd_nesterov_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, f32, i32, fp, vp, sz, vp]
     return lib
 
 

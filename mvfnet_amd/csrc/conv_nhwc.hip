@@ -47,6 +47,7 @@ struct ConvArgs {
     char* y;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int xps, split_c, x2ps, relu;
+    int dil;       // input dilation (dgrad of a strided conv: the gradient map is read as if zero-upsampled)
     int M;
     int cpt;       // chunks per tap = ceil(Cin*esz / 128)
     int nchunks;   // KH*KW*cpt
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
             const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
             a_ih0[i] = oh * a.stride - a.pad;
             a_iw0[i] = ow * a.stride - a.pad;
-            a_pix0[i] = (img * a.H + a_ih0[i]) * a.W + a_iw0[i];
+            a_pix0[i] = a.dil > 1 ? img * a.H * a.W : (img * a.H + a_ih0[i]) * a.W + a_iw0[i];
         } else {
             a_ih0[i] = -100000;   // never in bounds
             a_iw0[i] = -100000;
@@ -128,12 +129,24 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
         const int ps = from2 ? a.x2ps : a.xps;
 #pragma unroll
         for (int i = 0; i < A_ROWS_PT; ++i) {
-            const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-            const bool ok = cok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
+            int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
             ra[i] = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const long pix = (long)a_pix0[i] + kh * a.W + kw;
-                ra[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
+            if (a.dil > 1) {
+                // zero-upsampled view: only positions that are multiples of dil carry data
+                bool ok = cok && ih >= 0 && iw >= 0 && (ih % a.dil == 0) && (iw % a.dil == 0);
+                ih /= a.dil;
+                iw /= a.dil;
+                ok = ok && ih < a.H && iw < a.W;
+                if (ok) {
+                    const long pix = (long)a_pix0[i] + ih * a.W + iw;
+                    ra[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
+                }
+            } else {
+                const bool ok = cok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
+                if (ok) {
+                    const long pix = (long)a_pix0[i] + kh * a.W + kw;
+                    ra[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
+                }
             }
         }
         const long koff = ((long)(kh * a.KW + kw) * a.Cin + cc * CE) * ESZ;
@@ -316,7 +329,9 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
                     d->stride > 0 && d->pad >= 0, MVF_ESHAPE, "conv2d: bad dims");
-    const int ho = (d->h + 2 * d->pad - d->kh) / d->stride + 1, wo = (d->w + 2 * d->pad - d->kw) / d->stride + 1;
+    const int dil = d->in_dil > 1 ? d->in_dil : 1;
+    MVF_REQUIRE(dil == 1 || d->stride == 1, MVF_EINVAL, "conv2d: in_dil > 1 requires stride 1");
+    const int ho = ((d->h - 1) * dil + 1 + 2 * d->pad - d->kh) / d->stride + 1 + (dil - 1), wo = ((d->w - 1) * dil + 1 + 2 * d->pad - d->kw) / d->stride + 1 + (dil - 1);
     MVF_REQUIRE(d->ho > 0 && d->wo > 0 && d->ho <= ho && d->wo <= wo, MVF_ESHAPE,
                 "conv2d: ho,wo = %d,%d inconsistent with input %dx%d k%dx%d s%d p%d (max %d,%d)", d->ho, d->wo, d->h,
                 d->w, d->kh, d->kw, d->stride, d->pad, ho, wo);
@@ -340,7 +355,7 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
     a.bias = bias; a.y = (char*)y;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw;
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->ho; a.Wo = d->wo; a.xps = d->x_pix_stride;
-    a.split_c = d->split_c; a.x2ps = d->x2_pix_stride; a.relu = d->relu;
+    a.split_c = d->split_c; a.x2ps = d->x2_pix_stride; a.relu = d->relu; a.dil = dil;
     a.M = d->n * d->ho * d->wo;
     a.cpt = (d->cin + ce - 1) / ce;
     a.nchunks = d->kh * d->kw * a.cpt;

@@ -32,6 +32,7 @@ struct NhwcArgs {
     int pixw;      // pixels per workgroup
     int bands;     // workgroups per clip along pixels
     int out_c;     // channel pitch of `out` (c for a full tensor, cs for a compact slice buffer)
+    int flip;      // use taps reversed (transposed stencil: the data-gradient of the views)
 };
 
 template <typename ET, int VEC>
@@ -65,9 +66,10 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply(NhwcArgs a) {
     for (int i = 0; i < VEC; ++i) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            wt[i][j] = a.wt[(c0 + i) * 3 + j];
-            wh[i][j] = vh ? a.wh[(c0 + i) * 3 + j] : 0.f;
-            ww[i][j] = vw ? a.ww[(c0 + i) * 3 + j] : 0.f;
+            const int js = a.flip ? 2 - j : j;
+            wt[i][j] = a.wt[(c0 + i) * 3 + js];
+            wh[i][j] = vh ? a.wh[(c0 + i) * 3 + js] : 0.f;
+            ww[i][j] = vw ? a.ww[(c0 + i) * 3 + js] : 0.f;
         }
         sc[i] = hs ? a.scale[c0 + i] : 1.f;
         sh[i] = hs ? a.shift[c0 + i] : 0.f;
@@ -136,8 +138,9 @@ __global__ void copy_tail_nhwc(const ET* src, ET* dst, long npix, int c, int cs)
 size_t mvf_nhwc_ws_fwd_train(const mvf_desc_t*) { return 256; }
 size_t mvf_nhwc_ws_bwd(const mvf_desc_t*) { return 256; }
 
-int mvf_nhwc_fwd_infer_impl(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
-                            const float* ww, const float* scale, const float* shift, hipStream_t st) {
+struct NhwcFlip { int flip; };
+int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
+                             const float* ww, const float* scale, const float* shift, NhwcFlip fl, hipStream_t st) {
     // In-place hazard: a workgroup re-reads neighbour pixels that another workgroup may already have overwritten.
     MVF_REQUIRE(x != out, MVF_EINVAL,
                 "mvf_fwd_infer(NHWC): in-place is not supported in this layout (neighbour pixels are re-read from "
@@ -147,6 +150,7 @@ int mvf_nhwc_fwd_infer_impl(const mvf_desc_t* d, const void* x, void* out, int o
     a.nt = d->nt; a.c = d->c; a.h = d->h; a.w = d->w; a.T = d->n_segment; a.cs = d->cs; a.mode = d->mode;
     a.n_clips = d->nt / d->n_segment;
     a.out_c = out_c;
+    a.flip = fl.flip;
     const int esz = d->dtype == MVF_F32 ? 4 : 2;
     const bool vec = (d->cs % 4 == 0) && (d->c % 4 == 0) && (out_c % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % (4 * esz) == 0);
     a.cg = vec ? d->cs / 4 : d->cs;
@@ -181,6 +185,12 @@ int mvf_nhwc_fwd_infer_impl(const mvf_desc_t* d, const void* x, void* out, int o
     return MVF_OK;
 }
 
+int mvf_nhwc_fwd_infer_impl(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
+                            const float* ww, const float* scale, const float* shift, hipStream_t st) {
+    NhwcFlip f = {0};
+    return mvf_nhwc_fwd_infer_impl2(d, x, out, out_c, wt, wh, ww, scale, shift, f, st);
+}
+
 int mvf_nhwc_fwd_infer(const mvf_desc_t* d, const void* x, void* out, const float* wt, const float* wh,
                        const float* ww, const float* scale, const float* shift, hipStream_t st) {
     return mvf_nhwc_fwd_infer_impl(d, x, out, d->c, wt, wh, ww, scale, shift, st);
@@ -198,3 +208,130 @@ int mvf_nhwc_bwd(const mvf_desc_t*, const void*, const void*, const float*, cons
     mvf_set_error("mvf_bwd: NHWC layout not implemented yet (use MVF_NCHW)");
     return MVF_EUNSUPPORTED;
 }
+
+namespace {
+
+// 7 distinct tap-gradient sums per channel: dw[j] = sum_p dy[p] * s[p + (j-1)] for the t/h/w views (centre shared).
+// thread = (pixel lane, 4 channels); t slides in registers for s; partials [block][c][7] reduced by a second kernel.
+template <typename ET>
+__global__ __launch_bounds__(kThreads) void mvf_nhwc_tapgrad_kernel(const ET* x, int x_c, const ET* dy, int dy_c, int nt, int h, int w, int T,
+                                                                    int cs, int cgp, int pixw, int bands, float* part) {
+    __shared__ float4 red[kThreads];
+    const int HW = h * w;
+    const int n = blockIdx.x / bands, band = blockIdx.x % bands;
+    const int cgi = blockIdx.y * cgp + (threadIdx.x % cgp);
+    const int plane = threadIdx.x / cgp, nplanes = kThreads / cgp;
+    const bool ok = cgi * 4 < cs;
+    const int c0 = cgi * 4;
+    float4 s[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pend = min(HW, (band + 1) * pixw);
+    if (ok) {
+        for (int pix = band * pixw + plane; pix < pend; pix += nplanes) {
+            const int hh = pix / w, wv = pix - hh * w;
+            const long p0 = (long)n * T * HW + pix;
+            float4 xprev = make_float4(0.f, 0.f, 0.f, 0.f), xcur = ld4(x + p0 * x_c + c0), xnext;
+            for (int t = 0; t < T; ++t) {
+                const long pp = p0 + (long)t * HW;
+                const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+                xnext = (t + 1 < T) ? ld4(x + (pp + HW) * x_c + c0) : zero;
+                const float4 xup = hh > 0 ? ld4(x + (pp - w) * x_c + c0) : zero;
+                const float4 xdn = hh < h - 1 ? ld4(x + (pp + w) * x_c + c0) : zero;
+                const float4 xlf = wv > 0 ? ld4(x + (pp - 1) * x_c + c0) : zero;
+                const float4 xrt = wv < w - 1 ? ld4(x + (pp + 1) * x_c + c0) : zero;
+                const float4 d = ld4(dy + pp * dy_c + c0);
+#define ACC(k, v) s[k].x += d.x * v.x; s[k].y += d.y * v.y; s[k].z += d.z * v.z; s[k].w += d.w * v.w;
+                ACC(0, xprev) ACC(1, xnext) ACC(2, xup) ACC(3, xdn) ACC(4, xlf) ACC(5, xrt) ACC(6, xcur)
+#undef ACC
+                xprev = xcur;
+                xcur = xnext;
+            }
+        }
+    }
+    // reduce over the pixel lanes (planes) of the block, one accumulator at a time
+    for (int i = 0; i < 7; ++i) {
+        __syncthreads();
+        red[threadIdx.x] = s[i];
+        __syncthreads();
+        if (plane == 0 && ok) {
+            float4 tsum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < nplanes; ++r) {
+                const float4 v = red[r * cgp + (threadIdx.x % cgp)];
+                tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
+            }
+            float* p = part + ((long)blockIdx.x * cs + c0) * 7;
+            p[i] = tsum.x; p[7 + i] = tsum.y; p[14 + i] = tsum.z; p[21 + i] = tsum.w;
+        }
+    }
+}
+
+__global__ void mvf_tapgrad_finalize_kernel(const float* part, int nblk, int cs, int mode, float* dwt, float* dwh, float* dww) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cs) return;
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nblk; ++b)
+        for (int i = 0; i < 7; ++i) s[i] += part[((long)b * cs + c) * 7 + i];
+    dwt[c * 3 + 0] = (float)s[0]; dwt[c * 3 + 1] = (float)s[6]; dwt[c * 3 + 2] = (float)s[1];
+    if (dwh) { const bool on = mode & MVF_VIEW_H; dwh[c * 3 + 0] = on ? (float)s[2] : 0.f; dwh[c * 3 + 1] = on ? (float)s[6] : 0.f; dwh[c * 3 + 2] = on ? (float)s[3] : 0.f; }
+    if (dww) { const bool on = mode & MVF_VIEW_W; dww[c * 3 + 0] = on ? (float)s[4] : 0.f; dww[c * 3 + 1] = on ? (float)s[6] : 0.f; dww[c * 3 + 2] = on ? (float)s[5] : 0.f; }
+}
+
+struct TapPlan { int cgp, pixw, bands, gy; };
+TapPlan tap_plan(int n_clips, int hw, int cs) {
+    TapPlan p;
+    const int cg = cs / 4;
+    int cgp = 1;
+    while (cgp < cg && cgp < kThreads) cgp <<= 1;
+    p.cgp = cgp;
+    const int nplanes = kThreads / cgp;
+    int pixw = std::max(nplanes * 8, 1);
+    while ((long)n_clips * ((hw + pixw - 1) / pixw) > 2048 && pixw < hw) pixw *= 2;
+    p.pixw = std::min(pixw, hw);
+    p.bands = (hw + p.pixw - 1) / p.pixw;
+    p.gy = (cg + cgp - 1) / cgp;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Engine primitive (channels-last): out[..., :cs] (pitch out_c) = f( stencil_{T,H,W}( x[..., :cs] (pitch x_c) ) ),
+// f = hswish(scale*y+shift) when scale != NULL else identity; flip != 0 uses reversed taps (the transposed stencil,
+// i.e. the data-gradient of the three views).  x and out must not alias.
+int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
+                     const float* w_w, const float* scale, const float* shift, int flip, void* stream) {
+    MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs, MVF_EINVAL, "nhwc_stencil: bad argument");
+    mvf_desc_t dd = *d;
+    dd.c = x_c;
+    NhwcFlip f = {flip};
+    return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, scale, shift, f, (hipStream_t)stream);
+}
+
+size_t mvf_nhwc_tapgrad_workspace_bytes(const mvf_desc_t* d) {
+    if (!d || d->cs <= 0 || d->cs % 4) return 0;
+    TapPlan p = tap_plan(d->nt / d->n_segment, d->h * d->w, d->cs);
+    return align_up((size_t)(d->nt / d->n_segment) * p.bands * d->cs * 7 * sizeof(float), 256);
+}
+
+// dw_t/dw_h/dw_w [cs][3] = tap gradients of the three views given dy (pitch dy_c) and the forward input x (pitch x_c)
+int mvf_nhwc_tapgrad(const mvf_desc_t* d, const void* x, int x_c, const void* dy, int dy_c, float* dw_t, float* dw_h, float* dw_w,
+                     void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && x && dy && dw_t && d->cs % 4 == 0 && x_c % 4 == 0 && dy_c % 4 == 0, MVF_EINVAL, "nhwc_tapgrad: bad argument (cs %% 4?)");
+    MVF_REQUIRE(ws && ws_bytes >= mvf_nhwc_tapgrad_workspace_bytes(d), MVF_EWS, "nhwc_tapgrad: workspace too small");
+    const int n_clips = d->nt / d->n_segment;
+    TapPlan p = tap_plan(n_clips, d->h * d->w, d->cs);
+    dim3 grid(n_clips * p.bands, p.gy);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == MVF_F32)
+        hipLaunchKernelGGL(mvf_nhwc_tapgrad_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)x, x_c, (const float*)dy, dy_c, d->nt, d->h, d->w, d->n_segment, d->cs, p.cgp, p.pixw, p.bands, (float*)ws);
+    else
+        hipLaunchKernelGGL(mvf_nhwc_tapgrad_kernel<bf16_t>, grid, dim3(kThreads), 0, st, (const bf16_t*)x, x_c, (const bf16_t*)dy, dy_c, d->nt, d->h, d->w, d->n_segment, d->cs, p.cgp, p.pixw, p.bands, (float*)ws);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mvf_tapgrad_finalize_kernel, dim3((d->cs + 63) / 64), dim3(64), 0, st, (const float*)ws, n_clips * p.bands, d->cs, d->mode, dw_t, dw_h, dw_w);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,611 @@
+// Training-mode companions of the conv stack (all HBM-bound, channels-last [M][C] matrices):
+// batch-statistics BatchNorm forward/backward, residual/ReLU, max-pool fwd/bwd, TSN head + cross-entropy fwd/bwd,
+// clip-norm + SGD-nesterov.  Reference semantics: torch BatchNorm2d defaults (biased var to normalise, unbiased into
+// running_var, momentum 0.1; codes/models/common/norm.py:59 sets eps), Bottleneck.forward
+// (codes/models/backbones/resnet.py:208-244), TSNClsHead.forward + BaseHead.loss (heads/tsn_clshead.py:71-98,
+// heads/base.py:40-45), DistOptimizerHook.after_train_iter (core/dist_utils.py:61-67) with SGD(nesterov)
+// (configs/.../mvf_kinetics400_2d_rgb_r50_dense.py:152-154).
+//
+// Reductions over M are two-stage and atomic-free: per-block column partials [blocks][C][k] in fp32, then a
+// finalize kernel that sums them in fp64 in block order -> deterministic run to run.
+#include <algorithm>
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct ColPlan {
+    int cqb;     // channel quads handled by one block (threads along channels)
+    int rl;      // row lanes = 256 / cqb
+    int gx;      // blocks along channels
+    int gy;      // blocks along rows
+    int rows;    // rows per block
+};
+
+ColPlan col_plan(long M, int C) {
+    ColPlan p;
+    const int cq = C / 4;
+    int cqb = 1;
+    while (cqb < cq && cqb < 64) cqb <<= 1;
+    p.cqb = cqb;
+    p.rl = kThreads / cqb;
+    p.gx = (cq + cqb - 1) / cqb;
+    long want = std::max<long>(1, 2048 / p.gx);                  // ~2048 blocks in total
+    long rows = std::max<long>((M + want - 1) / want, (long)p.rl * 8);
+    rows = (rows + p.rl - 1) / p.rl * p.rl;
+    p.rows = (int)rows;
+    p.gy = (int)((M + rows - 1) / rows);
+    return p;
+}
+
+// reduce NV float4 accumulators over the row lanes of a block; result valid in row lane 0
+template <int NV>
+__device__ __forceinline__ void rowlane_reduce(float4 (&v)[NV], int cqb, int rl, float4* red) {
+    const int cq = threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[(i * rl + lane_r) * cqb + cq] = v[i];
+    __syncthreads();
+    if (lane_r == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < rl; ++r) {
+                const float4 t = red[(i * rl + r) * cqb + cq];
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            v[i] = s;
+        }
+    }
+}
+
+// ---- BN forward statistics: shifted sums  S1 = sum(z-K), S2 = sum((z-K)^2), K = running_mean (any K is exact) ----
+template <typename ET>
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const ET* z, long M, int C, const float* kshift, int cqb, int rows,
+                                                            float* part) {
+    __shared__ float4 red[2 * kThreads];
+    const int rl = kThreads / cqb;
+    const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
+    const bool ok = cq * 4 < C;
+    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && kshift) k4 = *reinterpret_cast<const float4*>(kshift + cq * 4);
+    float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
+    if (ok) {
+        for (long r = r0 + lane_r; r < r1; r += rl) {
+            float4 a = ld4(z + r * C + cq * 4);
+            a.x -= k4.x; a.y -= k4.y; a.z -= k4.z; a.w -= k4.w;
+            v[0].x += a.x; v[0].y += a.y; v[0].z += a.z; v[0].w += a.w;
+            v[1].x += a.x * a.x; v[1].y += a.y * a.y; v[1].z += a.z * a.z; v[1].w += a.w * a.w;
+        }
+    }
+    rowlane_reduce<2>(v, cqb, rl, red);
+    if (ok && lane_r == 0) {
+        float* p = part + ((long)blockIdx.y * C + cq * 4) * 2;
+        p[0] = v[0].x; p[1] = v[1].x; p[2] = v[0].y; p[3] = v[1].y; p[4] = v[0].z; p[5] = v[1].z; p[6] = v[0].w; p[7] = v[1].w;
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(int C, int nblk, long M, const float* part, const float* gamma, const float* beta,
+                                         float eps, float momentum, float* running_mean, float* running_var,
+                                         float* save_mean, float* save_invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += part[((long)b * C + c) * 2];
+        s2 += part[((long)b * C + c) * 2 + 1];
+    }
+    const double K = running_mean ? (double)running_mean[c] : 0.0;
+    const double d = s1 / (double)M;
+    const double mean = K + d;
+    double var = s2 / (double)M - d * d;
+    if (var < 0.0) var = 0.0;
+    const float invstd = 1.0f / sqrtf((float)var + eps);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    const float s = gamma[c] * invstd;
+    scale[c] = s;
+    shift[c] = beta[c] - (float)mean * s;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (double)M / (double)(M > 1 ? M - 1 : 1));
+}
+
+// ---- BN apply (+ residual) (+ ReLU):  out = act(z*scale + shift [+ r] [+ r*rscale + rshift]) ----
+template <typename ET>
+__global__ void bn_apply_kernel(const ET* z, long M, int C, const float* scale, const float* shift, const ET* r,
+                                const float* rscale, const float* rshift, int relu, ET* out) {
+    const int cq4 = C / 4;
+    const long total = M * cq4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % cq4);
+        const float4 s = *reinterpret_cast<const float4*>(scale + cq * 4), b = *reinterpret_cast<const float4*>(shift + cq * 4);
+        float4 v = ld4(z + i * 4);
+        v.x = v.x * s.x + b.x; v.y = v.y * s.y + b.y; v.z = v.z * s.z + b.z; v.w = v.w * s.w + b.w;
+        if (r) {
+            float4 q = ld4(r + i * 4);
+            if (rscale) {
+                const float4 rs = *reinterpret_cast<const float4*>(rscale + cq * 4), rb = *reinterpret_cast<const float4*>(rshift + cq * 4);
+                q.x = q.x * rs.x + rb.x; q.y = q.y * rs.y + rb.y; q.z = q.z * rs.z + rb.z; q.w = q.w * rs.w + rb.w;
+            }
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (relu == 2) {   // hard-swish (MVF activation, se_module.py:5-24)
+            v.x = v.x * (fminf(fmaxf(v.x + 3.f, 0.f), 6.f) / 6.f); v.y = v.y * (fminf(fmaxf(v.y + 3.f, 0.f), 6.f) / 6.f);
+            v.z = v.z * (fminf(fmaxf(v.z + 3.f, 0.f), 6.f) / 6.f); v.w = v.w * (fminf(fmaxf(v.w + 3.f, 0.f), 6.f) / 6.f);
+        }
+        st4(out + i * 4, v);
+    }
+}
+
+// ---- BN backward reductions: gm = g * mask ; sums of gm and gm*xhat.  mask from y>0 (block output) or from
+// ---- scale*z+shift > 0 (recomputed ReLU of this BN's own output) or none.  Optionally writes gm. ----
+template <typename ET>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const ET* g, int g_pitch, const ET* z, const ET* ymask, long M, int C,
+                                                                 const float* mean, const float* invstd, const float* scale,
+                                                                 const float* shift, int mask_mode, ET* gm_out, int cqb, int rows,
+                                                                 float* part) {
+    __shared__ float4 red[2 * kThreads];
+    const int rl = kThreads / cqb;
+    const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
+    const bool ok = cq * 4 < C;
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, sc = mu, sh = mu;
+    if (ok) {
+        mu = *reinterpret_cast<const float4*>(mean + cq * 4);
+        rs = *reinterpret_cast<const float4*>(invstd + cq * 4);
+        if (mask_mode >= 2) {
+            sc = *reinterpret_cast<const float4*>(scale + cq * 4);
+            sh = *reinterpret_cast<const float4*>(shift + cq * 4);
+        }
+    }
+    float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
+    if (ok) {
+        for (long r = r0 + lane_r; r < r1; r += rl) {
+            const long o = r * C + cq * 4;
+            float4 gv = ld4(g + r * g_pitch + cq * 4);
+            const float4 zv = ld4(z + o);
+            if (mask_mode == 1) {
+                const float4 yv = ld4(ymask + o);
+                gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f; gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
+            } else if (mask_mode == 2) {
+                gv.x = (zv.x * sc.x + sh.x) > 0.f ? gv.x : 0.f; gv.y = (zv.y * sc.y + sh.y) > 0.f ? gv.y : 0.f;
+                gv.z = (zv.z * sc.z + sh.z) > 0.f ? gv.z : 0.f; gv.w = (zv.w * sc.w + sh.w) > 0.f ? gv.w : 0.f;
+            } else if (mask_mode == 3) {   // hard-swish derivative (MVF: o = hswish(bn(y)))
+                gv.x *= hswish_grad_f(zv.x * sc.x + sh.x); gv.y *= hswish_grad_f(zv.y * sc.y + sh.y);
+                gv.z *= hswish_grad_f(zv.z * sc.z + sh.z); gv.w *= hswish_grad_f(zv.w * sc.w + sh.w);
+            }
+            if (gm_out) st4(gm_out + o, gv);
+            v[0].x += gv.x; v[0].y += gv.y; v[0].z += gv.z; v[0].w += gv.w;
+            v[1].x += gv.x * ((zv.x - mu.x) * rs.x); v[1].y += gv.y * ((zv.y - mu.y) * rs.y);
+            v[1].z += gv.z * ((zv.z - mu.z) * rs.z); v[1].w += gv.w * ((zv.w - mu.w) * rs.w);
+        }
+    }
+    rowlane_reduce<2>(v, cqb, rl, red);
+    if (ok && lane_r == 0) {
+        float* p = part + ((long)blockIdx.y * C + cq * 4) * 2;
+        p[0] = v[0].x; p[1] = v[1].x; p[2] = v[0].y; p[3] = v[1].y; p[4] = v[0].z; p[5] = v[1].z; p[6] = v[0].w; p[7] = v[1].w;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(int C, int nblk, const float* part, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += part[((long)b * C + c) * 2];
+        s2 += part[((long)b * C + c) * 2 + 1];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+}
+
+// dz = gamma*invstd * (gm - dbeta/M - xhat*dgamma/M); gm = g*mask recomputed as above (mask_mode 0: g is already masked)
+template <typename ET>
+__global__ void bn_bwd_apply_kernel(const ET* g, int g_pitch, const ET* z, long M, int C, const float* gamma, const float* mean,
+                                    const float* invstd, const float* scale, const float* shift, const float* dgamma,
+                                    const float* dbeta, int mask_mode, ET* dz) {
+    const int cq4 = C / 4;
+    const long total = M * cq4;
+    const float inv_m = 1.0f / (float)M;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq4) * 4;
+        float gv[4], zv[4], o[4];
+        { float4 t = ld4(g + (i / cq4) * g_pitch + c); gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w; }
+        { float4 t = ld4(z + i * 4); zv[0] = t.x; zv[1] = t.y; zv[2] = t.z; zv[3] = t.w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gk = gv[k];
+            if (mask_mode == 2 && !((zv[k] * scale[c + k] + shift[c + k]) > 0.f)) gk = 0.f;
+            if (mask_mode == 3) gk *= hswish_grad_f(zv[k] * scale[c + k] + shift[c + k]);
+            const float xh = (zv[k] - mean[c + k]) * invstd[c + k];
+            o[k] = gamma[c + k] * invstd[c + k] * (gk - dbeta[c + k] * inv_m - xh * dgamma[c + k] * inv_m);
+        }
+        st4(dz + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// ---- max-pool 3x3/2 pad 1 over relu(bn(z)) (stem), forward and backward (argmax recomputed: first max in scan order) ----
+template <typename ET>
+__global__ void maxpool_bn_fwd_kernel(const ET* z, int n, int h, int w, int c, int ho, int wo, const float* scale,
+                                      const float* shift, ET* y) {
+    const int c4 = c >> 2;
+    const long total = (long)n * ho * wo * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % c4);
+        long t = i / c4;
+        const int ow = (int)(t % wo); t /= wo;
+        const int oh = (int)(t % ho);
+        const int img = (int)(t / ho);
+        const float4 s = *reinterpret_cast<const float4*>(scale + cq * 4), b = *reinterpret_cast<const float4*>(shift + cq * 4);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ih = oh * 2 - 1 + dy;
+            if (ih < 0 || ih >= h) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iw = ow * 2 - 1 + dx;
+                if (iw < 0 || iw >= w) continue;
+                float4 v = ld4(z + (((long)img * h + ih) * w + iw) * c + cq * 4);
+                v.x = fmaxf(v.x * s.x + b.x, 0.f); v.y = fmaxf(v.y * s.y + b.y, 0.f);
+                v.z = fmaxf(v.z * s.z + b.z, 0.f); v.w = fmaxf(v.w * s.w + b.w, 0.f);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        st4(y + (((long)img * ho + oh) * wo + ow) * c + cq * 4, m);
+    }
+}
+
+// ga[input pixel] = sum over the (<=4) windows containing it of g[window] * [this pixel is the window's first max];
+// gather form (no atomics): each input pixel re-evaluates the windows that cover it.
+template <typename ET>
+__global__ void maxpool_bn_bwd_kernel(const ET* z, const ET* g, int n, int h, int w, int c, int ho, int wo,
+                                      const float* scale, const float* shift, ET* ga) {
+    const long total = (long)n * h * w * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        long t = i / c;
+        const int iw = (int)(t % w); t /= w;
+        const int ih = (int)(t % h);
+        const int img = (int)(t / h);
+        const float s = scale[ch], b = shift[ch];
+        const ET* zi = z + (long)img * h * w * c + ch;
+        const float mine = fmaxf(ldf(zi + ((long)ih * w + iw) * c) * s + b, 0.f);
+        float acc = 0.f;
+        for (int oh = (ih + 1 - 2 + 1) / 2; oh <= (ih + 1) / 2; ++oh) {           // windows with oh*2-1 <= ih <= oh*2+1
+            if (oh < 0 || oh >= ho) continue;
+            for (int ow = (iw + 1 - 2 + 1) / 2; ow <= (iw + 1) / 2; ++ow) {
+                if (ow < 0 || ow >= wo) continue;
+                // find the first max of window (oh, ow) in scan order
+                float best = -INFINITY;
+                int bh = -1, bw = -1;
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int y2 = oh * 2 - 1 + dy;
+                    if (y2 < 0 || y2 >= h) continue;
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int x2 = ow * 2 - 1 + dx;
+                        if (x2 < 0 || x2 >= w) continue;
+                        const float v = fmaxf(ldf(zi + ((long)y2 * w + x2) * c) * s + b, 0.f);
+                        if (v > best) { best = v; bh = y2; bw = x2; }
+                    }
+                }
+                if (bh == ih && bw == iw) acc += ldf(g + (((long)img * ho + oh) * wo + ow) * c + ch);
+            }
+        }
+        (void)mine;
+        stf(ga + i, acc);
+    }
+}
+
+// ---- head: per-frame avg-pool -> fc -> mean over segments -> cross-entropy (mean over clips) ----
+// pooled[frame][ch] = mean over hw ; lanes along channels
+template <typename ET>
+__global__ void frame_pool_kernel(const ET* feat, int hw, int c, const float* drop_mask, float* pooled) {
+    const int f = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const ET* p = feat + (long)f * hw * c + ch;
+    float s = 0.f;
+    for (int r = 0; r < hw; ++r) s += ldf(p + (long)r * c);
+    s = s / (float)hw;
+    if (drop_mask) s *= drop_mask[(long)f * c + ch];      // nn.Dropout: mask already scaled by 1/(1-p) (tsn_clshead.py:86-87)
+    pooled[(long)f * c + ch] = s;
+}
+
+// one block per clip: softmax CE of scores[clip] against label; writes loss contribution and dscores = (p - onehot)/clips
+__global__ void ce_loss_kernel(const float* scores, const long long* labels, int clips, int classes, float* loss_part, float* dscores) {
+    __shared__ float red[256];
+    const int cl = blockIdx.x, tid = threadIdx.x;
+    const float* s = scores + (long)cl * classes;
+    float mx = -INFINITY;
+    for (int k = tid; k < classes; k += blockDim.x) mx = fmaxf(mx, s[k]);
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float e = 0.f;
+    for (int k = tid; k < classes; k += blockDim.x) e += expf(s[k] - mx);
+    red[tid] = e;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float den = red[0];
+    const int lab = (int)labels[cl];
+    if (tid == 0) loss_part[cl] = (logf(den) + mx) - s[lab];
+    for (int k = tid; k < classes; k += blockDim.x) {
+        const float p = expf(s[k] - mx) / den;
+        dscores[(long)cl * classes + k] = (p - (k == lab ? 1.f : 0.f)) / (float)clips;
+    }
+}
+
+__global__ void mean_reduce_kernel(const float* v, int n, float* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += v[i];
+        out[0] = (float)(s / n);
+    }
+}
+
+// dW[k][c] = sum_clip dscores[clip][k] * pooledclip[clip][c] ; db[k] = sum_clip dscores[clip][k]   (pooledclip = mean over T)
+__global__ void head_fc_bwd_w_kernel(const float* dscores, const float* pooled, int clips, int T, int c, int classes, float* dw, float* db) {
+    const int k = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < c) {
+        float s = 0.f;
+        for (int cl = 0; cl < clips; ++cl) {
+            float pc = 0.f;
+            for (int t = 0; t < T; ++t) pc += pooled[((long)cl * T + t) * c + ch];
+            s += dscores[(long)cl * classes + k] * (pc / (float)T);
+        }
+        dw[(long)k * c + ch] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int cl = 0; cl < clips; ++cl) s += dscores[(long)cl * classes + k];
+        db[k] = s;
+    }
+}
+
+// dfeat[frame][hw][ch] = (1/(T*hw)) * sum_k dscores[clip][k] * W[k][ch]
+__global__ void head_dpool_kernel(const float* dscores, const float* w, int classes, int c, float scale, float* dpool) {
+    const int cl = blockIdx.y, ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float s = 0.f;
+    for (int k = 0; k < classes; ++k) s += dscores[(long)cl * classes + k] * w[(long)k * c + ch];
+    dpool[(long)cl * c + ch] = s * scale;
+}
+template <typename ET>
+__global__ void head_dfeat_kernel(const float* dpool, const float* drop_mask, int T, int hw, int c, long total, ET* dfeat) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        const long frame = i / ((long)hw * c);
+        float v = dpool[(frame / T) * c + ch];
+        if (drop_mask) v *= drop_mask[frame * c + ch];
+        stf(dfeat + i, v);
+    }
+}
+
+// ---- optimizer: global grad norm (two-stage), then clip + weight decay + SGD nesterov on a flat fp32 buffer ----
+__global__ void sqsum_partial_kernel(const float* g, long n, float* part) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void norm_finalize_kernel(const float* part, int nblk, float max_norm, float gscale, float* out /*[0]=norm,[1]=coef*/) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nblk; ++i) s += part[i];
+        const float nrm = fabsf(gscale) * (float)sqrt(s);
+        out[0] = nrm;
+        float coef = max_norm > 0.f ? max_norm / (nrm + 1e-6f) : 1.f;     // torch clip_grad_norm_
+        out[1] = coef < 1.f ? coef : 1.f;
+    }
+}
+__global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, long n, const float* coef_ptr, float gscale, float lr,
+                                    float momentum, float wd, int first_step) {
+    const float coef = (coef_ptr ? coef_ptr[1] : 1.f) * gscale;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        const float d = g[i] * coef + wd * pv;
+        const float b = first_step ? d : momentum * buf[i] + d;
+        buf[i] = b;
+        p[i] = pv - lr * (d + momentum * b);
+    }
+}
+
+inline int grid_for(long total, int cap = 256 * 16) { return (int)std::min<long>((total + 255) / 256, cap); }
+
+}  // namespace
+
+extern "C" {
+
+size_t mvf_bn_workspace_bytes(long m, int c) {
+    if (m <= 0 || c <= 0 || c % 4) return 0;
+    ColPlan p = col_plan(m, c);
+    return align_up((size_t)p.gy * c * 2 * sizeof(float), 256);
+}
+
+int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
+                       float* shift, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    MVF_REQUIRE(z && gamma && beta && save_mean && save_invstd && scale && shift && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_train_stats: bad argument (c %% 4?)");
+    MVF_REQUIRE(ws && ws_bytes >= mvf_bn_workspace_bytes(m, c), MVF_EWS, "bn_train_stats: workspace too small");
+    ColPlan p = col_plan(m, c);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const float*)z, m, c, running_mean, p.cqb, p.rows, part);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const bf16_t*)z, m, c, running_mean, p.cqb, p.rows, part);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, st, c, p.gy, m, part, gamma, beta, eps, momentum,
+                       running_mean, running_var, save_mean, save_invstd, scale, shift);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
+                 const float* rscale, const float* rshift, int relu, void* out, int dtype, void* stream) {
+    MVF_REQUIRE(z && scale && shift && out && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_apply: bad argument");
+    MVF_REQUIRE((rscale == nullptr) == (rshift == nullptr), MVF_EINVAL, "bn_apply: rscale/rshift must come together");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = m * (c / 4);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)z, m, c, scale, shift, (const float*)residual, rscale, rshift, relu, (float*)out);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)z, m, c, scale, shift, (const bf16_t*)residual, rscale, rshift, relu, (bf16_t*)out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* mean, const float* invstd,
+                      const float* scale, const float* shift, int mask_mode, void* gm_out, float* dgamma, float* dbeta,
+                      void* ws, size_t ws_bytes, int dtype, void* stream) {
+    MVF_REQUIRE(g && z && mean && invstd && dgamma && dbeta && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_bwd_reduce: bad argument");
+    MVF_REQUIRE(mask_mode >= 0 && mask_mode <= 3 && (mask_mode != 1 || ymask) && (mask_mode < 2 || (scale && shift)) && g_pitch >= c && g_pitch % 4 == 0, MVF_EINVAL, "bn_bwd_reduce: bad mask_mode / pitch");
+    MVF_REQUIRE(ws && ws_bytes >= mvf_bn_workspace_bytes(m, c), MVF_EWS, "bn_bwd_reduce: workspace too small");
+    ColPlan p = col_plan(m, c);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const float*)g, g_pitch, (const float*)z, (const float*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (float*)gm_out, p.cqb, p.rows, part);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const bf16_t*)g, g_pitch, (const bf16_t*)z, (const bf16_t*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (bf16_t*)gm_out, p.cqb, p.rows, part);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, st, c, p.gy, part, dgamma, dbeta);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_bn_bwd_apply(const void* g, int g_pitch, const void* z, long m, int c, const float* gamma, const float* mean, const float* invstd,
+                     const float* scale, const float* shift, const float* dgamma, const float* dbeta, int mask_mode, void* dz,
+                     int dtype, void* stream) {
+    MVF_REQUIRE(g && z && gamma && mean && invstd && dgamma && dbeta && dz && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_bwd_apply: bad argument");
+    MVF_REQUIRE((mask_mode == 0 || ((mask_mode == 2 || mask_mode == 3) && scale && shift)) && g_pitch >= c && g_pitch % 4 == 0, MVF_EINVAL, "bn_bwd_apply: mask_mode must be 0, 2 or 3");
+    const long total = m * (c / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)g, g_pitch, (const float*)z, m, c, gamma, mean, invstd, scale, shift, dgamma, dbeta, mask_mode, (float*)dz);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)g, g_pitch, (const bf16_t*)z, m, c, gamma, mean, invstd, scale, shift, dgamma, dbeta, mask_mode, (bf16_t*)dz);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,
+                            int dtype, void* stream) {
+    MVF_REQUIRE(z && y && scale && shift && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool_bn_relu_fwd: bad argument");
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    const long total = (long)n * ho * wo * (c / 4);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (const float*)z, n, h, w, c, ho, wo, scale, shift, (float*)y);
+    else
+        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<bf16_t>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, n, h, w, c, ho, wo, scale, shift, (bf16_t*)y);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_maxpool_bn_relu_bwd(const void* z, const void* g, int n, int h, int w, int c, const float* scale, const float* shift,
+                            void* ga, int dtype, void* stream) {
+    MVF_REQUIRE(z && g && ga && scale && shift && n > 0 && h > 0 && w > 0 && c > 0, MVF_EINVAL, "maxpool_bn_relu_bwd: bad argument");
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    const long total = (long)n * h * w * c;
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(maxpool_bn_bwd_kernel<float>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (const float*)z, (const float*)g, n, h, w, c, ho, wo, scale, shift, (float*)ga);
+    else
+        hipLaunchKernelGGL(maxpool_bn_bwd_kernel<bf16_t>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (const bf16_t*)g, n, h, w, c, ho, wo, scale, shift, (bf16_t*)ga);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+// head, training: feat (clips*T, hw, c) -> pooled (clips*T, c) fp32 [kept for backward] -> scores (clips, classes) -> loss
+int mvf_head_train_fwd(const void* feat, int clips, int t, int hw, int c, const float* fc_w, const float* fc_b, int classes,
+                       const long long* labels, const float* drop_mask, float* pooled, float* scores, float* dscores, float* loss_part, float* loss,
+                       int dtype, void* stream);
+int mvf_head_train_bwd(const float* dscores, const float* pooled, const float* fc_w, const float* drop_mask, int clips, int t, int hw, int c, int classes,
+                       float* dfc_w, float* dfc_b, float* dpool_ws, void* dfeat, int dtype, void* stream);
+
+}  // extern "C"
+
+// frame-level fc + segment mean (training keeps per-frame pooled features for the weight gradient)
+namespace {
+__global__ void head_fc_seg_kernel(const float* pooled, const float* w, const float* b, int clips, int T, int c, int classes, float* scores) {
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (gw >= clips * classes) return;
+    const int clip = gw / classes, k = gw - clip * classes;
+    const float* wr = w + (long)k * c;
+    float tot = 0.f;
+    for (int t = 0; t < T; ++t) {                     // fc per frame, then consensus mean (tsn_clshead.py:92-96)
+        const float* p = pooled + ((long)clip * T + t) * c;
+        float s = 0.f;
+        for (int i = lane; i < c; i += 64) s += p[i] * wr[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        tot += s + (b ? b[k] : 0.f);
+    }
+    if (lane == 0) scores[gw] = tot / (float)T;
+}
+}  // namespace
+
+extern "C" {
+
+int mvf_head_train_fwd(const void* feat, int clips, int t, int hw, int c, const float* fc_w, const float* fc_b, int classes,
+                       const long long* labels, const float* drop_mask, float* pooled, float* scores, float* dscores, float* loss_part, float* loss,
+                       int dtype, void* stream) {
+    MVF_REQUIRE(feat && fc_w && labels && pooled && scores && dscores && loss_part && loss && clips > 0 && t > 0 && hw > 0 && c > 0 && classes > 0, MVF_EINVAL, "head_train_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g((c + 255) / 256, clips * t);
+    if (dtype == MVF_F32) hipLaunchKernelGGL(frame_pool_kernel<float>, g, dim3(256), 0, st, (const float*)feat, hw, c, drop_mask, pooled);
+    else hipLaunchKernelGGL(frame_pool_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)feat, hw, c, drop_mask, pooled);
+    MVF_LAUNCH_CHECK();
+    const long waves = (long)clips * classes;
+    hipLaunchKernelGGL(head_fc_seg_kernel, dim3((int)((waves * 64 + 255) / 256)), dim3(256), 0, st, pooled, fc_w, fc_b, clips, t, c, classes, scores);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(clips), dim3(256), 0, st, scores, labels, clips, classes, loss_part, dscores);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_reduce_kernel, dim3(1), dim3(64), 0, st, loss_part, clips, loss);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_head_train_bwd(const float* dscores, const float* pooled, const float* fc_w, const float* drop_mask, int clips, int t, int hw, int c, int classes,
+                       float* dfc_w, float* dfc_b, float* dpool_ws, void* dfeat, int dtype, void* stream) {
+    MVF_REQUIRE(dscores && pooled && fc_w && dfc_w && dfc_b && dpool_ws && dfeat, MVF_EINVAL, "head_train_bwd: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_fc_bwd_w_kernel, dim3((c + 255) / 256, classes), dim3(256), 0, st, dscores, pooled, clips, t, c, classes, dfc_w, dfc_b);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_dpool_kernel, dim3((c + 255) / 256, clips), dim3(256), 0, st, dscores, fc_w, classes, c, 1.0f / ((float)t * hw), dpool_ws);
+    MVF_LAUNCH_CHECK();
+    const long total = (long)clips * t * hw * c;
+    if (dtype == MVF_F32) hipLaunchKernelGGL(head_dfeat_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, dpool_ws, drop_mask, t, hw, c, total, (float*)dfeat);
+    else hipLaunchKernelGGL(head_dfeat_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, dpool_ws, drop_mask, t, hw, c, total, (bf16_t*)dfeat);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+// clip_grad_norm_(max_norm, L2) over the flat gradient, then p -= lr * (d + mom*buf), d = g*coef*gscale + wd*p, buf = mom*buf + d
+// (torch.optim.SGD nesterov; first_step: buf = d).  norm_out[0] = total norm (after gscale), norm_out[1] = clip coefficient.
+size_t mvf_sgd_workspace_bytes(long n) { return 1024 * sizeof(float); }
+
+int mvf_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, long n, float grad_scale, float max_norm,
+                          float lr, float momentum, float weight_decay, int first_step, float* norm_out, void* ws,
+                          size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(params && grads && momentum_buf && norm_out && n > 0, MVF_EINVAL, "sgd_nesterov_step: bad argument");
+    MVF_REQUIRE(ws && ws_bytes >= mvf_sgd_workspace_bytes(n), MVF_EWS, "sgd_nesterov_step: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    const int nb = (int)std::min<long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(sqsum_partial_kernel, dim3(nb), dim3(256), 0, st, grads, n, part);
+    MVF_LAUNCH_CHECK();
+    // the norm is of the scaled gradient (all-reduce sum / world happens before clipping, dist_utils.py:63-66)
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, st, part, nb, max_norm, grad_scale, norm_out);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n)), dim3(256), 0, st, params, grads, momentum_buf, n, norm_out, grad_scale, lr, momentum, weight_decay, first_step);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+}  // extern "C"

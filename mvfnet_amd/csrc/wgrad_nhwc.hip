@@ -1,0 +1,227 @@
+// Weight gradient of the channels-last conv as an MFMA GEMM with the contraction over pixels (fp32).
+//
+//   dW[co][kh][kw][ci] = sum_m dZ[m][co] * X[img(m)][oh(m)*s+kh-p][ow(m)*s+kw-p][ci]        (zero outside the image)
+//
+// GEMM view: C[co][kcol] += A^T B with A = dZ [M][Cout], B = im2col(X) [M][K], K = KH*KW*Cin, contraction over m.
+// Both operands are "m-major" in memory (rows of Cout / Cin contiguous channels), which is exactly what the fp32
+// MFMA wants here: for v_mfma_f32_32x32x2_f32 lane l supplies A[i = l&31][k = l>>5] -- 32 consecutive output channels
+// of ONE pixel -- so the LDS tiles stay row-major [m][channels], are filled with plain 16-B stores and read with
+// conflict-free ds_read_b32 (2 reads per MFMA; the 64-cycle fp32 MFMA leaves the LDS idle anyway).
+// The pixel range is split over gridDim.y workgroups; each writes its partial tile, and a second kernel sums the
+// partials in fixed order (deterministic, no atomics) while transposing to the parameter's OIHW layout.
+// Reference: autograd of nn.Conv2d in Bottleneck.forward (codes/models/backbones/resnet.py:208-244).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int BCO = 128, BK = 128, BMR = 32;       // output tile (co x kcol), pixel rows per chunk
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgArgs {
+    const float* dz;
+    const float* x;
+    const float* x2;
+    float* part;
+    int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, xps, split_c, x2ps;
+    int M, K, rows_per_split, tiles_k;
+};
+
+__global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ds[2][BMR][BCO];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BMR][BK];
+    const int tile_k = blockIdx.x % a.tiles_k, tile_co = blockIdx.x / a.tiles_k;
+    const int co0 = tile_co * BCO, k0 = tile_k * BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q = tid & 31, lrow = tid >> 5;                 // loader: 16-B unit within the 128-wide row, row-in-8
+    // this thread's fixed column of each operand
+    const int co = co0 + q * 4;
+    const bool co_ok = co < a.Cout;
+    const int kcol = k0 + q * 4;
+    const bool k_ok = kcol < a.K;
+    const int tap = k_ok ? kcol / a.Cin : 0;
+    const int ci = k_ok ? kcol - tap * a.Cin : 0;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const bool from2 = a.split_c > 0 && ci < a.split_c;
+    const float* xb = from2 ? a.x2 : a.x;
+    const int ps = from2 ? a.x2ps : a.xps;
+
+    const int m_begin = blockIdx.y * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nchunks = (m_end - m_begin + BMR - 1) / BMR;
+
+    float4 rd[4], rx[4];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_begin + c * BMR + lrow + 8 * i;
+            rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end) {
+                if (co_ok) rd[i] = *reinterpret_cast<const float4*>(a.dz + (long)m * a.Cout + co);
+                if (k_ok) {
+                    const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+                    if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+                        rx[i] = *reinterpret_cast<const float4*>(xb + ((long)(img * a.H + ih) * a.W + iw) * ps + ci);
+                }
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&Ds[buf][lrow + 8 * i][q * 4]) = rd[i];
+            *reinterpret_cast<float4*>(&Xs[buf][lrow + 8 * i][q * 4]) = rx[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int lr = lane >> 5, lc = lane & 31;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nchunks;
+        if (more) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < BMR / 2; ++kk) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = Ds[buf][2 * kk + lr][wm * 64 + i * 32 + lc];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = Xs[buf][2 * kk + lr][wn * 64 + j * 32 + lc];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    // partial[split][co][kcol]
+    float* out = a.part + (long)blockIdx.y * a.Cout * a.K;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = k0 + wn * 64 + j * 32 + lc;
+        if (col >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
+                if (row < a.Cout) out[(long)row * a.K + col] = acc[i][j][r];
+            }
+    }
+}
+
+// dW_oihw[co][ci][kh][kw] = sum_s part[s][co][(kh*KWP + kw)*CINP + ci]   (KWP/CINP = packed extents; stem: 8 / 4)
+__global__ void wgrad_reduce_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
+                                    float* dw) {
+    const long total = (long)cout * cin * kh * kw;
+    const long K = (long)kh * kwp * cinp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int x = (int)(t % kw); t /= kw;
+        const int y = (int)(t % kh); t /= kh;
+        const int ci = (int)(t % cin);
+        const int co = (int)(t / cin);
+        const long src = (long)co * K + ((long)y * kwp + x) * cinp + ci;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(long)k * cout * K + src];
+        dw[i] = s;
+    }
+}
+
+template <typename ET>
+__global__ void pack_dgrad_weight_kernel(const float* w, int cout, int cin, int kh, int kw, ET* out) {
+    // out[ci][kh'][kw'][co] = w[co][ci][KH-1-kh'][KW-1-kw']
+    const long total = (long)cin * kh * kw * cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int co = (int)(t % cout); t /= cout;
+        const int x = (int)(t % kw); t /= kw;
+        const int y = (int)(t % kh);
+        const int ci = (int)(t / kh);
+        stf(out + i, w[(((long)co * cin + ci) * kh + (kh - 1 - y)) * kw + (kw - 1 - x)]);
+    }
+}
+
+int plan_split(int M, int tiles) {
+    int want = std::max(1, 1536 / std::max(tiles, 1));
+    int rows = std::max((M + want - 1) / want, 256);
+    rows = (rows + BMR - 1) / BMR * BMR;
+    return rows;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
+    if (!d || d->cout <= 0 || d->cin <= 0) return 0;
+    const int M = d->n * d->ho * d->wo, K = d->kh * d->kw * d->cin;
+    const int tiles = ((d->cout + BCO - 1) / BCO) * ((K + BK - 1) / BK);
+    const int rows = plan_split(M, tiles);
+    const int nsplit = (M + rows - 1) / rows;
+    return align_up((size_t)nsplit * d->cout * K * sizeof(float), 256);
+}
+
+// dw_oihw (cout, cin_real, kh, kw_real) fp32 <- dz (n,ho,wo,cout), x as in the forward descriptor.
+// kw_real/cin_real < packed extents only for the stem view (kh x 1 x 32 over the padded NHWC4 input = 7 x 8 x 4).
+int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real, int cin_real,
+                          int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && dz && x && dw_oihw, MVF_EINVAL, "wgrad: NULL argument");
+    MVF_REQUIRE(d->dtype == MVF_F32, MVF_EUNSUPPORTED, "wgrad: fp32 only in this round");
+    MVF_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride > 0, MVF_ESHAPE, "wgrad: cin/cout must be multiples of 4");
+    MVF_REQUIRE(kw_packed * cin_packed == d->kw * d->cin && kw_real <= kw_packed && cin_real <= cin_packed, MVF_EINVAL, "wgrad: packed extents inconsistent");
+    MVF_REQUIRE(ws && ws_bytes >= mvf_conv2d_wgrad_workspace_bytes(d), MVF_EWS, "wgrad: workspace too small");
+    if (d->split_c) MVF_REQUIRE(x2 && d->kh == 1 && d->kw == 1 && d->split_c % 4 == 0, MVF_EINVAL, "wgrad: bad split_c");
+    WgArgs a = {};
+    a.dz = (const float*)dz; a.x = (const float*)x; a.x2 = (const float*)x2; a.part = (float*)ws;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw;
+    a.stride = d->stride; a.pad = d->pad; a.Ho = d->ho; a.Wo = d->wo; a.xps = d->x_pix_stride;
+    a.split_c = d->split_c; a.x2ps = d->x2_pix_stride;
+    a.M = d->n * d->ho * d->wo; a.K = d->kh * d->kw * d->cin;
+    a.tiles_k = (a.K + BK - 1) / BK;
+    const int tiles = ((d->cout + BCO - 1) / BCO) * a.tiles_k;
+    a.rows_per_split = plan_split(a.M, tiles);
+    const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+    MVF_LAUNCH_CHECK();
+    const long total = (long)d->cout * cin_real * d->kh * kw_real;
+    const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, a.part, nsplit,
+                       d->cout, cin_real, kh_p, kw_real, kw_packed, cin_packed, dw_oihw);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_pack_conv_weight_dgrad(const float* w_oihw, int cout, int cin, int kh, int kw, void* w_packed, int dtype, void* stream) {
+    MVF_REQUIRE(w_oihw && w_packed && cout > 0 && cin > 0 && kh > 0 && kw > 0, MVF_EINVAL, "pack_conv_weight_dgrad: bad argument");
+    const long total = (long)cout * cin * kh * kw;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(pack_dgrad_weight_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, kh, kw, (float*)w_packed);
+    else
+        hipLaunchKernelGGL(pack_dgrad_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, kh, kw, (bf16_t*)w_packed);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+"""Data-parallel plumbing: one process per GPU over torch.distributed ('nccl' = RCCL on ROCm; 'gloo' in CPU tests).
+
+Mirror of the reference's `codes/core/dist_utils.py` (init_dist :70-92, allreduce_grads :38-49, _allreduce_coalesced
+:15-35, DistOptimizerHook :52-67, get_dist_info :116-131) and `codes/core/parallel/distributed.py`
+(MMDistributedDataParallel :11-62: broadcast of parameters + buffers at wrap time, no autograd hooks).
+
+MI355X notes: xGMI is point-to-point (7 links x ~153 GB/s per GPU); the R50 gradient is 97 MB fp32.  With the HIP
+TrainEngine every gradient already lives in ONE flat buffer, so the reference's "one flat bucket" semantics
+(bucket_size_mb=-1) is a single in-place all-reduce with no flatten/unflatten copies; `bucket_size_mb > 0` splits that
+buffer into contiguous chunks issued back to back (RCCL pipelines them over the rings).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def get_dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_dist(launcher="pytorch", backend="nccl", **kwargs):
+    """reference dist_utils.py:70-92 ('pytorch' launcher: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env)."""
+    if launcher != "pytorch":
+        raise ValueError("Invalid launcher type: %s (only 'pytorch' is built)" % launcher)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if backend == "nccl":
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    dist.init_process_group(backend=backend, **kwargs)
+    return rank, dist.get_world_size()
+
+
+def _buckets(tensors, bucket_size_mb):
+    if bucket_size_mb and bucket_size_mb > 0:
+        cap = int(bucket_size_mb * 1024 * 1024)
+        cur, size, out = [], 0, []
+        for t in tensors:
+            nb = t.numel() * t.element_size()
+            if cur and (size + nb > cap or t.dtype != cur[0].dtype):
+                out.append(cur)
+                cur, size = [], 0
+            cur.append(t)
+            size += nb
+        if cur:
+            out.append(cur)
+        return out
+    by_type = {}
+    for t in tensors:                       # reference default: one bucket per tensor type (dist_utils.py:21-27)
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    return list(by_type.values())
+
+
+def allreduce_coalesced(tensors, world_size, bucket_size_mb=-1):
+    for bucket in _buckets(tensors, bucket_size_mb):
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        dist.all_reduce(flat)
+        flat.div_(world_size)
+        off = 0
+        for t in bucket:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
+def allreduce_grads(params, coalesce=True, bucket_size_mb=-1):
+    """Average the gradients of `params` over all ranks (reference dist_utils.py:38-49)."""
+    grads = [p.grad.data for p in params if p.requires_grad and p.grad is not None]
+    _, world = get_dist_info()
+    if world == 1:
+        return
+    if coalesce:
+        allreduce_coalesced(grads, world, bucket_size_mb)
+    else:
+        for g in grads:
+            dist.all_reduce(g.div_(world))
+
+
+def allreduce_flat(flat, world_size=None, bucket_size_mb=-1):
+    """In-place average of one flat gradient buffer (the TrainEngine layout): no flatten/unflatten copies."""
+    _, world = get_dist_info()
+    world = world_size or world
+    if world == 1:
+        return flat
+    if bucket_size_mb and bucket_size_mb > 0:
+        step = max(1, int(bucket_size_mb * 1024 * 1024) // flat.element_size())
+        works = [dist.all_reduce(flat[i:i + step], async_op=True) for i in range(0, flat.numel(), step)]
+        for w in works:
+            w.wait()
+    else:
+        dist.all_reduce(flat)
+    flat.div_(world)
+    return flat
+
+
+class MMDistributedDataParallel(torch.nn.Module):
+    """reference parallel/distributed.py:11-62: broadcast parameters and buffers from rank 0 at wrap time; forward just
+    calls the module (inputs are expected on this rank's device); gradients are exchanged by DistOptimizerHook."""
+
+    def __init__(self, module, dim=0, broadcast_buffers=True, bucket_cap_mb=25):
+        super().__init__()
+        self.module, self.dim, self.broadcast_buffers = module, dim, broadcast_buffers
+        self.broadcast_bucket_size = bucket_cap_mb * 1024 * 1024
+        self._sync_params()
+
+    def _sync_params(self):
+        _, world = get_dist_info()
+        if world == 1:
+            return
+        tensors = list(self.module.state_dict().values()) if self.broadcast_buffers else [p.data for p in self.module.parameters()]
+        for t in tensors:
+            if t.numel():
+                dist.broadcast(t, 0)
+
+    def forward(self, *inputs, **kwargs):
+        return self.module(*inputs, **kwargs)
+
+
+class DistOptimizerHook(object):
+    """after_train_iter of the reference hook (dist_utils.py:52-67): zero_grad -> backward -> all-reduce / world ->
+    clip_grad_norm_ -> optimizer.step(), for any torch optimizer; `loss` comes from Recognizer2D.forward_train."""
+
+    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1):
+        self.grad_clip, self.coalesce, self.bucket_size_mb = grad_clip, coalesce, bucket_size_mb
+
+    def after_train_iter(self, model, optimizer, loss):
+        optimizer.zero_grad()
+        loss.backward()
+        allreduce_grads(model.parameters(), self.coalesce, self.bucket_size_mb)
+        total = None
+        if self.grad_clip is not None:
+            total = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], **self.grad_clip)
+        optimizer.step()
+        return total

@@ -58,8 +58,8 @@ class TSNClsHead(nn.Module):
         """x: (N*T, C, h, w) features [or (clips, C, T, h, w) with fcn_testing] -> (clips, num_classes) scores."""
         if not x.is_cuda:
             raise RuntimeError("TSNClsHead: mvfnet_amd runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
-        if self.training and self.dropout is not None:
-            raise NotImplementedError("mvfnet_amd: the training-mode head (dropout + backward) is not built yet; call .eval()")
+        if self.training and self.dropout is not None and torch.is_grad_enabled():
+            raise RuntimeError("TSNClsHead: in training the head runs inside Recognizer2D.forward_train (HIP train engine)")
         if x.dim() == 5:                                    # fcn_testing view (clips, C, T, h, w) of the NHWC buffer
             clips, c, t, h, w = x.shape
             feat = x.permute(0, 2, 3, 4, 1).reshape(clips * t, h, w, c)
@@ -70,5 +70,6 @@ class TSNClsHead(nn.Module):
         return self.engine().scores(feat, num_seg)
 
     def loss(self, cls_score, labels):
-        raise NotImplementedError("mvfnet_amd: the cross-entropy loss / training step is not built yet (oracle/net_torch.py "
-                                  "holds the CPU restatement used by the tests)")
+        """reference heads/base.py:40-45.  Stand-alone use is not needed by the hot path: Recognizer2D.forward_train
+        computes scores, loss and their gradients in one fused HIP head (mvf_head_train_fwd)."""
+        raise RuntimeError("TSNClsHead.loss: use Recognizer2D.forward_train (the loss is fused into the HIP train head)")

@@ -10,6 +10,23 @@ import torch.nn as nn
 from ..builder import RECOGNIZERS, build_backbone, build_head
 
 
+class _TrainStepFn(torch.autograd.Function):
+    """Whole-model autograd node: forward = HIP train forward + loss, backward = HIP backward chain."""
+
+    @staticmethod
+    def forward(ctx, eng, imgs, labels, *params):
+        ctx.eng = eng
+        ctx.n = len(params)
+        return eng.forward(imgs, labels).reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = ctx.eng
+        eng.backward()
+        eng.flat_grads.mul_(gout)
+        return (None, None, None) + tuple(eng.grad_of(p) for p in eng.model.parameters())
+
+
 @RECOGNIZERS.register_module
 class Recognizer2D(nn.Module):
     def __init__(self, modality="RGB", backbone=None, cls_head=None, fcn_testing=False, module_cfg=None,
@@ -63,9 +80,30 @@ class Recognizer2D(nn.Module):
             return self.forward_train(img_group, label, **kwargs)
         return self.forward_test(img_group, return_numpy, **kwargs)
 
+    # ---- training ---------------------------------------------------------------------------------------------
+    def train_engine(self, **opt):
+        """The HIP training engine bound to this model (created on first use; parameters become views of one flat
+        buffer).  opt: lr, momentum, weight_decay, max_norm (defaults = the reference's optimizer config)."""
+        if getattr(self, "_train_engine", None) is None:
+            from ..train_engine import TrainEngine
+            self._train_engine = TrainEngine(self, **opt)
+        return self._train_engine
+
     def forward_train(self, imgs, labels, **kwargs):
-        raise NotImplementedError("mvfnet_amd: forward_train (batch-stat BN conv stack, loss, backward) is not built yet; "
-                                  "the eval/inference path and the MVF module's own forward/backward are.")
+        """imgs [B, T, 3, H, W], labels [B, 1] -> {'loss_cls': scalar tensor} (reference recognizer2d.py:132-149).
+        The returned loss supports .backward(): gradients land in the parameters' .grad (views of the engine's flat
+        gradient buffer), as the reference's DistOptimizerHook expects."""
+        if not imgs.is_cuda:
+            raise RuntimeError("Recognizer2D: mvfnet_amd runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
+        bn_train = [m.training for m in self.backbone.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        if not all(bn_train):
+            raise NotImplementedError("forward_train with eval-mode (frozen) BatchNorm is not built; the shipped MVFNet "
+                                      "configs train with norm_eval=False")
+        eng = self.train_engine()
+        eng.dropout = self.cls_head.dropout_ratio if (self.cls_head.dropout is not None and self.cls_head.training) else 0.0
+        params = [p for p in self.parameters()]
+        loss = _TrainStepFn.apply(eng, imgs, labels, *params)
+        return dict(loss_cls=loss)
 
     def forward_test(self, imgs, return_numpy=True, **kwargs):
         """imgs [B, clips*crops*T, 3, H, W] -> (1 | clips, num_classes) (reference recognizer2d.py:151-179)."""

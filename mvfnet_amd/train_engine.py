@@ -1,0 +1,459 @@
+"""Training engine: one MVFNet train step (forward with batch-statistics BN, loss, backward, clip + SGD-nesterov) as a
+fixed sequence of HIP launches through the C ABI.
+
+Host-side mirror of Recognizer2D.forward_train (reference codes/models/recognizers/recognizer2d.py:132-149),
+Bottleneck.forward in train mode (codes/models/backbones/resnet.py:208-244, all BN layers on batch statistics:
+norm_eval=False in the shipped configs), MVF.forward in train mode (codes/models/modules/MVF.py:104-138), the head +
+loss (heads/tsn_clshead.py:71-98, heads/base.py:40-45), autograd's backward of all of it, and
+DistOptimizerHook.after_train_iter (codes/core/dist_utils.py:61-67).
+
+Layout: activations are channels-last matrices [m = n*h*w][c] in fp32.  Every parameter of the model lives in ONE
+flat fp32 buffer (the nn.Parameters are re-pointed at views of it), gradients in a second flat buffer and momentum in
+a third, so the data-parallel gradient exchange is a single in-place all-reduce of the flat gradient (what the
+reference's `_allreduce_coalesced` builds by copying) and the optimizer is one fused kernel.
+
+Kept per conv for the backward: its raw output z (pre-BN) and, for mid-block convs, a = relu(bn(z)); BN statistics.
+Nothing is recomputed except ReLU / hard-swish masks (from z and the folded scale/shift).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, MvfDesc, check, lib
+
+F32 = _lib.MVF_F32
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _BN(object):
+    """Handles to one BatchNorm's parameters / buffers / gradient slots + per-step statistics."""
+
+    def __init__(self, bn, eng, name):
+        self.c = bn.num_features
+        self.mod = bn
+        self.gamma, self.beta = bn.weight, bn.bias
+        self.dgamma, self.dbeta = eng.grad_of(bn.weight), eng.grad_of(bn.bias)
+        self.eps, self.momentum = bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
+        dev = bn.weight.device
+        self.mean = torch.empty(self.c, device=dev)
+        self.invstd = torch.empty(self.c, device=dev)
+        self.scale = torch.empty(self.c, device=dev)
+        self.shift = torch.empty(self.c, device=dev)
+
+    def stats(self, z, m, eng):
+        ws = eng.workspace(lib.mvf_bn_workspace_bytes(m, self.c))
+        check(lib.mvf_bn_train_stats(_p(z), m, self.c, _p(self.gamma), _p(self.beta), C.c_float(self.eps), C.c_float(self.momentum),
+                                     _p(self.mod.running_mean), _p(self.mod.running_var), _p(self.mean), _p(self.invstd), _p(self.scale),
+                                     _p(self.shift), _p(ws), ws.numel(), F32, _st()), "mvf_bn_train_stats")
+        self.mod.num_batches_tracked += 1
+
+    def apply(self, z, m, act, residual=None, rbn=None):
+        out = torch.empty_like(z)
+        check(lib.mvf_bn_apply(_p(z), m, self.c, _p(self.scale), _p(self.shift), _p(residual), _p(rbn.scale if rbn else None),
+                               _p(rbn.shift if rbn else None), act, _p(out), F32, _st()), "mvf_bn_apply")
+        return out
+
+    def backward(self, g, g_pitch, z, m, eng, mask_mode, ymask=None, gm_out=None):
+        """dgamma/dbeta into the flat grad buffer; returns dz."""
+        ws = eng.workspace(lib.mvf_bn_workspace_bytes(m, self.c))
+        check(lib.mvf_bn_bwd_reduce(_p(g), g_pitch, _p(z), _p(ymask), m, self.c, _p(self.mean), _p(self.invstd), _p(self.scale),
+                                    _p(self.shift), mask_mode, _p(gm_out), _p(self.dgamma), _p(self.dbeta), _p(ws), ws.numel(), F32, _st()),
+              "mvf_bn_bwd_reduce")
+        src, pitch, mode = (gm_out, self.c, 0) if gm_out is not None else (g, g_pitch, mask_mode if mask_mode != 1 else 0)
+        dz = torch.empty_like(z)
+        check(lib.mvf_bn_bwd_apply(_p(src), pitch, _p(z), m, self.c, _p(self.gamma), _p(self.mean), _p(self.invstd), _p(self.scale),
+                                   _p(self.shift), _p(self.dgamma), _p(self.dbeta), mode, _p(dz), F32, _st()), "mvf_bn_bwd_apply")
+        return dz
+
+
+class _TConv(object):
+    """One conv's parameter handle, per-step packed weights (forward and data-gradient) and launch helpers."""
+
+    def __init__(self, conv, eng, stem=False):
+        self.w = conv.weight
+        self.dw = eng.grad_of(conv.weight)
+        self.cout, self.cin, self.kh, self.kw = conv.weight.shape
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+        self.stem = stem
+        dev = conv.weight.device
+        if stem:
+            self.wp = torch.empty(self.cout, self.kh, 8, 4, device=dev)
+            self.wd = None
+        else:
+            self.wp = torch.empty(self.cout, self.kh, self.kw, self.cin, device=dev)
+            self.wd = torch.empty(self.cin, self.kh, self.kw, self.cout, device=dev)
+
+    def pack(self, need_dgrad=True):
+        if self.stem:
+            check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, 8, 4, None, _p(self.wp), F32, _st()), "pack")
+            return
+        check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, self.kw, self.cin, None, _p(self.wp), F32, _st()), "pack")
+        if need_dgrad:
+            check(lib.mvf_pack_conv_weight_dgrad(_p(self.w), self.cout, self.cin, self.kh, self.kw, _p(self.wd), F32, _st()), "pack_dgrad")
+
+    def desc(self, n, h, w, ho, wo, x_pitch, split_c=0):
+        if self.stem:
+            return ConvDesc(n, h, w, 32, self.cout, self.kh, 1, 2, 0, ho, wo, 4, F32, 0, 0, 0, 0)
+        return ConvDesc(n, h, w, self.cin, self.cout, self.kh, self.kw, self.stride, self.pad, ho, wo, x_pitch, F32, 0, split_c, split_c, 0)
+
+    def out_hw(self, h, w):
+        return (h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1
+
+    def forward(self, x, n, h, w, x_pitch=None, x2=None, split_c=0, ho=None, wo=None):
+        if ho is None:
+            ho, wo = self.out_hw(h, w)
+        d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
+        z = torch.empty(n * ho * wo, self.cout, device=x.device)
+        check(lib.mvf_conv2d_nhwc_fwd(C.byref(d), _p(x), _p(x2), _p(self.wp), None, None, _p(z), _st()), "conv fwd")
+        return z, ho, wo
+
+    def wgrad(self, dz, x, n, h, w, ho, wo, eng, x_pitch=None, x2=None, split_c=0):
+        d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
+        ws = eng.workspace(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)))
+        kwr, cinr, kwp, cinp = (self.kw, self.cin, 8, 4) if self.stem else (self.kw, self.cin, self.kw, self.cin)
+        check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
+
+    def dgrad(self, dz, n, ho, wo, h, w, residual=None):
+        """dx (n*h*w, cin) from dz (n*ho*wo, cout): a conv of dz with the flipped/transposed weights."""
+        d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, F32, 0, 0, 0,
+                     self.stride if self.stride > 1 else 0)
+        dx = torch.empty(n * h * w, self.cin, device=dz.device)
+        check(lib.mvf_conv2d_nhwc_fwd(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(dx), _st()), "conv dgrad")
+        return dx
+
+
+class _TMvf(object):
+    def __init__(self, mvf, eng):
+        self.cs, self.T = mvf.num_shift_channel, mvf.n_segment
+        self.mode = _lib.MODE_BITS[mvf.mode]
+        self.share, self.use_hs = mvf.share, mvf.use_hs
+        cs = self.cs
+        self.wt = mvf.shift_conv.weight
+        self.wh = mvf.shift_conv.weight if mvf.share else (mvf.h_conv.weight if self.mode & 2 else None)
+        self.ww = mvf.shift_conv.weight if mvf.share else (mvf.w_conv.weight if self.mode & 4 else None)
+        self.dwt = eng.grad_of(mvf.shift_conv.weight)
+        self.dwh = None if mvf.share or not (self.mode & 2) else eng.grad_of(mvf.h_conv.weight)
+        self.dww = None if mvf.share or not (self.mode & 4) else eng.grad_of(mvf.w_conv.weight)
+        self.bn = _BN(mvf.bn, eng, "mvf.bn") if self.use_hs else None
+        dev = mvf.shift_conv.weight.device
+        self.tmp_h = torch.empty(cs, 3, device=dev) if self.dwh is None else None     # scratch for views without own weights
+        self.tmp_w = torch.empty(cs, 3, device=dev) if self.dww is None else None
+
+    def desc(self, nt, h, w, c):
+        return MvfDesc(nt, c, h, w, self.T, self.cs, self.mode, _lib.MVF_NHWC, F32)
+
+    def forward(self, x, nt, h, w, c, eng):
+        m = nt * h * w
+        d = self.desc(nt, h, w, c)
+        y = torch.empty(m, self.cs, device=x.device)
+        check(lib.mvf_nhwc_stencil(C.byref(d), _p(x), c, _p(y), self.cs, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 0, _st()), "mvf stencil")
+        if not self.use_hs:
+            return y, y
+        self.bn.stats(y, m, eng)
+        return y, self.bn.apply(y, m, 2)
+
+    def backward(self, dxp, x, y, nt, h, w, c, eng):
+        """dxp (m, c): grad w.r.t. the conv input [o | x_rest]; on return its first cs channels hold the grad w.r.t. x's slice."""
+        m = nt * h * w
+        d = self.desc(nt, h, w, c)
+        if self.use_hs:
+            dy = self.bn.backward(dxp, c, y, m, eng, 3)
+        else:
+            dy = dxp[:, : self.cs].contiguous()
+        ws = eng.workspace(lib.mvf_nhwc_tapgrad_workspace_bytes(C.byref(d)))
+        dwh = self.dwh if self.dwh is not None else self.tmp_h
+        dww = self.dww if self.dww is not None else self.tmp_w
+        check(lib.mvf_nhwc_tapgrad(C.byref(d), _p(x), c, _p(dy), self.cs, _p(self.dwt), _p(dwh), _p(dww), _p(ws), ws.numel(), _st()), "mvf tapgrad")
+        if self.share:   # one weight tensor serves every view (MVF.py:114-116): gradients add up
+            self.dwt.view(self.cs, 3).add_(dwh.view(self.cs, 3) if self.mode & 2 else 0).add_(dww.view(self.cs, 3) if self.mode & 4 else 0)
+        check(lib.mvf_nhwc_stencil(C.byref(d), _p(dy), self.cs, _p(dxp), c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 1, _st()), "mvf stencil^T")
+
+
+class _TBlock(object):
+    def __init__(self, blk, eng):
+        from .modules.MVF import MVF
+        c1 = blk.conv1
+        self.mvf = None
+        if isinstance(c1, MVF):
+            if c1.num_shift_channel:
+                self.mvf = _TMvf(c1, eng)
+            c1 = c1.net
+        self.c1, self.b1 = _TConv(c1, eng), _BN(blk.bn1, eng, "bn1")
+        self.c2, self.b2 = _TConv(blk.conv2, eng), _BN(blk.bn2, eng, "bn2")
+        self.c3, self.b3 = _TConv(blk.conv3, eng), _BN(blk.bn3, eng, "bn3")
+        self.cd = self.bd = None
+        if blk.downsample is not None:
+            self.cd, self.bd = _TConv(blk.downsample[0], eng), _BN(blk.downsample[1], eng, "down")
+        self.split_ok = self.mvf is not None and self.mvf.cs % 32 == 0
+
+    def convs(self):
+        return [c for c in (self.c1, self.c2, self.c3, self.cd) if c is not None]
+
+    def forward(self, x, nt, h, w, c, eng):
+        m = nt * h * w
+        s = dict(x=x, h=h, w=w, c=c)
+        if self.mvf is not None:
+            s["y"], o = self.mvf.forward(x, nt, h, w, c, eng)
+            if self.split_ok:
+                s["o"] = o
+                z1, _, _ = self.c1.forward(x, nt, h, w, c, x2=o, split_c=self.mvf.cs)
+            else:   # odd slice widths: materialise [o | x_rest]
+                xin = x.clone()
+                xin[:, : self.mvf.cs] = o
+                s["xin"] = xin
+                z1, _, _ = self.c1.forward(xin, nt, h, w, c)
+        else:
+            z1, _, _ = self.c1.forward(x, nt, h, w, c)
+        self.b1.stats(z1, m, eng)
+        a1 = self.b1.apply(z1, m, 1)
+        z2, ho, wo = self.c2.forward(a1, nt, h, w)
+        m2 = nt * ho * wo
+        self.b2.stats(z2, m2, eng)
+        a2 = self.b2.apply(z2, m2, 1)
+        z3, _, _ = self.c3.forward(a2, nt, ho, wo)
+        self.b3.stats(z3, m2, eng)
+        if self.cd is not None:
+            zd, _, _ = self.cd.forward(x, nt, h, w)
+            self.bd.stats(zd, m2, eng)
+            out = self.b3.apply(z3, m2, 1, residual=zd, rbn=self.bd)
+            s["zd"] = zd
+        else:
+            out = self.b3.apply(z3, m2, 1, residual=x)
+        s.update(z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, out=out, ho=ho, wo=wo)
+        self.saved = s
+        return out, ho, wo, self.c3.cout
+
+    def backward(self, g, nt, eng):
+        s = self.saved
+        h, w, c, ho, wo = s["h"], s["w"], s["c"], s["ho"], s["wo"]
+        m, m2 = nt * h * w, nt * ho * wo
+        gm = torch.empty_like(g)
+        dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 1, ymask=s["out"], gm_out=gm)
+        self.c3.wgrad(dz3, s["a2"], nt, ho, wo, ho, wo, eng)
+        da2 = self.c3.dgrad(dz3, nt, ho, wo, ho, wo)
+        del dz3
+        dz2 = self.b2.backward(da2, self.c2.cout, s["z2"], m2, eng, 2)
+        del da2
+        self.c2.wgrad(dz2, s["a1"], nt, h, w, ho, wo, eng)
+        da1 = self.c2.dgrad(dz2, nt, ho, wo, h, w)
+        del dz2
+        dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2)
+        del da1
+        resid = gm
+        if self.cd is not None:
+            dzd = self.bd.backward(gm, self.cd.cout, s["zd"], m2, eng, 0)
+            self.cd.wgrad(dzd, s["x"], nt, h, w, ho, wo, eng, x_pitch=c)
+            resid = self.cd.dgrad(dzd, nt, ho, wo, h, w)
+            del dzd
+        if self.mvf is None:
+            self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c)
+            dx = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid)
+        else:
+            if self.split_ok:
+                self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c, x2=s["o"], split_c=self.mvf.cs)
+            else:
+                self.c1.wgrad(dz1, s["xin"], nt, h, w, h, w, eng, x_pitch=c)
+            dxp = self.c1.dgrad(dz1, nt, h, w, h, w)
+            self.mvf.backward(dxp, s["x"], s["y"], nt, h, w, c, eng)
+            dx = eng.add(dxp, resid)
+        self.saved = None
+        return dx
+
+
+class _ParamStore(object):
+    """Flat fp32 parameter / gradient / momentum buffers for a module; its nn.Parameters become views."""
+
+    def _init_store(self, model):
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("the HIP training engine needs the model on an MI355X device; no CPU fallback")
+        self.model, self.device = model, dev
+        params = [p for p in model.parameters()]
+        n = sum(p.numel() for p in params)
+        pad = lambda k: (k + 3) // 4 * 4
+        total = sum(pad(p.numel()) for p in params)
+        self.flat_params = torch.zeros(total, device=dev)
+        self.flat_grads = torch.zeros(total, device=dev)
+        self.flat_mom = torch.zeros(total, device=dev)
+        self._grad_view = {}
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                v = self.flat_params[off:off + k].view(p.shape)
+                v.copy_(p.data.float())
+                p.data = v
+                gv = self.flat_grads[off:off + k].view(p.shape)
+                self._grad_view[id(p)] = gv
+                off += pad(k)
+        self.n_params = n
+        self._ws = None
+        self.norm_out = torch.zeros(2, device=dev)
+        self.steps = 0
+        self._ones = {}
+
+    def grad_of(self, p):
+        return self._grad_view[id(p)]
+
+    def workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def add(self, a, b):
+        """a + b (elementwise) through mvf_bn_apply with unit scale / zero shift."""
+        m, c = a.shape
+        if c not in self._ones:
+            self._ones[c] = (torch.ones(c, device=a.device), torch.zeros(c, device=a.device))
+        one, zero = self._ones[c]
+        out = torch.empty_like(a)
+        check(lib.mvf_bn_apply(_p(a), m, c, _p(one), _p(zero), _p(b), None, None, 0, _p(out), F32, _st()), "add")
+        return out
+
+    def attach_grads(self):
+        """Expose the flat gradient views as .grad of the parameters (for external optimizers / inspection)."""
+        for p in self.model.parameters():
+            p.grad = self._grad_view[id(p)]
+
+
+class BlockTrainer(_ParamStore):
+    """Train-mode forward/backward of ONE mvfnet_amd Bottleneck (with or without MVF) -- used by the parity tests."""
+
+    def __init__(self, block):
+        self._init_store(block)
+        self.blk = _TBlock(block, self)
+
+    def forward(self, x_nchw):
+        nt, c, h, w = x_nchw.shape
+        self.nt = nt
+        for cv in self.blk.convs():
+            cv.pack()
+        x = x_nchw.permute(0, 2, 3, 1).contiguous().view(nt * h * w, c)
+        out, ho, wo, co = self.blk.forward(x, nt, h, w, c, self)
+        return out.view(nt, ho, wo, co).permute(0, 3, 1, 2)
+
+    def backward(self, g_nchw):
+        nt, co, ho, wo = g_nchw.shape
+        s = self.blk.saved
+        h, w, c = s["h"], s["w"], s["c"]
+        g = g_nchw.permute(0, 2, 3, 1).contiguous().view(nt * ho * wo, co)
+        dx = self.blk.backward(g, nt, self)
+        return dx.view(nt, h, w, c).permute(0, 3, 1, 2)
+
+
+class TrainEngine(_ParamStore):
+    """One-GPU training step for a mvfnet_amd Recognizer2D (fp32)."""
+
+    def __init__(self, model, lr=0.015, momentum=0.9, weight_decay=1e-4, max_norm=40.0):
+        self._init_store(model)
+        self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
+        bb = model.backbone
+        self.stem, self.stem_bn = _TConv(bb.conv1, self, stem=True), _BN(bb.bn1, self, "bn1")
+        self.blocks = [_TBlock(blk, self) for name in bb.res_layers for blk in getattr(bb, name)]
+        head = model.cls_head
+        self.fc_w, self.fc_b = head.new_fc.weight, head.new_fc.bias
+        self.dfc_w, self.dfc_b = self.grad_of(head.new_fc.weight), self.grad_of(head.new_fc.bias)
+        self.dropout = head.dropout_ratio if head.dropout is not None else 0.0
+        self.num_classes = head.num_classes
+
+    # ---- one step -----------------------------------------------------------------------------------------------
+    def forward(self, imgs, labels, stages=None):
+        """imgs [B, T, 3, H, W] fp32, labels [B, 1] / [B] int64 (GPU) -> loss tensor (1,), keeps activations."""
+        if not imgs.is_cuda or imgs.dtype != torch.float32:
+            raise RuntimeError("TrainEngine.forward: float32 GPU input required")
+        b, t = imgs.shape[0], imgs.shape[1]
+        x = imgs.reshape((-1, 3) + tuple(imgs.shape[3:])).contiguous()
+        nt, _, h, w = x.shape
+        self.stem.pack()
+        for blk in self.blocks:
+            for cv in blk.convs():
+                cv.pack()
+        hp, wp = h + 6, (w + 6 + 2 + 1) // 2 * 2
+        xp = torch.empty(nt, hp, wp, 4, device=x.device)
+        check(lib.mvf_stem_prep(_p(x), nt, 3, h, w, 3, wp, _p(xp), F32, _st()), "stem_prep")
+        ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+        z0, _, _ = self.stem.forward(xp, nt, hp, wp, ho=ho, wo=wo)
+        self.stem_bn.stats(z0, nt * ho * wo, self)
+        h2, w2 = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+        p0 = torch.empty(nt * h2 * w2, 64, device=x.device)
+        check(lib.mvf_maxpool_bn_relu_fwd(_p(z0), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(p0), F32, _st()), "maxpool fwd")
+        self.saved = dict(xp=xp, z0=z0, nt=nt, hp=hp, wp=wp, ho=ho, wo=wo, t=t, b=b)
+        if stages is not None:
+            stages["maxpool"] = p0.view(nt, h2, w2, 64)
+        xcur, hc, wc, cc = p0, h2, w2, 64
+        ends, k = [], 0
+        for name in self.model.backbone.res_layers:
+            k += len(getattr(self.model.backbone, name))
+            ends.append(k)
+        for i, blk in enumerate(self.blocks):
+            xcur, hc, wc, cc = blk.forward(xcur, nt, hc, wc, cc, self)
+            if stages is not None and (i + 1) in ends:
+                stages["layer%d" % (ends.index(i + 1) + 1)] = xcur.view(nt, hc, wc, cc)
+        # head + loss
+        lab = labels.reshape(-1).to(device=x.device, dtype=torch.int64).contiguous()
+        mask = None
+        if self.dropout > 0.0:
+            keep = 1.0 - self.dropout
+            mask = (torch.rand(nt, cc, device=x.device) < keep).float().div_(keep)
+        dev = x.device
+        pooled = torch.empty(nt, cc, device=dev)
+        scores = torch.empty(b, self.num_classes, device=dev)
+        dscores = torch.empty(b, self.num_classes, device=dev)
+        loss_part = torch.empty(b, device=dev)
+        loss = torch.empty(1, device=dev)
+        check(lib.mvf_head_train_fwd(_p(xcur), b, t, hc * wc, cc, _p(self.fc_w), _p(self.fc_b), self.num_classes, _p(lab), _p(mask), _p(pooled),
+                                     _p(scores), _p(dscores), _p(loss_part), _p(loss), F32, _st()), "head fwd")
+        self.saved.update(pooled=pooled, dscores=dscores, mask=mask, hw=hc * wc, c=cc, feat_shape=xcur.shape, scores=scores)
+        return loss
+
+    def backward(self):
+        s = self.saved
+        nt, b, t = s["nt"], s["b"], s["t"]
+        dpool = torch.empty(b, s["c"], device=self.device)
+        g = torch.empty(s["feat_shape"], device=self.device)
+        check(lib.mvf_head_train_bwd(_p(s["dscores"]), _p(s["pooled"]), _p(self.fc_w), _p(s["mask"]), b, t, s["hw"], s["c"], self.num_classes,
+                                     _p(self.dfc_w), _p(self.dfc_b), _p(dpool), _p(g), F32, _st()), "head bwd")
+        for blk in reversed(self.blocks):
+            g = blk.backward(g, nt, self)
+        ho, wo = s["ho"], s["wo"]
+        ga = torch.empty(nt * ho * wo, 64, device=self.device)
+        check(lib.mvf_maxpool_bn_relu_bwd(_p(s["z0"]), _p(g), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(ga), F32, _st()), "maxpool bwd")
+        dz0 = self.stem_bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2)
+        self.stem.wgrad(dz0, s["xp"], nt, s["hp"], s["wp"], ho, wo, self)
+        self.saved = None
+
+    def allreduce_grads(self):
+        """reference dist_utils.py:38-49: ONE flat all-reduce (sum); the division by world size is folded into the
+        optimizer kernel's grad_scale."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_grads)
+            return dist.get_world_size()
+        return 1
+
+    def step(self, lr=None):
+        world = self.allreduce_grads()
+        n = self.flat_params.numel()
+        ws = self.workspace(lib.mvf_sgd_workspace_bytes(n))
+        check(lib.mvf_sgd_nesterov_step(_p(self.flat_params), _p(self.flat_grads), _p(self.flat_mom), n, C.c_float(1.0 / world),
+                                        C.c_float(self.max_norm or 0.0), C.c_float(self.lr if lr is None else lr), C.c_float(self.momentum),
+                                        C.c_float(self.weight_decay), int(self.steps == 0), _p(self.norm_out), _p(ws), ws.numel(), _st()), "sgd step")
+        self.steps += 1
+        bb = self.model.backbone
+        if hasattr(bb, "invalidate_engine"):
+            bb.invalidate_engine()
+        return self.norm_out
+
+    def train_step(self, imgs, labels, lr=None):
+        loss = self.forward(imgs, labels)
+        self.backward()
+        self.step(lr)
+        return loss
