@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- MVFNet-R50 8x8 hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--clips B] [--no-cpu-baseline]
+    python bench.py [--mode train|infer] [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--clips B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic clips already resident in HBM:
-BASELINE.json configs[1] -- MVFNet-ResNet50 8x8, 32 clips of 8 x 3 x 224 x 224 per GPU, fp32, eval BatchNorm,
-forward only (Recognizer2D.forward_test -> HIP engine).  Clips are independent units, so N GPUs run N
-replicas of the weights on N disjoint batches with no data-path collective ("weak" scaling); the timed region is
-bracketed by barrier + synchronize and the MAX over ranks is reported.
+BASELINE.json's metric is "clips/sec (fwd+bwd) MVFNet-R50 8x8 224^2".  One "step" (default --mode train) = one full
+training iteration of the reference's hot path over one batch of synthetic clips already resident in HBM:
+forward with batch-statistics BatchNorm + MVF + head + cross-entropy, backward, [all-reduce of the flat gradient / world
+over RCCL when N > 1], clip_grad_norm_(40), SGD-nesterov update -- 32 clips of 8 x 3 x 224 x 224 per GPU, fp32
+(the reference trains in fp32: fp16 is commented out in its configs).  `--mode infer` is BASELINE configs[1]
+(eval-BN forward only, fp32 or bf16).
 
-The JSON line also carries
-  roofline      the dominant kernel (implicit-GEMM conv): algorithmic FLOP of the conv launches of one step divided
-                by their summed HIP-event durations (measured live, on the launch stream), vs the dense MFMA peak
-  cpu_baseline  the CPU restatement (oracle/net_torch.py, kind "port") timed on this box's host cores on a bounded
-                sample of the same workload (rank 0, N=1 only)
+Clips are independent units: N GPUs hold N replicas and N disjoint batches (weak scaling); the only collective is the
+gradient all-reduce of the training step.  The timed region is bracketed by barrier + synchronize, MAX over ranks.
+
+Extra objects in the JSON line
+  roofline      dominant kernel (implicit-GEMM conv `conv_igemm_kernel`: forward convs + data-gradient convs):
+                algorithmic FLOP of its launches in one step / their summed HIP-event durations (instrumented passes on
+                the launch stream, outside the timed region) vs the dense MFMA peak of the dtype; `wgrad` sub-object
+                for the weight-gradient kernel
+  cpu_baseline  the CPU restatement (oracle/net_torch.py, kind "port") of the same step on this box's host cores, bounded
+                sample; plus the same restatement run by PyTorch-ROCm eager on this GPU (the ">= 1.5x" comparator)
 """
 import argparse
 import json
@@ -34,20 +40,21 @@ T_FRAMES, SIZE = 8, 224
 
 def parse():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--clips", type=int, default=32, help="clips per GPU per step")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--streams", type=int, default=2, help="independent clip-group launch chains (HIP streams)")
-    ap.add_argument("--per-layer", action="store_true", help="print a per-conv-launch timing table to stderr")
+    ap.add_argument("--streams", type=int, default=2, help="infer: independent clip-group launch chains (HIP streams)")
+    ap.add_argument("--per-layer", action="store_true", help="print a per-launch timing table to stderr")
     return ap.parse_args()
 
 
-def build_model(depth, dtype):
+def build_model(depth, dtype, train):
     import mvfnet_amd
     from mvfnet_amd import synth
     m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(depth, T_FRAMES), None, dict(average_clips=None))
@@ -56,54 +63,125 @@ def build_model(depth, dtype):
     vals = synth.synth_state_dict({pre + k: tuple(v.shape) for k, v in sd.items()})
     m.load_state_dict({k: torch.from_numpy(vals[pre + k]) for k in sd}, strict=True)
     m.backbone.engine_dtype = torch.float32 if dtype == "f32" else torch.bfloat16
-    return m.cuda().eval()
+    m = m.cuda()
+    return m.train() if train else m.eval()
 
 
-def conv_roofline(model, imgs, dtype, reps=3, per_layer=False):
-    """Per-launch HIP-event timing of every implicit-GEMM conv launch of one step (instrumented passes, outside
-    the timed region).  Events are recorded on torch's current stream, which is the stream the C ABI launches on."""
+class _Timer(object):
+    """HIP-event bracket around every call of a bound method; events go on torch's current stream = the launch stream."""
+
+    def __init__(self):
+        self.rec = []
+
+    def wrap(self, cls, name, describe):
+        orig = getattr(cls, name)
+        timer = self
+
+        def timed(obj, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(obj, *a, **kw)
+            e1.record()
+            timer.rec.append((e0, e1) + describe(obj, out, *a, **kw))
+            return out
+
+        setattr(cls, name, timed)
+        return lambda: setattr(cls, name, orig)
+
+
+def _summ(rec, per_layer, tag):
+    ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+    fl = sum(r[2] for r in rec)
+    by = sum(r[4] for r in rec)
+    if per_layer:
+        agg = {}
+        for r in rec:
+            a = agg.setdefault(r[3], [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += r[0].elapsed_time(r[1])
+            a[2] += r[2]
+        for k, (cnt, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            print("  %-6s %-44s x%-2d %8.3f ms  %7.1f TF/s" % (tag, k, cnt, t, f / t / 1e9), file=sys.stderr)
+    return ms, fl, by, len(rec)
+
+
+def roofline_infer(model, imgs, dtype, per_layer):
     from mvfnet_amd import engine as E
-    records = []
-    orig = E._Conv.run
+    t = _Timer()
+    esz = 4 if dtype == "f32" else 2
 
-    def timed(self, x, n, h, w, c_total, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig(self, x, n, h, w, c_total, **kw)
-        e1.record()
+    def desc(self, out, x, n, h, w, c_total, **kw):
         y, ho, wo = out
-        k_alg = 147 if self.kw == 1 and self.cin == 32 and self.kh == 7 else self.kh * self.kw * self.cin
-        esz = 4 if dtype == "f32" else 2
+        stem = self.kw == 1 and self.cin == 32 and self.kh == 7
+        k_alg = 147 if stem else self.kh * self.kw * self.cin
         st = kw.get("stride") or self.stride
         in_px = n * ho * wo if (self.kh == 1 and self.kw == 1 and st > 1) else n * h * w
-        nbytes = esz * (in_px * (c_total if self.kw == 1 and self.cin == 32 and self.kh == 7 else self.cin)
-                        + n * ho * wo * self.cout * (2 if kw.get("residual") is not None else 1) + self.wp.numel())
-        records.append((e0, e1, 2.0 * n * ho * wo * self.cout * k_alg,
-                        "M%d N%d K%d k%dx%d s%d" % (n * ho * wo, self.cout, k_alg, self.kh, self.kw, st), nbytes))
-        return out
+        nbytes = esz * (in_px * (c_total if stem else self.cin) + n * ho * wo * self.cout * (2 if kw.get("residual") is not None else 1) + self.wp.numel())
+        return (2.0 * n * ho * wo * self.cout * k_alg, "M%d N%d K%d k%dx%d s%d" % (n * ho * wo, self.cout, k_alg, self.kh, self.kw, st), nbytes)
 
-    E._Conv.run = timed
+    undo = t.wrap(E._Conv, "run", desc)
+    streams = model.backbone.engine().streams
+    model.backbone.engine().streams = 1
     try:
-        tot_ms, tot_flop, launches = 0.0, 0.0, 0
-        for _ in range(reps):
-            del records[:]
+        tot = [0.0, 0.0, 0.0, 0]
+        reps = 3
+        for i in range(reps):
+            del t.rec[:]
             model(imgs, None, return_loss=False, return_numpy=False)
             torch.cuda.synchronize()
-            tot_ms += sum(r[0].elapsed_time(r[1]) for r in records)
-            tot_flop += sum(r[2] for r in records)
-            launches += len(records)
-            tot_bytes = sum(r[4] for r in records)
-        if per_layer:
-            agg = {}
-            for r in records:
-                ms = r[0].elapsed_time(r[1])
-                a = agg.setdefault(r[3], [0, 0.0, 0.0])
-                a[0] += 1; a[1] += ms; a[2] += r[2]
-            for k, (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                print("  %-40s x%-2d %8.3f ms  %7.1f TF/s" % (k, cnt, ms, fl / ms / 1e9), file=sys.stderr)
+            r = _summ(t.rec, per_layer and i == reps - 1, "conv")
+            tot = [a + b for a, b in zip(tot, r)]
     finally:
-        E._Conv.run = orig
-    achieved = tot_flop / (tot_ms * 1e-3) / 1e12
+        undo()
+        model.backbone.engine().streams = streams
+    return _roof(tot, reps, dtype)
+
+
+def roofline_train(eng, imgs, labels, dtype, per_layer):
+    from mvfnet_amd import train_engine as TE
+    tc, tw = _Timer(), _Timer()
+
+    def dfwd(self, out, x, n, h, w, x_pitch=None, x2=None, split_c=0, ho=None, wo=None):
+        z, ho, wo = out
+        k_alg = 147 if self.stem else self.kh * self.kw * self.cin
+        in_px = n * ho * wo if (self.kh == 1 and self.stride > 1) else n * h * w
+        nbytes = 4 * (in_px * (4 if self.stem else self.cin) + n * ho * wo * self.cout + self.w.numel())
+        return (2.0 * n * ho * wo * self.cout * k_alg, "fwd   M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)
+
+    def ddgr(self, out, dz, n, ho, wo, h, w, residual=None):
+        fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin          # algorithmic = the forward conv's MACs
+        nbytes = 4 * (n * ho * wo * self.cout + n * h * w * self.cin * (2 if residual is not None else 1) + self.w.numel())
+        return (fl, "dgrad M%d N%d K%d s%d" % (n * h * w, self.cin, self.kh * self.kw * self.cout, self.stride), nbytes)
+
+    def dwgr(self, out, dz, x, n, h, w, ho, wo, eng_, x_pitch=None, x2=None, split_c=0):
+        k_alg = 147 if self.stem else self.kh * self.kw * self.cin
+        nbytes = 4 * (n * ho * wo * self.cout + n * h * w * (4 if self.stem else self.cin) + self.w.numel())
+        return (2.0 * n * ho * wo * self.cout * k_alg, "wgrad M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)
+
+    undo = [tc.wrap(TE._TConv, "forward", dfwd), tc.wrap(TE._TConv, "dgrad", ddgr), tw.wrap(TE._TConv, "wgrad", dwgr)]
+    try:
+        totc, totw = [0.0, 0.0, 0.0, 0], [0.0, 0.0, 0.0, 0]
+        reps = 2
+        for i in range(reps):
+            del tc.rec[:], tw.rec[:]
+            eng.forward(imgs, labels)
+            eng.backward()
+            torch.cuda.synchronize()
+            totc = [a + b for a, b in zip(totc, _summ(tc.rec, per_layer and i == reps - 1, "igemm"))]
+            totw = [a + b for a, b in zip(totw, _summ(tw.rec, per_layer and i == reps - 1, "wgrad"))]
+    finally:
+        for u in undo:
+            u()
+    r = _roof(totc, reps, dtype)
+    w = _roof(totw, reps, dtype)
+    r["wgrad"] = {k: w[k] for k in ("achieved", "frac", "launches_per_step", "avg_launch_us", "flop_per_launch", "ms_per_step")}
+    r["wgrad"]["kernel"] = "wgrad_kernel"
+    return r
+
+
+def _roof(tot, reps, dtype):
+    ms, fl, by, n = tot
+    achieved = fl / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
     traffic = None
     pmc = os.path.join(REPO, "profiles", "pmc_conv_bytes_per_launch.json")
@@ -113,14 +191,14 @@ def conv_roofline(model, imgs, dtype, reps=3, per_layer=False):
         except Exception:
             traffic = None
     return {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "alg_bytes_per_launch": round(tot_bytes / (launches // reps)), "launches_per_step": launches // reps,
-            "avg_launch_us": round(tot_ms * 1e3 / launches, 2), "flop_per_launch": round(tot_flop / launches),
-            "conv_ms_per_step": round(tot_ms / reps, 3)}
+            "frac": round(achieved / peak, 4), "traffic": traffic, "alg_bytes_per_launch": round(by / n),
+            "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2), "flop_per_launch": round(fl / n),
+            "ms_per_step": round(ms / reps, 3)}
 
 
-def cpu_baseline(depth, seconds, gpu_clips=32):
-    """The CPU restatement of the same graph (oracle/net_torch.py), all host cores, bounded sample."""
+def cpu_baseline(depth, seconds, mode, gpu_clips):
+    """The CPU restatement of the same step (oracle/net_torch.py) on the host cores, bounded sample; and the same
+    restatement executed by PyTorch-ROCm eager (MIOpen / rocBLAS) on this GPU."""
     from mvfnet_amd import synth
     from mvfnet_amd.arch import state_dict_shapes
     from oracle import net_torch
@@ -128,52 +206,81 @@ def cpu_baseline(depth, seconds, gpu_clips=32):
     shp = state_dict_shapes(depth)
     pre = "r%d/" % depth
     vals = synth.synth_state_dict({pre + k: v for k, v in shp.items()})
-    sd = {k: torch.from_numpy(vals[pre + k]) for k in shp}
-    clips = 4
+    train = mode == "train"
+
+    def make_sd(dev):
+        sd = {}
+        for k in shp:
+            t = torch.from_numpy(vals[pre + k]).to(dev)
+            if train and t.dtype == torch.float32 and "running" not in k:
+                t.requires_grad_(True)
+            sd[k] = t
+        return sd
+
+    def one_step(sd, imgs, labels, mom):
+        if not train:
+            with torch.no_grad():
+                return net_torch.forward_test(imgs, sd, depth, T_FRAMES, None)
+        params = {k: v for k, v in sd.items() if v.requires_grad}
+        for p in params.values():
+            p.grad = None
+        nb = {}
+        loss = net_torch.forward_train(imgs, labels, sd, depth, new_buffers=nb, dropout_ratio=0.5)
+        loss.backward()
+        with torch.no_grad():
+            net_torch.sgd_nesterov_step(params, {k: v.grad for k, v in params.items()}, mom)
+            for k, v in nb.items():
+                sd[k] = v
+        return loss
+
+    clips = 4 if not train else 2
     imgs = torch.from_numpy(synth.synth_clip_batch(clips, T_FRAMES, SIZE, SIZE, seed=7))
-    # oneDNN/OpenMP with one thread per hardware thread (256 here) thrashes; try a few team sizes, keep the best
+    labels = torch.from_numpy(synth.synth_labels(clips))
     best = None
     cands = sorted(set(t for t in (8, 16, 32, 64) if t <= cores) or {cores})
-    with torch.no_grad():
-        for thr in cands:
-            torch.set_num_threads(thr)
-            t0 = time.perf_counter()
-            net_torch.forward_test(imgs, sd, depth, T_FRAMES, None)      # warm-up (also bounds a pathological setting)
-            if time.perf_counter() - t0 > seconds:
-                continue
-            t0 = time.perf_counter()
-            n = 0
-            while True:
-                net_torch.forward_test(imgs, sd, depth, T_FRAMES, None)
-                n += 1
-                el = time.perf_counter() - t0
-                if el > seconds / len(cands) or n >= 50:
-                    break
-            rate = clips * n / el
-            if best is None or rate > best[0]:
-                best = (rate, thr, n, el)
-    if best is None:
-        return {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "sample": "no thread count finished in %.0f s" % seconds}
-    rate, thr, n, el = best
+    for thr in cands:
+        torch.set_num_threads(thr)
+        sd, mom = make_sd("cpu"), {}
+        t0 = time.perf_counter()
+        one_step(sd, imgs, labels, mom)                # warm-up (also bounds a pathological setting)
+        if time.perf_counter() - t0 > seconds:
+            continue
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            one_step(sd, imgs, labels, mom)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > seconds / len(cands) or n >= 50:
+                break
+        rate = clips * n / el
+        if best is None or rate > best[0]:
+            best = (rate, thr, n, el)
     eager = None
-    try:   # same restatement executed by PyTorch-ROCm eager (MIOpen/rocBLAS) on this GPU: the ">= 1.5x" comparator
-        gsd = {k: v.cuda() for k, v in sd.items()}
+    try:
+        gsd, gmom = make_sd("cuda"), {}
         gim = torch.randn(gpu_clips, T_FRAMES, 3, SIZE, SIZE, device="cuda")
+        glab = torch.randint(0, 400, (gpu_clips, 1), device="cuda")
         torch.backends.cudnn.benchmark = True
-        with torch.no_grad():
-            for _ in range(3):
-                net_torch.forward_test(gim, gsd, depth, T_FRAMES, None)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                net_torch.forward_test(gim, gsd, depth, T_FRAMES, None)
-            torch.cuda.synchronize()
-            eager = round(gpu_clips * 5 / (time.perf_counter() - t0), 2)
+        for _ in range(3):
+            one_step(gsd, gim, glab, gmom)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            one_step(gsd, gim, glab, gmom)
+        torch.cuda.synchronize()
+        eager = round(gpu_clips * 5 / (time.perf_counter() - t0), 2)
     except Exception as e:   # comparator only
         eager = "failed: %s" % str(e)[:80]
-    return {"torch_eager_gpu_clips_per_s": eager, "value": round(rate, 2), "unit": "clips/s", "cores": thr, "kind": "port", "host_hw_threads": cores,
-            "sample": "%d x %d clips of %dx3x%dx%d, fp32 eval forward, torch CPU (oneDNN) %d threads (best of %s), %.1f s" % (
-                n, clips, T_FRAMES, SIZE, SIZE, thr, cands, el)}
+    what = "fp32 train step (fwd+bwd+clip+SGD)" if train else "fp32 eval forward"
+    if best is None:
+        return {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "torch_eager_gpu_clips_per_s": eager,
+                "sample": "no thread count finished in %.0f s" % seconds}
+    rate, thr, n, el = best
+    return {"value": round(rate, 2), "unit": "clips/s", "cores": thr, "kind": "port", "host_hw_threads": cores,
+            "torch_eager_gpu_clips_per_s": eager,
+            "sample": "%d x %d clips of %dx3x%dx%d, %s, torch CPU (oneDNN) %d threads (best of %s), %.1f s" % (
+                n, clips, T_FRAMES, SIZE, SIZE, what, thr, cands, el)}
 
 
 def main():
@@ -181,11 +288,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                         "bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if args.mode == "train" and args.dtype != "f32":
+        raise SystemExit("--mode train is fp32 (bf16 training is not built yet)")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -193,13 +302,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    model = build_model(args.depth, args.dtype)
-    model.backbone.engine().streams = args.streams
+    train = args.mode == "train"
+    model = build_model(args.depth, args.dtype, train)
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     imgs = torch.randn(args.clips, T_FRAMES, 3, SIZE, SIZE, device="cuda", generator=gen)
+    labels = torch.randint(0, 400, (args.clips, 1), device="cuda", generator=gen)
+    if train:
+        eng = model.train_engine()          # lr .015, momentum .9, wd 1e-4, clip 40: the reference's optimizer config
+        eng.dropout = 0.5
 
-    def step():
-        return model(imgs, None, return_loss=False, return_numpy=False)
+        def step():
+            return eng.train_step(imgs, labels)
+    else:
+        model.backbone.engine().streams = args.streams
+
+        def step():
+            return model(imgs, None, return_loss=False, return_numpy=False)
 
     for _ in range(args.warmup):
         out = step()
@@ -225,23 +343,29 @@ def main():
         from mvfnet_amd.arch import conv_macs_per_image
         ms = el / args.steps * 1e3
         value = world * args.clips * args.steps / el
-        flop_clip = 2.0 * conv_macs_per_image(args.depth, SIZE) * T_FRAMES
+        flop_clip = 2.0 * conv_macs_per_image(args.depth, SIZE) * T_FRAMES * (3 if train else 1)
+        what = ("train step: fwd (batch-stat BN) + loss + bwd + %sclip + SGD-nesterov" % ("RCCL all-reduce + " if world > 1 else "")) if train \
+            else "eval-BN forward (BASELINE.json configs[1])"
         res = {
-            "metric": "clips/sec (fwd) MVFNet-R%d 8x8 224^2" % args.depth,
+            "metric": "clips/sec (%s) MVFNet-R%d 8x8 224^2" % ("fwd+bwd" if train else "fwd", args.depth),
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: MVFNet-ResNet%d 8x8, %d clips/GPU of 8x3x224x224, %s, "
-                                   "eval-BN forward through the HIP engine (stem+16 bottlenecks+9 MVF+head)" % (
-                                       args.depth, args.clips, "fp32" if args.dtype == "f32" else "bf16"),
-                       "clips_per_gpu": args.clips, "frames_per_clip": T_FRAMES, "parallelism": "replicas x%d (clips sharded, no collective)" % world},
+            "config": {"workload": "MVFNet-ResNet%d 8x8, %d clips/GPU of 8x3x224x224, %s, %s; all through the HIP C ABI "
+                                   "(stem + %s bottlenecks + MVF + TSN head)" % (
+                                       args.depth, args.clips, "fp32" if args.dtype == "f32" else "bf16", what,
+                                       {50: 16, 101: 33, 152: 50}[args.depth]),
+                       "clips_per_gpu": args.clips, "frames_per_clip": T_FRAMES,
+                       "parallelism": ("dp%d: replicas, one flat gradient all-reduce per step" % world) if train else
+                                      ("replicas x%d (clips sharded, no collective)" % world)},
             "model_tflops": round(value * flop_clip / 1e12, 2),
-            "note": "BASELINE.json's metric is quoted as fwd+bwd; this round measures the forward configuration (configs[1]) "
-                    "-- the training-mode conv stack/backward is not built yet",
         }
-        res["roofline"] = conv_roofline(model, imgs, args.dtype, per_layer=args.per_layer)
+        if train:
+            res["roofline"] = roofline_train(eng, imgs, labels, args.dtype, args.per_layer)
+        else:
+            res["roofline"] = roofline_infer(model, imgs, args.dtype, args.per_layer)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds, args.clips)
+            res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds, args.mode, args.clips)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
