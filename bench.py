@@ -237,7 +237,8 @@ def cpu_baseline(depth, seconds, mode, gpu_clips):
     imgs = torch.from_numpy(synth.synth_clip_batch(clips, T_FRAMES, SIZE, SIZE, seed=7))
     labels = torch.from_numpy(synth.synth_labels(clips))
     best = None
-    cands = sorted(set(t for t in (8, 16, 32, 64) if t <= cores) or {cores})
+    # oneDNN with one thread per hardware thread (256 here) thrashes for minutes; 8-16 threads measured best on this host
+    cands = sorted(set(t for t in ((8, 16) if train else (8, 16, 32)) if t <= cores) or {cores})
     for thr in cands:
         torch.set_num_threads(thr)
         sd, mom = make_sd("cpu"), {}
