@@ -33,7 +33,7 @@ ColPlan col_plan(long M, int C) {
     p.cqb = cqb;
     p.rl = kThreads / cqb;
     p.gx = (cq + cqb - 1) / cqb;
-    long want = std::max<long>(1, 2048 / p.gx);                  // ~2048 blocks in total
+    long want = std::max<long>(1, 1024 / p.gx);                  // ~1024 blocks in total
     long rows = std::max<long>((M + want - 1) / want, (long)p.rl * 8);
     rows = (rows + p.rl - 1) / p.rl * p.rl;
     p.rows = (int)rows;
@@ -88,16 +88,37 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const ET* z, long M,
     }
 }
 
-__global__ void bn_stats_finalize_kernel(int C, int nblk, long M, const float* part, const float* gamma, const float* beta,
+// partial sums [nblk][C][2] -> per-channel (s1, s2) in fp64; 32 channels x 8 block-lanes per workgroup, fixed order
+__device__ __forceinline__ bool reduce_partials(const float* part, int C, int nblk, int& c, double& s1, double& s2) {
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int k = bl; k < nblk; k += 8) {
+            const float2 v = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
+            a += v.x;
+            b += v.y;
+        }
+    }
+    sh[0][bl][cl] = a;
+    sh[1][bl][cl] = b;
+    __syncthreads();
+    if (bl != 0 || c >= C) return false;
+    s1 = s2 = 0.0;
+    for (int k = 0; k < 8; ++k) {
+        s1 += sh[0][k][cl];
+        s2 += sh[1][k][cl];
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(int C, int nblk, long M, const float* part, const float* gamma, const float* beta,
                                          float eps, float momentum, float* running_mean, float* running_var,
                                          float* save_mean, float* save_invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += part[((long)b * C + c) * 2];
-        s2 += part[((long)b * C + c) * 2 + 1];
-    }
+    int c;
+    double s1, s2;
+    if (!reduce_partials(part, C, nblk, c, s1, s2)) return;
     const double K = running_mean ? (double)running_mean[c] : 0.0;
     const double d = s1 / (double)M;
     const double mean = K + d;
@@ -191,14 +212,10 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const ET* g, in
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(int C, int nblk, const float* part, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += part[((long)b * C + c) * 2];
-        s2 += part[((long)b * C + c) * 2 + 1];
-    }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nblk, const float* part, float* dgamma, float* dbeta) {
+    int c;
+    double s1, s2;
+    if (!reduce_partials(part, C, nblk, c, s1, s2)) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
 }
@@ -213,18 +230,27 @@ __global__ void bn_bwd_apply_kernel(const ET* g, int g_pitch, const ET* z, long 
     const float inv_m = 1.0f / (float)M;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % cq4) * 4;
-        float gv[4], zv[4], o[4];
-        { float4 t = ld4(g + (i / cq4) * g_pitch + c); gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w; }
-        { float4 t = ld4(z + i * 4); zv[0] = t.x; zv[1] = t.y; zv[2] = t.z; zv[3] = t.w; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float gk = gv[k];
-            if (mask_mode == 2 && !((zv[k] * scale[c + k] + shift[c + k]) > 0.f)) gk = 0.f;
-            if (mask_mode == 3) gk *= hswish_grad_f(zv[k] * scale[c + k] + shift[c + k]);
-            const float xh = (zv[k] - mean[c + k]) * invstd[c + k];
-            o[k] = gamma[c + k] * invstd[c + k] * (gk - dbeta[c + k] * inv_m - xh * dgamma[c + k] * inv_m);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c), mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 rs = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 dg = *reinterpret_cast<const float4*>(dgamma + c), db = *reinterpret_cast<const float4*>(dbeta + c);
+        float4 gv = ld4(g + (i / cq4) * g_pitch + c);
+        const float4 zv = ld4(z + i * 4);
+        if (mask_mode >= 2) {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+            if (mask_mode == 2) {
+                gv.x = (zv.x * sc.x + sh.x) > 0.f ? gv.x : 0.f; gv.y = (zv.y * sc.y + sh.y) > 0.f ? gv.y : 0.f;
+                gv.z = (zv.z * sc.z + sh.z) > 0.f ? gv.z : 0.f; gv.w = (zv.w * sc.w + sh.w) > 0.f ? gv.w : 0.f;
+            } else {
+                gv.x *= hswish_grad_f(zv.x * sc.x + sh.x); gv.y *= hswish_grad_f(zv.y * sc.y + sh.y);
+                gv.z *= hswish_grad_f(zv.z * sc.z + sh.z); gv.w *= hswish_grad_f(zv.w * sc.w + sh.w);
+            }
         }
-        st4(dz + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+        float4 o;
+        o.x = ga.x * rs.x * (gv.x - db.x * inv_m - ((zv.x - mu.x) * rs.x) * dg.x * inv_m);
+        o.y = ga.y * rs.y * (gv.y - db.y * inv_m - ((zv.y - mu.y) * rs.y) * dg.y * inv_m);
+        o.z = ga.z * rs.z * (gv.z - db.z * inv_m - ((zv.z - mu.z) * rs.z) * dg.z * inv_m);
+        o.w = ga.w * rs.w * (gv.w - db.w * inv_m - ((zv.w - mu.w) * rs.w) * dg.w * inv_m);
+        st4(dz + i * 4, o);
     }
 }
 
@@ -442,7 +468,7 @@ int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const f
     else
         hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const bf16_t*)z, m, c, running_mean, p.cqb, p.rows, part);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, st, c, p.gy, m, part, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, st, c, p.gy, m, part, gamma, beta, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd, scale, shift);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
@@ -476,7 +502,7 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const bf16_t*)g, g_pitch, (const bf16_t*)z, (const bf16_t*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (bf16_t*)gm_out, p.cqb, p.rows, part);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, st, c, p.gy, part, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, st, c, p.gy, part, dgamma, dbeta);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

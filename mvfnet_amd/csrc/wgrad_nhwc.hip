@@ -132,18 +132,19 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
 // dW_oihw[co][ci][kh][kw] = sum_s part[s][co][(kh*KWP + kw)*CINP + ci]   (KWP/CINP = packed extents; stem: 8 / 4)
 __global__ void wgrad_reduce_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
                                     float* dw) {
-    const long total = (long)cout * cin * kh * kw;
+    // threads run over the PACKED layout (coalesced reads of the nsplit partial slabs); the write is the transposing one
     const long K = (long)kh * kwp * cinp;
+    const long total = (long)cout * K;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long t = i;
-        const int x = (int)(t % kw); t /= kw;
-        const int y = (int)(t % kh); t /= kh;
-        const int ci = (int)(t % cin);
-        const int co = (int)(t / cin);
-        const long src = (long)co * K + ((long)y * kwp + x) * cinp + ci;
+        const int ci = (int)(t % cinp); t /= cinp;
+        const int x = (int)(t % kwp); t /= kwp;
+        const int y = (int)(t % kh);
+        const int co = (int)(t / kh);
+        if (ci >= cin || x >= kw) continue;
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(long)k * cout * K + src];
-        dw[i] = s;
+        for (int k = 0; k < nsplit; ++k) s += part[(long)k * total + i];
+        dw[(((long)co * cin + ci) * kh + y) * kw + x] = s;
     }
 }
 
@@ -204,7 +205,7 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
     MVF_LAUNCH_CHECK();
-    const long total = (long)d->cout * cin_real * d->kh * kw_real;
+    const long total = (long)d->cout * d->kh * d->kw * d->cin;
     const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, a.part, nsplit,
                        d->cout, cin_real, kh_p, kw_real, kw_packed, cin_packed, dw_oihw);
