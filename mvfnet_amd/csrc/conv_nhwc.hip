@@ -47,7 +47,10 @@ struct ConvArgs {
     char* y;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int xps, split_c, x2ps, relu;
-    int dil;       // input dilation (dgrad of a strided conv: the gradient map is read as if zero-upsampled)
+    int dil;       // input dilation (generic fallback; the strided data-gradient is normally decomposed into parity classes)
+    int pad_w;     // horizontal padding (pad = vertical)
+    int w_kh0, w_kw0, w_ts, w_kwfull;   // weight tap (kh,kw) of this launch = full-pack tap (kh0 + kh*ts, kw0 + kw*ts)
+    int o_s, o_ph, o_pw, o_hfull, o_wfull;   // o_s > 0: output pixel (oh,ow) lands at (oh*o_s+o_ph, ow*o_s+o_pw) of an o_hfull x o_wfull map
     int M;
     int cpt;       // chunks per tap = ceil(Cin*esz / 128)
     int nchunks;   // KH*KW*cpt
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
             const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
             const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
             a_ih0[i] = oh * a.stride - a.pad;
-            a_iw0[i] = ow * a.stride - a.pad;
+            a_iw0[i] = ow * a.stride - a.pad_w;
             a_pix0[i] = a.dil > 1 ? img * a.H * a.W : (img * a.H + a_ih0[i]) * a.W + a_iw0[i];
         } else {
             a_ih0[i] = -100000;   // never in bounds
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
                 }
             }
         }
-        const long koff = ((long)(kh * a.KW + kw) * a.Cin + cc * CE) * ESZ;
+        const long koff = ((long)((a.w_kh0 + kh * a.w_ts) * a.w_kwfull + (a.w_kw0 + kw * a.w_ts)) * a.Cin + cc * CE) * ESZ;
 #pragma unroll
         for (int i = 0; i < B_ROWS_PT; ++i) {
             rb[i] = make_uint4(0, 0, 0, 0);
@@ -180,8 +183,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_chunk();
-    store_chunk(0);
+    if (a.nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+    }
     __syncthreads();
 
     const int frag_off = (lane & 31) * kPitch + (lane >> 5) * 16;
@@ -258,7 +263,13 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
             const int m = m0 + row;
             if (m < a.M) {
                 float4 v = *reinterpret_cast<const float4*>(smem + row * CP + cq * 16);
-                const long o = (long)m * a.Cout + col;
+                long opix = m;
+                if (a.o_s > 0) {
+                    const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    opix = ((long)img * a.o_hfull + oh * a.o_s + a.o_ph) * a.o_wfull + ow * a.o_s + a.o_pw;
+                }
+                const long o = opix * a.Cout + col;
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 if (res) {
                     const float4 rv = ld4(res + o);
@@ -361,14 +372,44 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
     a.nchunks = d->kh * d->kw * a.cpt;
     a.wK = (long)d->kh * d->kw * d->cin;
     (void)esz;
+    a.pad_w = d->pad; a.w_kh0 = 0; a.w_kw0 = 0; a.w_ts = 1; a.w_kwfull = d->kw;
     hipStream_t st = (hipStream_t)stream;
-    const bool narrow = d->cout <= 64;
-    if (d->dtype == MVF_F32) {
-        if (narrow) return launch_conv<float, 4, 1, 1, 2>(a, st);
-        return launch_conv<float, 2, 2, 2, 2>(a, st);
-    }
-    if (narrow) return launch_conv<bf16_t, 4, 1, 1, 2>(a, st);
-    return launch_conv<bf16_t, 2, 2, 2, 2>(a, st);
+    auto launch = [&](const ConvArgs& aa) -> int {
+        const bool narrow = d->cout <= 64;
+        if (d->dtype == MVF_F32) {
+            if (narrow) return launch_conv<float, 4, 1, 1, 2>(aa, st);
+            return launch_conv<float, 2, 2, 2, 2>(aa, st);
+        }
+        if (narrow) return launch_conv<bf16_t, 4, 1, 1, 2>(aa, st);
+        return launch_conv<bf16_t, 2, 2, 2, 2>(aa, st);
+    };
+    if (dil == 1) return launch(a);
+    // Data gradient of a stride-s conv: output pixel (ih, iw) only sees taps with (ih - pad + kh) % s == 0, so the s*s
+    // parity classes (ih % s, iw % s) are independent plain stride-1 convs over the gradient map with ceil(k/s)-tap
+    // kernels: s*s launches doing k*k/(s*s) of the zero-upsampled work (9 taps instead of 36 for a 3x3 stride-2 conv).
+    const int s_ = dil;
+    for (int ph = 0; ph < s_; ++ph)
+        for (int pw = 0; pw < s_; ++pw) {
+            ConvArgs c = a;
+            c.dil = 1;
+            const int kh0 = ((d->pad - ph) % s_ + s_) % s_, kw0 = ((d->pad - pw) % s_ + s_) % s_;
+            c.KH = kh0 < d->kh ? (d->kh - kh0 + s_ - 1) / s_ : 0;
+            c.KW = kw0 < d->kw ? (d->kw - kw0 + s_ - 1) / s_ : 0;
+            if (c.KH == 0 || c.KW == 0) c.KH = c.KW = 0;
+            c.w_kh0 = kh0; c.w_kw0 = kw0; c.w_ts = s_; c.w_kwfull = d->kw;
+            c.pad = -((ph - d->pad + kh0) / s_);          // exact: (ph - pad + kh0) is a multiple of s
+            c.pad_w = -((pw - d->pad + kw0) / s_);
+            c.stride = 1;
+            c.Ho = (d->ho - ph + s_ - 1) / s_;
+            c.Wo = (d->wo - pw + s_ - 1) / s_;
+            if (c.Ho <= 0 || c.Wo <= 0) continue;
+            c.M = d->n * c.Ho * c.Wo;
+            c.nchunks = c.KH * c.KW * c.cpt;
+            c.o_s = s_; c.o_ph = ph; c.o_pw = pw; c.o_hfull = d->ho; c.o_wfull = d->wo;
+            int rc = launch(c);
+            if (rc) return rc;
+        }
+    return MVF_OK;
 }
 
 int mvf_pack_conv_weight(const float* w_oihw, int cout, int cin, int kh, int kw, int kw_pad, int cin_pad,

@@ -285,43 +285,50 @@ __global__ void maxpool_bn_fwd_kernel(const ET* z, int n, int h, int w, int c, i
 }
 
 // ga[input pixel] = sum over the (<=4) windows containing it of g[window] * [this pixel is the window's first max];
-// gather form (no atomics): each input pixel re-evaluates the windows that cover it.
+// gather form (no atomics): each input pixel re-evaluates the windows that cover it; 4 channels per thread.
 template <typename ET>
 __global__ void maxpool_bn_bwd_kernel(const ET* z, const ET* g, int n, int h, int w, int c, int ho, int wo,
                                       const float* scale, const float* shift, ET* ga) {
-    const long total = (long)n * h * w * c;
+    const int c4 = c >> 2;
+    const long total = (long)n * h * w * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % c);
-        long t = i / c;
+        const int cq = (int)(i % c4);
+        long t = i / c4;
         const int iw = (int)(t % w); t /= w;
         const int ih = (int)(t % h);
         const int img = (int)(t / h);
-        const float s = scale[ch], b = shift[ch];
-        const ET* zi = z + (long)img * h * w * c + ch;
-        const float mine = fmaxf(ldf(zi + ((long)ih * w + iw) * c) * s + b, 0.f);
-        float acc = 0.f;
-        for (int oh = (ih + 1 - 2 + 1) / 2; oh <= (ih + 1) / 2; ++oh) {           // windows with oh*2-1 <= ih <= oh*2+1
-            if (oh < 0 || oh >= ho) continue;
-            for (int ow = (iw + 1 - 2 + 1) / 2; ow <= (iw + 1) / 2; ++ow) {
-                if (ow < 0 || ow >= wo) continue;
-                // find the first max of window (oh, ow) in scan order
-                float best = -INFINITY;
-                int bh = -1, bw = -1;
+        const float4 s = *reinterpret_cast<const float4*>(scale + cq * 4), b = *reinterpret_cast<const float4*>(shift + cq * 4);
+        const ET* zi = z + (long)img * h * w * c + cq * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {                 // windows with oh*2-1 <= ih <= oh*2+1
+            if (oh >= ho) continue;
+            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+                if (ow >= wo) continue;
+                float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int bidx[4] = {-1, -1, -1, -1};
                 for (int dy = 0; dy < 3; ++dy) {
                     const int y2 = oh * 2 - 1 + dy;
                     if (y2 < 0 || y2 >= h) continue;
                     for (int dx = 0; dx < 3; ++dx) {
                         const int x2 = ow * 2 - 1 + dx;
                         if (x2 < 0 || x2 >= w) continue;
-                        const float v = fmaxf(ldf(zi + ((long)y2 * w + x2) * c) * s + b, 0.f);
-                        if (v > best) { best = v; bh = y2; bw = x2; }
+                        const float4 q = ld4(zi + ((long)y2 * w + x2) * c);
+                        const float v[4] = {fmaxf(q.x * s.x + b.x, 0.f), fmaxf(q.y * s.y + b.y, 0.f), fmaxf(q.z * s.z + b.z, 0.f), fmaxf(q.w * s.w + b.w, 0.f)};
+                        const int idx = y2 * w + x2;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (v[k] > best[k]) { best[k] = v[k]; bidx[k] = idx; }     // first max in scan order wins
                     }
                 }
-                if (bh == ih && bw == iw) acc += ldf(g + (((long)img * ho + oh) * wo + ow) * c + ch);
+                const float4 gv = ld4(g + (((long)img * ho + oh) * wo + ow) * c + cq * 4);
+                const int me = ih * w + iw;
+                if (bidx[0] == me) acc[0] += gv.x;
+                if (bidx[1] == me) acc[1] += gv.y;
+                if (bidx[2] == me) acc[2] += gv.z;
+                if (bidx[3] == me) acc[3] += gv.w;
             }
         }
-        (void)mine;
-        stf(ga + i, acc);
+        st4(ga + i * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
 }
 
@@ -537,9 +544,9 @@ int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const flo
 
 int mvf_maxpool_bn_relu_bwd(const void* z, const void* g, int n, int h, int w, int c, const float* scale, const float* shift,
                             void* ga, int dtype, void* stream) {
-    MVF_REQUIRE(z && g && ga && scale && shift && n > 0 && h > 0 && w > 0 && c > 0, MVF_EINVAL, "maxpool_bn_relu_bwd: bad argument");
+    MVF_REQUIRE(z && g && ga && scale && shift && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool_bn_relu_bwd: bad argument");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
-    const long total = (long)n * h * w * c;
+    const long total = (long)n * h * w * (c / 4);
     if (dtype == MVF_F32)
         hipLaunchKernelGGL(maxpool_bn_bwd_kernel<float>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (const float*)z, (const float*)g, n, h, w, c, ho, wo, scale, shift, (float*)ga);
     else

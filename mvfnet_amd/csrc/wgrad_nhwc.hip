@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int BCO = 128, BK = 128, BMR = 32;       // output tile (co x kcol), pixel rows per chunk
+constexpr int BMR = 32;                             // pixel rows per chunk
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct WgArgs {
@@ -29,18 +29,23 @@ struct WgArgs {
     int M, K, rows_per_split, tiles_k;
 };
 
+// Output tile BCO x BK = (2*TM*32) x (2*TN*32): 128x128 (TM=TN=2), 64x128 for Cout <= 64 (TM=1), 128x64 for K <= 64 (TN=1)
+template <int TM, int TN>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
+    constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
+    constexpr int UA = BCO / 4, UB = BK / 4;           // 16-B units per row of each operand tile
+    constexpr int PA = BMR * UA / kThreads, PB = BMR * UB / kThreads;   // units per thread per chunk
     __shared__ __attribute__((aligned(16))) float Ds[2][BMR][BCO];
     __shared__ __attribute__((aligned(16))) float Xs[2][BMR][BK];
     const int tile_k = blockIdx.x % a.tiles_k, tile_co = blockIdx.x / a.tiles_k;
     const int co0 = tile_co * BCO, k0 = tile_k * BK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int q = tid & 31, lrow = tid >> 5;                 // loader: 16-B unit within the 128-wide row, row-in-8
-    // this thread's fixed column of each operand
-    const int co = co0 + q * 4;
+    // loaders: thread -> (16-B unit q within the row, first row); rows advance by kThreads/U per pass
+    const int qa = tid % UA, ra0 = tid / UA, qb = tid % UB, rb0 = tid / UB;
+    const int co = co0 + qa * 4;
     const bool co_ok = co < a.Cout;
-    const int kcol = k0 + q * 4;
+    const int kcol = k0 + qb * 4;
     const bool k_ok = kcol < a.K;
     const int tap = k_ok ? kcol / a.Cin : 0;
     const int ci = k_ok ? kcol - tap * a.Cin : 0;
@@ -53,38 +58,39 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     const int nchunks = (m_end - m_begin + BMR - 1) / BMR;
 
-    float4 rd[4], rx[4];
+    float4 rd[PA], rx[PB];
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m_begin + c * BMR + lrow + 8 * i;
+        for (int i = 0; i < PA; ++i) {
+            const int m = m_begin + c * BMR + ra0 + (kThreads / UA) * i;
             rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end && co_ok) rd[i] = *reinterpret_cast<const float4*>(a.dz + (long)m * a.Cout + co);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int m = m_begin + c * BMR + rb0 + (kThreads / UB) * i;
             rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_end) {
-                if (co_ok) rd[i] = *reinterpret_cast<const float4*>(a.dz + (long)m * a.Cout + co);
-                if (k_ok) {
-                    const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
-                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-                    const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
-                    if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-                        rx[i] = *reinterpret_cast<const float4*>(xb + ((long)(img * a.H + ih) * a.W + iw) * ps + ci);
-                }
+            if (m < m_end && k_ok) {
+                const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+                const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+                if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+                    rx[i] = *reinterpret_cast<const float4*>(xb + ((long)(img * a.H + ih) * a.W + iw) * ps + ci);
             }
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(&Ds[buf][lrow + 8 * i][q * 4]) = rd[i];
-            *reinterpret_cast<float4*>(&Xs[buf][lrow + 8 * i][q * 4]) = rx[i];
-        }
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4*>(&Ds[buf][ra0 + (kThreads / UA) * i][qa * 4]) = rd[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<float4*>(&Xs[buf][rb0 + (kThreads / UB) * i][qb * 4]) = rx[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -100,15 +106,15 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
         if (more) load_chunk(c + 1);
 #pragma unroll
         for (int kk = 0; kk < BMR / 2; ++kk) {
-            float fa[2], fb[2];
+            float fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = Ds[buf][2 * kk + lr][wm * 64 + i * 32 + lc];
+            for (int i = 0; i < TM; ++i) fa[i] = Ds[buf][2 * kk + lr][(wm * TM + i) * 32 + lc];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = Xs[buf][2 * kk + lr][wn * 64 + j * 32 + lc];
+            for (int j = 0; j < TN; ++j) fb[j] = Xs[buf][2 * kk + lr][(wn * TN + j) * 32 + lc];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
@@ -116,14 +122,14 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
     // partial[split][co][kcol]
     float* out = a.part + (long)blockIdx.y * a.Cout * a.K;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = k0 + wn * 64 + j * 32 + lc;
+    for (int j = 0; j < TN; ++j) {
+        const int col = k0 + (wn * TN + j) * 32 + lc;
         if (col >= a.K) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
+                const int row = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
                 if (row < a.Cout) out[(long)row * a.K + col] = acc[i][j][r];
             }
     }
@@ -169,6 +175,13 @@ int plan_split(int M, int tiles) {
     return rows;
 }
 
+struct WgTile { int bco, bk; };
+WgTile pick_tile(int cout, int K) {
+    if (cout <= 64) return {64, 128};
+    if (K <= 64) return {128, 64};
+    return {128, 128};
+}
+
 }  // namespace
 
 extern "C" {
@@ -176,7 +189,8 @@ extern "C" {
 size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
     if (!d || d->cout <= 0 || d->cin <= 0) return 0;
     const int M = d->n * d->ho * d->wo, K = d->kh * d->kw * d->cin;
-    const int tiles = ((d->cout + BCO - 1) / BCO) * ((K + BK - 1) / BK);
+    const WgTile t = pick_tile(d->cout, K);
+    const int tiles = ((d->cout + t.bco - 1) / t.bco) * ((K + t.bk - 1) / t.bk);
     const int rows = plan_split(M, tiles);
     const int nsplit = (M + rows - 1) / rows;
     return align_up((size_t)nsplit * d->cout * K * sizeof(float), 256);
@@ -198,12 +212,15 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->ho; a.Wo = d->wo; a.xps = d->x_pix_stride;
     a.split_c = d->split_c; a.x2ps = d->x2_pix_stride;
     a.M = d->n * d->ho * d->wo; a.K = d->kh * d->kw * d->cin;
-    a.tiles_k = (a.K + BK - 1) / BK;
-    const int tiles = ((d->cout + BCO - 1) / BCO) * a.tiles_k;
+    const WgTile t = pick_tile(d->cout, a.K);
+    a.tiles_k = (a.K + t.bk - 1) / t.bk;
+    const int tiles = ((d->cout + t.bco - 1) / t.bco) * a.tiles_k;
     a.rows_per_split = plan_split(a.M, tiles);
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+    if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<1, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+    else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<2, 1>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
     MVF_LAUNCH_CHECK();
     const long total = (long)d->cout * d->kh * d->kw * d->cin;
     const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);

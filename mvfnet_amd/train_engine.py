@@ -116,10 +116,24 @@ class _TConv(object):
         return z, ho, wo
 
     def wgrad(self, dz, x, n, h, w, ho, wo, eng, x_pitch=None, x2=None, split_c=0):
+        """Weight gradient; issued on the engine's side stream so it overlaps the data-gradient / BN chain (they are
+        independent given dz) and fills the CUs the other chain's partial tile waves leave idle."""
         d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
-        ws = eng.workspace(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)))
         kwr, cinr, kwp, cinp = (self.kw, self.cin, 8, 4) if self.stem else (self.kw, self.cin, self.kw, self.cin)
-        check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
+        nbytes = lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d))
+        side = eng.side_stream()
+        if side is None:
+            ws = eng.workspace(nbytes)
+            check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
+            return
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ws = eng.workspace(nbytes, side=True)
+            check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
+        for t in (dz, x, x2):
+            if t is not None:
+                t.record_stream(side)
 
     def dgrad(self, dz, n, ho, wo, h, w, residual=None):
         """dx (n*h*w, cin) from dz (n*ho*wo, cout): a conv of dz with the flipped/transposed weights."""
@@ -303,10 +317,26 @@ class _ParamStore(object):
     def grad_of(self, p):
         return self._grad_view[id(p)]
 
-    def workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.device)
-        return self._ws
+    def workspace(self, nbytes, side=False):
+        key = "_ws_side" if side else "_ws"
+        ws = getattr(self, key, None)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.device)
+            setattr(self, key, ws)
+        return ws
+
+    overlap_wgrad = True
+
+    def side_stream(self):
+        if not self.overlap_wgrad:
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
+    def join_side(self):
+        if getattr(self, "_side", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def add(self, a, b):
         """a + b (elementwise) through mvf_bn_apply with unit scale / zero shift."""
@@ -346,6 +376,7 @@ class BlockTrainer(_ParamStore):
         h, w, c = s["h"], s["w"], s["c"]
         g = g_nchw.permute(0, 2, 3, 1).contiguous().view(nt * ho * wo, co)
         dx = self.blk.backward(g, nt, self)
+        self.join_side()
         return dx.view(nt, h, w, c).permute(0, 3, 1, 2)
 
 
@@ -428,6 +459,7 @@ class TrainEngine(_ParamStore):
         check(lib.mvf_maxpool_bn_relu_bwd(_p(s["z0"]), _p(g), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(ga), F32, _st()), "maxpool bwd")
         dz0 = self.stem_bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2)
         self.stem.wgrad(dz0, s["xp"], nt, s["hp"], s["wp"], ho, wo, self)
+        self.join_side()
         self.saved = None
 
     def allreduce_grads(self):
