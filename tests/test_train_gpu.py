@@ -297,3 +297,29 @@ def test_forward_train_autograd_api_and_external_optimizer():
     m.eval()
     s = m(imgs, None, return_loss=False)
     assert s.shape == (2, 400) and np.isfinite(s).all()
+
+
+def test_r101_16x4_train_loss_vs_oracle_and_runner_resume(tmp_path):
+    """BASELINE config 4 family (R101, T=16; reduced to 2 clips at 64^2): train-mode loss vs the CPU oracle, then the
+    runner shell: 2 iterations, checkpoint, resume."""
+    from mvfnet_amd.runner import Runner
+    from oracle import net_torch
+    m = _model(101, 16)
+    cpu_sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 16, 64, 64, seed=4))
+    labels = torch.from_numpy(synth.synth_labels(2, seed=4))
+    with torch.no_grad():
+        ref = float(net_torch.forward_train(imgs, labels, cpu_sd, 101))
+    run = Runner(m, work_dir=str(tmp_path), ckpt_interval=1, log_interval=0, warmup_iters=10)
+    loss = run.engine.forward(imgs.cuda(), labels.cuda())
+    assert abs(float(loss) - ref) < 1e-4 * abs(ref)
+    run.engine.backward()
+    loader = [dict(img_group=imgs.cuda(), label=labels.cuda())] * 2
+    run.run(loader, max_epochs=1)
+    assert run.iter == 2 and (tmp_path / "epoch_1.pth").exists() and (tmp_path / "latest.pth").exists()
+    w_after = m.backbone.conv1.weight.detach().clone()
+    m2 = _model(101, 16)
+    run2 = Runner(m2, work_dir=str(tmp_path), log_interval=0)
+    run2.resume(str(tmp_path / "latest.pth"))
+    assert run2.epoch == 1 and run2.iter == 2 and torch.equal(m2.backbone.conv1.weight, w_after)
+    assert torch.equal(run2.engine.flat_mom, run.engine.flat_mom)
