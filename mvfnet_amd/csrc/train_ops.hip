@@ -33,7 +33,7 @@ ColPlan col_plan(long M, int C) {
     p.cqb = cqb;
     p.rl = kThreads / cqb;
     p.gx = (cq + cqb - 1) / cqb;
-    long want = std::max<long>(1, 1024 / p.gx);                  // ~1024 blocks in total
+    long want = std::max<long>(1, 512 / p.gx);                   // ~512 blocks in total (2 per CU)
     long rows = std::max<long>((M + want - 1) / want, (long)p.rl * 8);
     rows = (rows + p.rl - 1) / p.rl * p.rl;
     p.rows = (int)rows;

@@ -136,21 +136,35 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
 }
 
 // dW_oihw[co][ci][kh][kw] = sum_s part[s][co][(kh*KWP + kw)*CINP + ci]   (KWP/CINP = packed extents; stem: 8 / 4)
-__global__ void wgrad_reduce_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
                                     float* dw) {
-    // threads run over the PACKED layout (coalesced reads of the nsplit partial slabs); the write is the transposing one
+    // 64 consecutive packed elements x 4 split-lanes per workgroup: coalesced 256-B reads of every partial slab, four
+    // independent accumulators per lane for memory-level parallelism, fixed summation order (deterministic)
+    __shared__ float red[4][64];
     const long K = (long)kh * kwp * cinp;
     const long total = (long)cout * K;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < total) {
+        int k = sl;
+        for (; k + 12 < nsplit; k += 16) {
+            s0 += part[(long)k * total + i];
+            s1 += part[(long)(k + 4) * total + i];
+            s2 += part[(long)(k + 8) * total + i];
+            s3 += part[(long)(k + 12) * total + i];
+        }
+        for (; k < nsplit; k += 4) s0 += part[(long)k * total + i];
+    }
+    red[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && i < total) {
         long t = i;
         const int ci = (int)(t % cinp); t /= cinp;
         const int x = (int)(t % kwp); t /= kwp;
         const int y = (int)(t % kh);
         const int co = (int)(t / kh);
-        if (ci >= cin || x >= kw) continue;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(long)k * total + i];
-        dw[(((long)co * cin + ci) * kh + y) * kw + x] = s;
+        if (ci < cin && x < kw) dw[(((long)co * cin + ci) * kh + y) * kw + x] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
 }
 
@@ -169,7 +183,7 @@ __global__ void pack_dgrad_weight_kernel(const float* w, int cout, int cin, int 
 }
 
 int plan_split(int M, int tiles) {
-    int want = std::max(1, 1536 / std::max(tiles, 1));
+    int want = std::max(1, 1024 / std::max(tiles, 1));
     int rows = std::max((M + want - 1) / want, 256);
     rows = (rows + BMR - 1) / BMR * BMR;
     return rows;
@@ -224,7 +238,7 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     MVF_LAUNCH_CHECK();
     const long total = (long)d->cout * d->kh * d->kw * d->cin;
     const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, a.part, nsplit,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, a.part, nsplit,
                        d->cout, cin_real, kh_p, kw_real, kw_packed, cin_packed, dw_oihw);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
