@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--eager-compare", action="store_true",
+                    help="also time the same restatement under PyTorch-ROCm eager on this GPU (cudnn.benchmark=True as the reference "
+                         "config sets it; MIOpen's kernel search makes this take 3-25 minutes, so it is opt-in)")
     ap.add_argument("--streams", type=int, default=2, help="infer: independent clip-group launch chains (HIP streams)")
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch timing table to stderr")
     return ap.parse_args()
@@ -199,7 +202,7 @@ def _roof(tot, reps, dtype):
             "ms_per_step": round(ms / reps, 3)}
 
 
-def cpu_baseline(depth, seconds, mode, gpu_clips):
+def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=False):
     """The CPU restatement of the same step (oracle/net_torch.py) on the host cores, bounded sample; and the same
     restatement executed by PyTorch-ROCm eager (MIOpen / rocBLAS) on this GPU."""
     from mvfnet_amd import synth
@@ -262,6 +265,8 @@ def cpu_baseline(depth, seconds, mode, gpu_clips):
             best = (rate, thr, n, el)
     eager = None
     try:
+        if not eager_compare:
+            raise RuntimeError("skipped (run bench.py --eager-compare; last measured values are in DESIGN.md section 5)")
         gsd, gmom = make_sd("cuda"), {}
         gim = torch.randn(gpu_clips, T_FRAMES, 3, SIZE, SIZE, device="cuda")
         glab = torch.randint(0, 400, (gpu_clips, 1), device="cuda")
@@ -275,7 +280,7 @@ def cpu_baseline(depth, seconds, mode, gpu_clips):
         torch.cuda.synchronize()
         eager = round(gpu_clips * 5 / (time.perf_counter() - t0), 2)
     except Exception as e:   # comparator only
-        eager = "failed: %s" % str(e)[:80]
+        eager = str(e)[:110]
     what = "fp32 train step (fwd+bwd+clip+SGD)" if train else "fp32 eval forward"
     if best is None:
         return {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "torch_eager_gpu_clips_per_s": eager,
@@ -369,7 +374,7 @@ def main():
         else:
             res["roofline"] = roofline_infer(model, imgs, args.dtype, args.per_layer)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds, args.mode, args.clips)
+            res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds, args.mode, args.clips, args.eager_compare)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
