@@ -116,6 +116,11 @@ typedef struct {
 
 int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                         const float* bias, const void* residual, void* y, void* stream);
+/* Same, with a scratch buffer (>= mvf_conv2d_workspace_bytes) that enables the stream-K decomposition of the last,
+ * partial wave of output tiles (partial accumulators + publication flags live there).  One buffer per stream. */
+size_t mvf_conv2d_workspace_bytes(const mvf_conv_desc_t* d);
+int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
+                           const float* bias, const void* residual, void* y, void* ws, size_t ws_bytes, void* stream);
 
 /* w_oihw fp32 (cout, cin, kh, kw) [x scale[cout]] -> packed [cout][kh][kw_pad][cin_pad] in `dtype`
  * (zero padded; kw_pad >= kw, cin_pad >= cin).  bias_out[co] = shift[co] (copied) when given.

@@ -56,6 +56,10 @@ def _load():
     cp = C.POINTER(ConvDesc)
     lib.mvf_conv2d_nhwc_fwd.restype = i32
     lib.mvf_conv2d_nhwc_fwd.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp]
+    lib.mvf_conv2d_workspace_bytes.restype = sz
+    lib.mvf_conv2d_workspace_bytes.argtypes = [cp]
+    lib.mvf_conv2d_nhwc_fwd_ws.restype = i32
+    lib.mvf_conv2d_nhwc_fwd_ws.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, sz, vp]
     lib.mvf_pack_conv_weight.restype = i32
     lib.mvf_pack_conv_weight.argtypes = [fp, i32, i32, i32, i32, i32, i32, fp, vp, i32, vp]
     lib.mvf_bn_fold.restype = i32

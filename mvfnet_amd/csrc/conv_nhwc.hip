@@ -76,19 +76,30 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     return base + idx;
 }
 
+// What a workgroup does with the accumulators of one (tile, chunk range) segment
+enum SegMode { SEG_FULL = 0, SEG_PRODUCE = 1, SEG_FINISH = 2 };
+
+struct SkArgs {            // stream-K tail (see launch_conv): G workgroups share `tail` tiles x nchunks chunk-units
+    float* ws;             // [G][tile elements] partial accumulators, one slot per producing workgroup
+    unsigned* flags;       // [G] 0 -> 1 when slot g is published
+    unsigned* err;         // set to 1 if a bounded spin gives up
+    int tile0;             // first tile of the tail set
+    int units_base, units_rem, G;
+};
+
 template <typename ET, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
+                                          const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(BM == kBM, "BM must be 128");
     static_assert(WM * WN == 4, "4 waves");
     constexpr int ESZ = TT<ET>::ESZ, UE = TT<ET>::UE, CE = TT<ET>::CE;
     constexpr int A_ROWS_PT = BM / 32;      // rows per thread in the A loader (256 thr = 32 rows x 8 units)
     constexpr int B_ROWS_PT = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __syncthreads();                                   // LDS hand-over from a previous segment of this workgroup
     char* As = smem;                                   // [2][BM][kPitch]
     char* Bs = smem + 2 * BM * kPitch;                 // [2][BN][kPitch]
 
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tn_i = tile % a.tiles_n, tm_i = tile / a.tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,7 +133,12 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
     }
 
     uint4 ra[A_ROWS_PT], rb[B_ROWS_PT];
-    int kh = 0, kw = 0, cc = 0;          // position of the NEXT chunk to load
+    int cc = c_begin % a.cpt, kw, kh;    // position of the NEXT chunk to load
+    {
+        const int tap = c_begin / a.cpt;
+        kh = tap / (a.KW > 0 ? a.KW : 1);
+        kw = tap - kh * a.KW;
+    }
 
     auto load_chunk = [&]() {
         const int ci = cc * CE + q * UE;                       // first channel of this thread's unit
@@ -183,16 +199,17 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (a.nchunks > 0) {
+    const int nseg = c_end - c_begin;
+    if (nseg > 0) {
         load_chunk();
         store_chunk(0);
     }
     __syncthreads();
 
     const int frag_off = (lane & 31) * kPitch + (lane >> 5) * 16;
-    for (int kc = 0; kc < a.nchunks; ++kc) {
+    for (int kc = 0; kc < nseg; ++kc) {
         const int buf = kc & 1;
-        const bool more = kc + 1 < a.nchunks;
+        const bool more = kc + 1 < nseg;
         if (more) load_chunk();
         const char* Ab = As + buf * BM * kPitch + (wm * TM * 32) * kPitch + frag_off;
         const char* Bb = Bs + buf * BN * kPitch + (wn * TN * 32) * kPitch + frag_off;
@@ -228,6 +245,49 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
         }
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
+    }
+
+    // ---- stream-K hand-over of partial accumulators (inter-workgroup, placement independent: agent-scope release on
+    // the producer, ONE relaxed poll + agent-scope acquire on the consumer; cdna_hip_programming.md Guideline 16) -----
+    if (mode == SEG_PRODUCE) {
+        float* slot = sk.ws + (long)g_self * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slot[((i * TN + j) * 16 + r) * kThreads + tid] = acc[i][j][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(sk.flags + g_self, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (mode == SEG_FINISH) {
+        for (int g = g_first; g < g_self; ++g) {
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(sk.flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 26)) {                 // bounded: never hang the device
+                        __hip_atomic_store(sk.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const float* slot = sk.ws + (long)g * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((i * TN + j) * 16 + r) * kThreads + tid];
+        }
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------
@@ -284,6 +344,46 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
+template <typename ET, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<ET, WM, WN, TM, TN>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+// Stream-K tail: the last, partial wave of tiles is NOT run one tile per workgroup (which leaves e.g. 47 % of the CUs idle
+// for 784 tiles on 512 slots); its tiles x chunks are cut into G equal contiguous unit ranges.  A range is
+// [tail part of tile A][whole tiles][head part of tile B]; a workgroup first computes and PUBLISHES the head part (so its
+// successor never waits long), then whole tiles, and last FINISHES tile A: it adds the partials published by the lower-
+// numbered workgroups that own A's earlier chunks and runs the normal fused epilogue.  Waits only ever point at lower
+// workgroup ids whose publication is the first thing they do -> no cyclic wait, no co-residency requirement.
+template <typename ET, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(kThreads) void conv_streamk_kernel(ConvArgs a, SkArgs sk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int g = blockIdx.x, nc = a.nchunks;
+    auto start_of = [&](int w) { return w < sk.units_rem ? w * (sk.units_base + 1) : sk.units_rem * (sk.units_base + 1) + (w - sk.units_rem) * sk.units_base; };
+    auto wg_of = [&](int u) {
+        const int bnd = sk.units_rem * (sk.units_base + 1);
+        return u < bnd ? u / (sk.units_base + 1) : sk.units_rem + (u - bnd) / sk.units_base;
+    };
+    const int u0 = start_of(g), u1 = start_of(g + 1);
+    const int t_first = u0 / nc, t_last = (u1 - 1) / nc;
+    const int cb_first = u0 - t_first * nc, ce_last = u1 - t_last * nc;       // chunk range ends inside the first / last tile
+    // 1) publish the trailing partial (head or middle part of tile t_last), if this range does not finish that tile
+    const bool last_partial = ce_last < nc;
+    if (last_partial) {
+        const int cb = t_last == t_first ? cb_first : 0;
+        conv_tile<ET, WM, WN, TM, TN>(a, smem, sk.tile0 + t_last, cb, ce_last, SEG_PRODUCE, sk, 0, g);
+    }
+    // 2) whole tiles, and 3) the leading tile last (it may have to gather partials from lower workgroups)
+    const int t_hi = last_partial ? t_last - 1 : t_last;
+    for (int t = t_first + 1; t <= t_hi; ++t) conv_tile<ET, WM, WN, TM, TN>(a, smem, sk.tile0 + t, 0, nc, SEG_FULL, sk, 0, g);
+    if (t_first <= t_hi) {
+        if (cb_first == 0) conv_tile<ET, WM, WN, TM, TN>(a, smem, sk.tile0 + t_first, 0, nc, SEG_FULL, sk, 0, g);
+        else conv_tile<ET, WM, WN, TM, TN>(a, smem, sk.tile0 + t_first, cb_first, nc, SEG_FINISH, sk, wg_of(t_first * nc), g);
+    }
+}
+
 template <typename ET>
 __global__ void pack_weight_kernel(const float* w, int cout, int cin, int kh, int kw, int kwp, int cinp,
                                    const float* scale, ET* out) {
@@ -312,20 +412,66 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     shift[i] = beta[i] - mean[i] * s;
 }
 
+struct SkHost {
+    void* ws;
+    size_t ws_bytes;
+};
+
+int sk_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+        }
+        slots = 2 * cus;                  // 2 workgroups per CU (72 KB LDS each)
+    }
+    return slots;
+}
+
+size_t sk_ws_bytes() { return (size_t)sk_slots() * (128 * 128 * sizeof(float)) + 4096; }
+
 template <typename ET, int WM, int WN, int TM, int TN>
-int launch_conv(const ConvArgs& a0, hipStream_t st) {
+int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     ConvArgs a = a0;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * kPitch;
     auto kern = conv_igemm_kernel<ET, WM, WN, TM, TN>;
+    auto kern_sk = conv_streamk_kernel<ET, WM, WN, TM, TN>;
     static bool attr_done = false;   // per instantiation; idempotent, so a benign race at worst
     if (!attr_done) {
         MVF_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(kThreads), lds, st, a);
+    const int tiles = a.tiles_m * a.tiles_n, slots = sk_slots();
+    const int full = tiles / slots * slots, tail = tiles - full;
+    // stream-K pays when the last wave is substantially empty and there is enough K to cut (fix-up costs ~10 us)
+    const bool use_sk = skh.ws && skh.ws_bytes >= sk_ws_bytes() && tail > 0 && tail <= (slots * 7) / 8 && a.nchunks >= 4 &&
+                        (long)tail * a.nchunks >= slots;
+    if (!use_sk) {
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(kThreads), lds, st, a);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
+    if (full > 0) {
+        hipLaunchKernelGGL(kern, dim3(full), dim3(kThreads), lds, st, a);
+        MVF_LAUNCH_CHECK();
+    }
+    SkArgs sk;
+    const long units = (long)tail * a.nchunks;
+    sk.G = slots;
+    sk.units_base = (int)(units / sk.G);
+    sk.units_rem = (int)(units % sk.G);
+    sk.tile0 = full;
+    sk.ws = (float*)skh.ws;
+    sk.flags = (unsigned*)((char*)skh.ws + (size_t)slots * (128 * 128 * sizeof(float)));
+    sk.err = sk.flags + slots;
+    MVF_HIP_OK(hipMemsetAsync(sk.flags, 0, (size_t)(slots + 1) * sizeof(unsigned), st));
+    hipLaunchKernelGGL(kern_sk, dim3(sk.G), dim3(kThreads), lds, st, a, sk);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -334,8 +480,15 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
 
 extern "C" {
 
+size_t mvf_conv2d_workspace_bytes(const mvf_conv_desc_t*) { return sk_ws_bytes(); }
+
 int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                         const float* bias, const void* residual, void* y, void* stream) {
+    return mvf_conv2d_nhwc_fwd_ws(d, x, x2, w_packed, bias, residual, y, nullptr, 0, stream);
+}
+
+int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
+                           const float* bias, const void* residual, void* y, void* ws, size_t ws_bytes, void* stream) {
     MVF_REQUIRE(d && x && w_packed && y, MVF_EINVAL, "conv2d: NULL argument");
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -374,14 +527,15 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
     (void)esz;
     a.pad_w = d->pad; a.w_kh0 = 0; a.w_kw0 = 0; a.w_ts = 1; a.w_kwfull = d->kw;
     hipStream_t st = (hipStream_t)stream;
+    SkHost skh = {ws, ws_bytes};
     auto launch = [&](const ConvArgs& aa) -> int {
         const bool narrow = d->cout <= 64;
         if (d->dtype == MVF_F32) {
-            if (narrow) return launch_conv<float, 4, 1, 1, 2>(aa, st);
-            return launch_conv<float, 2, 2, 2, 2>(aa, st);
+            if (narrow) return launch_conv<float, 4, 1, 1, 2>(aa, skh, st);
+            return launch_conv<float, 2, 2, 2, 2>(aa, skh, st);
         }
-        if (narrow) return launch_conv<bf16_t, 4, 1, 1, 2>(aa, st);
-        return launch_conv<bf16_t, 2, 2, 2, 2>(aa, st);
+        if (narrow) return launch_conv<bf16_t, 4, 1, 1, 2>(aa, skh, st);
+        return launch_conv<bf16_t, 2, 2, 2, 2>(aa, skh, st);
     };
     if (dil == 1) return launch(a);
     // Data gradient of a stride-s conv: output pixel (ih, iw) only sees taps with (ih - pad + kh) % s == 0, so the s*s

@@ -31,6 +31,19 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SK_WS = {}
+
+
+def _sk_workspace(device):
+    """Stream-K scratch (partial accumulators + flags) for the conv kernel: one buffer per (device, stream)."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    ws = _SK_WS.get(key)
+    if ws is None:
+        ws = torch.empty(lib.mvf_conv2d_workspace_bytes(None), dtype=torch.uint8, device=device)
+        _SK_WS[key] = ws
+    return ws
+
+
 class _Conv(object):
     """One packed conv (+ folded BN) and its launch descriptor."""
 
@@ -76,8 +89,9 @@ class _Conv(object):
         y = torch.empty(n, ho, wo, self.cout, dtype=self.dt, device=x.device)
         d = ConvDesc(n, h, w, self.cin, self.cout, self.kh, self.kw, stride, pad, ho, wo, c_total, _DT[self.dt], self.relu,
                      split_c, split_c)
-        check(lib.mvf_conv2d_nhwc_fwd(C.byref(d), _p(x), _p(x2), _p(self.wp), _p(self.bias), _p(residual), _p(y), _stream()),
-              "mvf_conv2d_nhwc_fwd")
+        ws = _sk_workspace(x.device)
+        check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(x), _p(x2), _p(self.wp), _p(self.bias), _p(residual), _p(y), _p(ws), ws.numel(),
+                                         _stream()), "mvf_conv2d_nhwc_fwd")
         return y, ho, wo
 
 

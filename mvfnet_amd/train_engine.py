@@ -33,6 +33,11 @@ def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _conv_ws(device):
+    from .engine import _sk_workspace
+    return _sk_workspace(device)
+
+
 class _BN(object):
     """Handles to one BatchNorm's parameters / buffers / gradient slots + per-step statistics."""
 
@@ -112,7 +117,8 @@ class _TConv(object):
             ho, wo = self.out_hw(h, w)
         d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
         z = torch.empty(n * ho * wo, self.cout, device=x.device)
-        check(lib.mvf_conv2d_nhwc_fwd(C.byref(d), _p(x), _p(x2), _p(self.wp), None, None, _p(z), _st()), "conv fwd")
+        ws = _conv_ws(x.device)
+        check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(x), _p(x2), _p(self.wp), None, None, _p(z), _p(ws), ws.numel(), _st()), "conv fwd")
         return z, ho, wo
 
     def wgrad(self, dz, x, n, h, w, ho, wo, eng, x_pitch=None, x2=None, split_c=0):
@@ -140,7 +146,8 @@ class _TConv(object):
         d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, F32, 0, 0, 0,
                      self.stride if self.stride > 1 else 0)
         dx = torch.empty(n * h * w, self.cin, device=dz.device)
-        check(lib.mvf_conv2d_nhwc_fwd(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(dx), _st()), "conv dgrad")
+        ws = _conv_ws(dz.device)
+        check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(dx), _p(ws), ws.numel(), _st()), "conv dgrad")
         return dx
 
 

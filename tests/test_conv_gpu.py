@@ -127,3 +127,44 @@ def test_stem_maxpool_head_ops_vs_oracle():
         avg = torch.empty(1, classes, device="cuda")
         check(lib.mvf_average_clip(p(out), clips, classes, kind, p(avg), None))
         assert rel_err(avg.cpu().numpy(), fn(ref).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [
+    (256, 14, 14, 256, 256, 3, 1, 1),     # 784 tiles on 512 slots: 1 full wave + stream-K tail of 272 tiles
+    (256, 7, 7, 512, 512, 3, 1, 1),       # 392 tiles: everything is tail
+    (256, 14, 14, 1024, 256, 1, 1, 0),    # K = 32 chunks
+    (200, 7, 7, 2048, 512, 1, 1, 0),      # ragged M (9800 rows, 77 tiles)
+    (256, 14, 14, 512, 64, 1, 1, 0),      # narrow tile kernel, 392 tiles
+], ids=lambda c: "n%d_%dx%d_c%d_o%d_k%d" % c[:6])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_conv_streamk_tail_matches_plain_launch_and_oracle(case, dtype):
+    """The stream-K decomposition of the last tile wave (with workspace) must equal the one-tile-per-workgroup launch
+    (without) up to fp32 summation order, for the fused bias+residual+ReLU epilogue, and match the oracle on a slice."""
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    n, h, w, cin, cout, k, stride, pad = case
+    dt = _lib.MVF_F32 if dtype == torch.float32 else _lib.MVF_BF16
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(n, h, w, cin, device="cuda", generator=gen).to(dtype)
+    wgt = torch.randn(cout, cin, k, k, device="cuda", generator=gen) * (2.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(cout, device="cuda", generator=gen) * 0.1
+    res = torch.randn(n, h, w, cout, device="cuda", generator=gen).to(dtype)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    wp = torch.empty(cout, k, k, cin, dtype=dtype, device="cuda")
+    check(lib.mvf_pack_conv_weight(p(wgt), cout, cin, k, k, k, cin, None, p(wp), dt, None))
+    d = _lib.ConvDesc(n, h, w, cin, cout, k, k, stride, pad, h, w, cin, dt, 1, 0, 0, 0)
+    y0 = torch.empty(n, h, w, cout, dtype=dtype, device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd(C.byref(d), p(x), None, p(wp), p(bias), p(res), p(y0), None))
+    ws = torch.empty(lib.mvf_conv2d_workspace_bytes(C.byref(d)), dtype=torch.uint8, device="cuda")
+    for rep in range(3):                                   # repeated launches reuse (and must re-zero) the flags
+        y1 = torch.full_like(y0, float("nan"))
+        check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), p(x), None, p(wp), p(bias), p(res), p(y1), p(ws), ws.numel(), None))
+        torch.cuda.synchronize()
+        err_flag = ws.view(torch.int32)[(ws.numel() - 4096) // 4 + 512].item()
+        assert err_flag == 0, "stream-K spin gave up"
+        assert torch.isfinite(y1.float()).all()
+        assert rel_err(y1.float().cpu().numpy(), y0.float().cpu().numpy()) < (2e-6 if dtype == torch.float32 else 1e-2)
+    sl = slice(n - 2, n)
+    ref = F.relu(F.conv2d(x[sl].float().cpu().permute(0, 3, 1, 2), (wp.float().cpu().permute(0, 3, 1, 2)), bias.cpu(), stride=stride, padding=pad)
+                 + res[sl].float().cpu().permute(0, 3, 1, 2))
+    assert rel_err(y1[sl].float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < (2e-5 if dtype == torch.float32 else 1e-2)
