@@ -163,7 +163,7 @@ def test_conv_streamk_tail_matches_plain_launch_and_oracle(case, dtype):
         err_flag = ws.view(torch.int32)[(ws.numel() - 4096) // 4 + 512].item()
         assert err_flag == 0, "stream-K spin gave up"
         assert torch.isfinite(y1.float()).all()
-        assert rel_err(y1.float().cpu().numpy(), y0.float().cpu().numpy()) < (2e-6 if dtype == torch.float32 else 1e-2)
+        assert rel_err(y1.float().cpu().numpy(), y0.float().cpu().numpy()) < (1e-5 if dtype == torch.float32 else 1e-2)   # fp32: summation order only
     sl = slice(n - 2, n)
     ref = F.relu(F.conv2d(x[sl].float().cpu().permute(0, 3, 1, 2), (wp.float().cpu().permute(0, 3, 1, 2)), bias.cpu(), stride=stride, padding=pad)
                  + res[sl].float().cpu().permute(0, 3, 1, 2))
