@@ -450,8 +450,11 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     const int tiles = a.tiles_m * a.tiles_n, slots = sk_slots();
     const int full = tiles / slots * slots, tail = tiles - full;
     // stream-K pays when the last wave is substantially empty and there is enough K to cut (fix-up costs ~10 us)
-    const bool use_sk = skh.ws && skh.ws_bytes >= sk_ws_bytes() && tail > 0 && tail <= (slots * 7) / 8 && a.nchunks >= 4 &&
-                        (long)tail * a.nchunks >= slots;
+    // one wave of tiles lasts ~nchunks x 3.9 us (fp32 MFMA, 2 workgroups per CU) / ~1 us (bf16); cutting the partial wave
+    // saves (1 - tail/slots) of that and costs ~60 us (memset + launch + 64 KB partial round trip per workgroup)
+    const float wave_us = a.nchunks * (sizeof(ET) == 4 ? 3.9f : 1.0f);
+    const bool use_sk = skh.ws && skh.ws_bytes >= sk_ws_bytes() && tail > 0 && (long)tail * a.nchunks >= slots &&
+                        (1.0f - (float)tail / slots) * wave_us > 60.0f;
     if (!use_sk) {
         hipLaunchKernelGGL(kern, dim3(tiles), dim3(kThreads), lds, st, a);
         MVF_LAUNCH_CHECK();

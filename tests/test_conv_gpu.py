@@ -133,8 +133,8 @@ def test_stem_maxpool_head_ops_vs_oracle():
     (256, 14, 14, 256, 256, 3, 1, 1),     # 784 tiles on 512 slots: 1 full wave + stream-K tail of 272 tiles
     (256, 7, 7, 512, 512, 3, 1, 1),       # 392 tiles: everything is tail
     (256, 14, 14, 1024, 256, 1, 1, 0),    # K = 32 chunks
-    (200, 7, 7, 2048, 512, 1, 1, 0),      # ragged M (9800 rows, 77 tiles)
-    (256, 14, 14, 512, 64, 1, 1, 0),      # narrow tile kernel, 392 tiles
+    (200, 7, 7, 2048, 512, 1, 1, 0),      # ragged M (9800 rows, 77 tiles x 4), K = 64 chunks
+    (256, 14, 14, 2048, 64, 1, 1, 0),     # narrow tile kernel, 392 tiles
 ], ids=lambda c: "n%d_%dx%d_c%d_o%d_k%d" % c[:6])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_conv_streamk_tail_matches_plain_launch_and_oracle(case, dtype):
