@@ -155,7 +155,7 @@ def test_conv_streamk_tail_matches_plain_launch_and_oracle(case, dtype):
     d = _lib.ConvDesc(n, h, w, cin, cout, k, k, stride, pad, h, w, cin, dt, 1, 0, 0, 0)
     y0 = torch.empty(n, h, w, cout, dtype=dtype, device="cuda")
     check(lib.mvf_conv2d_nhwc_fwd(C.byref(d), p(x), None, p(wp), p(bias), p(res), p(y0), None))
-    ws = torch.empty(lib.mvf_conv2d_workspace_bytes(C.byref(d)), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(lib.mvf_conv2d_workspace_bytes(C.byref(d)), dtype=torch.uint8, device="cuda")   # zeroed: the error word is only written by a stream-K launch
     for rep in range(3):                                   # repeated launches reuse (and must re-zero) the flags
         y1 = torch.full_like(y0, float("nan"))
         check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), p(x), None, p(wp), p(bias), p(res), p(y1), p(ws), ws.numel(), None))
