@@ -257,32 +257,36 @@ class _TBlock(object):
         h, w, c, ho, wo = s["h"], s["w"], s["c"], s["ho"], s["wo"]
         m, m2 = nt * h * w, nt * ho * wo
         gm = torch.empty_like(g)
+        # Order matters for the two-stream overlap: each weight-gradient GEMM is queued on the side stream AFTER the
+        # data-gradient GEMM that shares its dz has been queued on the main stream, so it starts when the main stream
+        # moves on to the (HBM-bound) BatchNorm-backward kernels of the next layer -- MFMA work under memory work --
+        # instead of fighting the data-gradient GEMM for the matrix cores.
         dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 1, ymask=s["out"], gm_out=gm)
-        self.c3.wgrad(dz3, s["a2"], nt, ho, wo, ho, wo, eng)
         da2 = self.c3.dgrad(dz3, nt, ho, wo, ho, wo)
+        self.c3.wgrad(dz3, s["a2"], nt, ho, wo, ho, wo, eng)
         del dz3
         dz2 = self.b2.backward(da2, self.c2.cout, s["z2"], m2, eng, 2)
         del da2
-        self.c2.wgrad(dz2, s["a1"], nt, h, w, ho, wo, eng)
         da1 = self.c2.dgrad(dz2, nt, ho, wo, h, w)
+        self.c2.wgrad(dz2, s["a1"], nt, h, w, ho, wo, eng)
         del dz2
         dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2)
         del da1
         resid = gm
         if self.cd is not None:
             dzd = self.bd.backward(gm, self.cd.cout, s["zd"], m2, eng, 0)
-            self.cd.wgrad(dzd, s["x"], nt, h, w, ho, wo, eng, x_pitch=c)
             resid = self.cd.dgrad(dzd, nt, ho, wo, h, w)
+            self.cd.wgrad(dzd, s["x"], nt, h, w, ho, wo, eng, x_pitch=c)
             del dzd
         if self.mvf is None:
-            self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c)
             dx = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid)
+            self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c)
         else:
+            dxp = self.c1.dgrad(dz1, nt, h, w, h, w)
             if self.split_ok:
                 self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c, x2=s["o"], split_c=self.mvf.cs)
             else:
                 self.c1.wgrad(dz1, s["xin"], nt, h, w, h, w, eng, x_pitch=c)
-            dxp = self.c1.dgrad(dz1, nt, h, w, h, w)
             self.mvf.backward(dxp, s["x"], s["y"], nt, h, w, c, eng)
             dx = eng.add(dxp, resid)
         self.saved = None
