@@ -93,14 +93,16 @@ class _TConv(object):
             self.wp = torch.empty(self.cout, self.kh, 8, 4, device=dev)
             self.wd = None
         else:
-            self.wp = torch.empty(self.cout, self.kh, self.kw, self.cin, device=dev)
+            # a 1x1 kernel's OIHW storage (cout, cin, 1, 1) already IS the packed [cout][1][1][cin] layout: no forward pack
+            self.wp = self.w if (self.kh == 1 and self.kw == 1) else torch.empty(self.cout, self.kh, self.kw, self.cin, device=dev)
             self.wd = torch.empty(self.cin, self.kh, self.kw, self.cout, device=dev)
 
     def pack(self, need_dgrad=True):
         if self.stem:
             check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, 8, 4, None, _p(self.wp), F32, _st()), "pack")
             return
-        check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, self.kw, self.cin, None, _p(self.wp), F32, _st()), "pack")
+        if self.wp is not self.w:
+            check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, self.kw, self.cin, None, _p(self.wp), F32, _st()), "pack")
         if need_dgrad:
             check(lib.mvf_pack_conv_weight_dgrad(_p(self.w), self.cout, self.cin, self.kh, self.kw, _p(self.wd), F32, _st()), "pack_dgrad")
 
