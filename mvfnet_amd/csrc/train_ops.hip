@@ -95,11 +95,23 @@ __device__ __forceinline__ bool reduce_partials(const float* part, int C, int nb
     c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int k = bl; k < nblk; k += 8) {
+        // 4 loads in flight per lane (the loop is latency-bound: nblk/8 dependent round trips otherwise); fixed order
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+        int k = bl;
+        for (; k + 24 < nblk; k += 32) {
+            const float2 v0 = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
+            const float2 v1 = *reinterpret_cast<const float2*>(part + ((long)(k + 8) * C + c) * 2);
+            const float2 v2 = *reinterpret_cast<const float2*>(part + ((long)(k + 16) * C + c) * 2);
+            const float2 v3 = *reinterpret_cast<const float2*>(part + ((long)(k + 24) * C + c) * 2);
+            a += v0.x; b += v0.y; a1 += v1.x; b1 += v1.y; a2 += v2.x; b2 += v2.y; a3 += v3.x; b3 += v3.y;
+        }
+        for (; k < nblk; k += 8) {
             const float2 v = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
             a += v.x;
             b += v.y;
         }
+        a = (a + a1) + (a2 + a3);
+        b = (b + b1) + (b2 + b3);
     }
     sh[0][bl][cl] = a;
     sh[1][bl][cl] = b;
