@@ -306,7 +306,7 @@ def main():
         raise SystemExit("--mode train is fp32 (bf16 training is not built yet)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -319,6 +319,7 @@ def main():
     if train:
         eng = model.train_engine()          # lr .015, momentum .9, wd 1e-4, clip 40: the reference's optimizer config
         eng.dropout = 0.5
+        eng.force_allreduce = dist is not None
 
         def step():
             return eng.train_step(imgs, labels)

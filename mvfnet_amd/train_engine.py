@@ -479,10 +479,12 @@ class TrainEngine(_ParamStore):
         """reference dist_utils.py:38-49: ONE flat all-reduce (sum); the division by world size is folded into the
         optimizer kernel's grad_scale."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_allreduce):
             dist.all_reduce(self.flat_grads)
             return dist.get_world_size()
         return 1
+
+    force_allreduce = False
 
     def step(self, lr=None):
         world = self.allreduce_grads()
