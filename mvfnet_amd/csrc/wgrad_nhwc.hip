@@ -21,16 +21,19 @@ constexpr int BMR = 32;                             // pixel rows per chunk
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct WgArgs {
-    const float* dz;
-    const float* x;
-    const float* x2;
+    const void* dz;
+    const void* x;
+    const void* x2;
     float* part;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, xps, split_c, x2ps;
     int M, K, rows_per_split, tiles_k;
 };
 
 // Output tile BCO x BK = (2*TM*32) x (2*TN*32): 128x128 (TM=TN=2), 64x128 for Cout <= 64 (TM=1), 128x64 for K <= 64 (TN=1)
-template <int TM, int TN>
+// ET = storage type of dz / x (fp32 or bf16).  bf16 operands are widened to fp32 on the way into LDS and the contraction
+// runs on the exact-fp32 MFMA: the pixel-major operand shape cannot feed the bf16 MFMA (8 consecutive k per lane) without a
+// transposing read, and the weight gradient wants fp32 accumulation over ~10^6 pixels anyway.
+template <typename ET, int TM, int TN>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
     constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
     constexpr int UA = BCO / 4, UB = BK / 4;           // 16-B units per row of each operand tile
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
     const int ci = k_ok ? kcol - tap * a.Cin : 0;
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
     const bool from2 = a.split_c > 0 && ci < a.split_c;
-    const float* xb = from2 ? a.x2 : a.x;
+    const ET* xb = reinterpret_cast<const ET*>(from2 ? a.x2 : a.x);
+    const ET* dzp = reinterpret_cast<const ET*>(a.dz);
     const int ps = from2 ? a.x2ps : a.xps;
 
     const int m_begin = blockIdx.y * a.rows_per_split;
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
         for (int i = 0; i < PA; ++i) {
             const int m = m_begin + c * BMR + ra0 + (kThreads / UA) * i;
             rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_end && co_ok) rd[i] = *reinterpret_cast<const float4*>(a.dz + (long)m * a.Cout + co);
+            if (m < m_end && co_ok) rd[i] = ld4(dzp + (long)m * a.Cout + co);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
                 const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
                 const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
                 if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-                    rx[i] = *reinterpret_cast<const float4*>(xb + ((long)(img * a.H + ih) * a.W + iw) * ps + ci);
+                    rx[i] = ld4(xb + ((long)(img * a.H + ih) * a.W + iw) * ps + ci);
             }
         }
     };
@@ -215,13 +219,13 @@ size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
 int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real, int cin_real,
                           int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, void* stream) {
     MVF_REQUIRE(d && dz && x && dw_oihw, MVF_EINVAL, "wgrad: NULL argument");
-    MVF_REQUIRE(d->dtype == MVF_F32, MVF_EUNSUPPORTED, "wgrad: fp32 only in this round");
+    MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "wgrad: bad dtype");
     MVF_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride > 0, MVF_ESHAPE, "wgrad: cin/cout must be multiples of 4");
     MVF_REQUIRE(kw_packed * cin_packed == d->kw * d->cin && kw_real <= kw_packed && cin_real <= cin_packed, MVF_EINVAL, "wgrad: packed extents inconsistent");
     MVF_REQUIRE(ws && ws_bytes >= mvf_conv2d_wgrad_workspace_bytes(d), MVF_EWS, "wgrad: workspace too small");
     if (d->split_c) MVF_REQUIRE(x2 && d->kh == 1 && d->kw == 1 && d->split_c % 4 == 0, MVF_EINVAL, "wgrad: bad split_c");
     WgArgs a = {};
-    a.dz = (const float*)dz; a.x = (const float*)x; a.x2 = (const float*)x2; a.part = (float*)ws;
+    a.dz = dz; a.x = x; a.x2 = x2; a.part = (float*)ws;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw;
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->ho; a.Wo = d->wo; a.xps = d->x_pix_stride;
     a.split_c = d->split_c; a.x2ps = d->x2_pix_stride;
@@ -232,9 +236,15 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     a.rows_per_split = plan_split(a.M, tiles);
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
     hipStream_t st = (hipStream_t)stream;
-    if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<1, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
-    else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<2, 1>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+    if (d->dtype == MVF_F32) {
+        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+    } else {
+        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 1>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+    }
     MVF_LAUNCH_CHECK();
     const long total = (long)d->cout * d->kh * d->kw * d->cin;
     const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);

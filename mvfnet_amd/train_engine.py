@@ -42,6 +42,7 @@ class _BN(object):
     """Handles to one BatchNorm's parameters / buffers / gradient slots + per-step statistics."""
 
     def __init__(self, bn, eng, name):
+        self.eng = eng
         self.c = bn.num_features
         self.mod = bn
         self.gamma, self.beta = bn.weight, bn.bias
@@ -57,25 +58,25 @@ class _BN(object):
         ws = eng.workspace(lib.mvf_bn_workspace_bytes(m, self.c))
         check(lib.mvf_bn_train_stats(_p(z), m, self.c, _p(self.gamma), _p(self.beta), C.c_float(self.eps), C.c_float(self.momentum),
                                      _p(self.mod.running_mean), _p(self.mod.running_var), _p(self.mean), _p(self.invstd), _p(self.scale),
-                                     _p(self.shift), _p(ws), ws.numel(), F32, _st()), "mvf_bn_train_stats")
+                                     _p(self.shift), _p(ws), ws.numel(), eng.dt, _st()), "mvf_bn_train_stats")
         self.mod.num_batches_tracked += 1
 
     def apply(self, z, m, act, residual=None, rbn=None):
         out = torch.empty_like(z)
         check(lib.mvf_bn_apply(_p(z), m, self.c, _p(self.scale), _p(self.shift), _p(residual), _p(rbn.scale if rbn else None),
-                               _p(rbn.shift if rbn else None), act, _p(out), F32, _st()), "mvf_bn_apply")
+                               _p(rbn.shift if rbn else None), act, _p(out), self.eng.dt, _st()), "mvf_bn_apply")
         return out
 
     def backward(self, g, g_pitch, z, m, eng, mask_mode, ymask=None, gm_out=None):
         """dgamma/dbeta into the flat grad buffer; returns dz."""
         ws = eng.workspace(lib.mvf_bn_workspace_bytes(m, self.c))
         check(lib.mvf_bn_bwd_reduce(_p(g), g_pitch, _p(z), _p(ymask), m, self.c, _p(self.mean), _p(self.invstd), _p(self.scale),
-                                    _p(self.shift), mask_mode, _p(gm_out), _p(self.dgamma), _p(self.dbeta), _p(ws), ws.numel(), F32, _st()),
+                                    _p(self.shift), mask_mode, _p(gm_out), _p(self.dgamma), _p(self.dbeta), _p(ws), ws.numel(), eng.dt, _st()),
               "mvf_bn_bwd_reduce")
         src, pitch, mode = (gm_out, self.c, 0) if gm_out is not None else (g, g_pitch, mask_mode if mask_mode != 1 else 0)
         dz = torch.empty_like(z)
         check(lib.mvf_bn_bwd_apply(_p(src), pitch, _p(z), m, self.c, _p(self.gamma), _p(self.mean), _p(self.invstd), _p(self.scale),
-                                   _p(self.shift), _p(self.dgamma), _p(self.dbeta), mode, _p(dz), F32, _st()), "mvf_bn_bwd_apply")
+                                   _p(self.shift), _p(self.dgamma), _p(self.dbeta), mode, _p(dz), eng.dt, _st()), "mvf_bn_bwd_apply")
         return dz
 
 
@@ -83,33 +84,36 @@ class _TConv(object):
     """One conv's parameter handle, per-step packed weights (forward and data-gradient) and launch helpers."""
 
     def __init__(self, conv, eng, stem=False):
+        self.eng = eng
         self.w = conv.weight
         self.dw = eng.grad_of(conv.weight)
         self.cout, self.cin, self.kh, self.kw = conv.weight.shape
         self.stride, self.pad = conv.stride[0], conv.padding[0]
         self.stem = stem
         dev = conv.weight.device
+        td = eng.tdtype
         if stem:
-            self.wp = torch.empty(self.cout, self.kh, 8, 4, device=dev)
+            self.wp = torch.empty(self.cout, self.kh, 8, 4, device=dev, dtype=td)
             self.wd = None
         else:
-            # a 1x1 kernel's OIHW storage (cout, cin, 1, 1) already IS the packed [cout][1][1][cin] layout: no forward pack
-            self.wp = self.w if (self.kh == 1 and self.kw == 1) else torch.empty(self.cout, self.kh, self.kw, self.cin, device=dev)
-            self.wd = torch.empty(self.cin, self.kh, self.kw, self.cout, device=dev)
+            # a 1x1 kernel's fp32 OIHW storage (cout, cin, 1, 1) already IS the packed [cout][1][1][cin] layout: no forward pack
+            same = self.kh == 1 and self.kw == 1 and td == torch.float32
+            self.wp = self.w if same else torch.empty(self.cout, self.kh, self.kw, self.cin, device=dev, dtype=td)
+            self.wd = torch.empty(self.cin, self.kh, self.kw, self.cout, device=dev, dtype=td)
 
     def pack(self, need_dgrad=True):
         if self.stem:
-            check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, 8, 4, None, _p(self.wp), F32, _st()), "pack")
+            check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, 8, 4, None, _p(self.wp), self.eng.dt, _st()), "pack")
             return
         if self.wp is not self.w:
-            check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, self.kw, self.cin, None, _p(self.wp), F32, _st()), "pack")
+            check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, self.kw, self.cin, None, _p(self.wp), self.eng.dt, _st()), "pack")
         if need_dgrad:
-            check(lib.mvf_pack_conv_weight_dgrad(_p(self.w), self.cout, self.cin, self.kh, self.kw, _p(self.wd), F32, _st()), "pack_dgrad")
+            check(lib.mvf_pack_conv_weight_dgrad(_p(self.w), self.cout, self.cin, self.kh, self.kw, _p(self.wd), self.eng.dt, _st()), "pack_dgrad")
 
     def desc(self, n, h, w, ho, wo, x_pitch, split_c=0):
         if self.stem:
-            return ConvDesc(n, h, w, 32, self.cout, self.kh, 1, 2, 0, ho, wo, 4, F32, 0, 0, 0, 0)
-        return ConvDesc(n, h, w, self.cin, self.cout, self.kh, self.kw, self.stride, self.pad, ho, wo, x_pitch, F32, 0, split_c, split_c, 0)
+            return ConvDesc(n, h, w, 32, self.cout, self.kh, 1, 2, 0, ho, wo, 4, self.eng.dt, 0, 0, 0, 0)
+        return ConvDesc(n, h, w, self.cin, self.cout, self.kh, self.kw, self.stride, self.pad, ho, wo, x_pitch, self.eng.dt, 0, split_c, split_c, 0)
 
     def out_hw(self, h, w):
         return (h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1
@@ -118,7 +122,7 @@ class _TConv(object):
         if ho is None:
             ho, wo = self.out_hw(h, w)
         d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
-        z = torch.empty(n * ho * wo, self.cout, device=x.device)
+        z = torch.empty(n * ho * wo, self.cout, device=x.device, dtype=self.eng.tdtype)
         ws = _conv_ws(x.device)
         check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(x), _p(x2), _p(self.wp), None, None, _p(z), _p(ws), ws.numel(), _st()), "conv fwd")
         return z, ho, wo
@@ -145,9 +149,9 @@ class _TConv(object):
 
     def dgrad(self, dz, n, ho, wo, h, w, residual=None):
         """dx (n*h*w, cin) from dz (n*ho*wo, cout): a conv of dz with the flipped/transposed weights."""
-        d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, F32, 0, 0, 0,
+        d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, self.eng.dt, 0, 0, 0,
                      self.stride if self.stride > 1 else 0)
-        dx = torch.empty(n * h * w, self.cin, device=dz.device)
+        dx = torch.empty(n * h * w, self.cin, device=dz.device, dtype=self.eng.tdtype)
         ws = _conv_ws(dz.device)
         check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(dx), _p(ws), ws.numel(), _st()), "conv dgrad")
         return dx
@@ -155,6 +159,7 @@ class _TConv(object):
 
 class _TMvf(object):
     def __init__(self, mvf, eng):
+        self.eng = eng
         self.cs, self.T = mvf.num_shift_channel, mvf.n_segment
         self.mode = _lib.MODE_BITS[mvf.mode]
         self.share, self.use_hs = mvf.share, mvf.use_hs
@@ -171,12 +176,12 @@ class _TMvf(object):
         self.tmp_w = torch.empty(cs, 3, device=dev) if self.dww is None else None
 
     def desc(self, nt, h, w, c):
-        return MvfDesc(nt, c, h, w, self.T, self.cs, self.mode, _lib.MVF_NHWC, F32)
+        return MvfDesc(nt, c, h, w, self.T, self.cs, self.mode, _lib.MVF_NHWC, self.eng.dt)
 
     def forward(self, x, nt, h, w, c, eng):
         m = nt * h * w
         d = self.desc(nt, h, w, c)
-        y = torch.empty(m, self.cs, device=x.device)
+        y = torch.empty(m, self.cs, device=x.device, dtype=self.eng.tdtype)
         check(lib.mvf_nhwc_stencil(C.byref(d), _p(x), c, _p(y), self.cs, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 0, _st()), "mvf stencil")
         if not self.use_hs:
             return y, y
@@ -215,7 +220,7 @@ class _TBlock(object):
         self.cd = self.bd = None
         if blk.downsample is not None:
             self.cd, self.bd = _TConv(blk.downsample[0], eng), _BN(blk.downsample[1], eng, "down")
-        self.split_ok = self.mvf is not None and self.mvf.cs % 32 == 0
+        self.split_ok = self.mvf is not None and self.mvf.cs % (32 if eng.tdtype == torch.float32 else 64) == 0
 
     def convs(self):
         return [c for c in (self.c1, self.c2, self.c3, self.cd) if c is not None]
@@ -298,7 +303,11 @@ class _TBlock(object):
 class _ParamStore(object):
     """Flat fp32 parameter / gradient / momentum buffers for a module; its nn.Parameters become views."""
 
-    def _init_store(self, model):
+    def _init_store(self, model, dtype=torch.float32):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("training dtype must be float32 or bfloat16 (activation storage; weights/statistics/gradients stay fp32)")
+        self.tdtype = dtype
+        self.dt = _lib.MVF_F32 if dtype == torch.float32 else _lib.MVF_BF16
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("the HIP training engine needs the model on an MI355X device; no CPU fallback")
@@ -358,7 +367,7 @@ class _ParamStore(object):
             self._ones[c] = (torch.ones(c, device=a.device), torch.zeros(c, device=a.device))
         one, zero = self._ones[c]
         out = torch.empty_like(a)
-        check(lib.mvf_bn_apply(_p(a), m, c, _p(one), _p(zero), _p(b), None, None, 0, _p(out), F32, _st()), "add")
+        check(lib.mvf_bn_apply(_p(a), m, c, _p(one), _p(zero), _p(b), None, None, 0, _p(out), self.dt, _st()), "add")
         return out
 
     def attach_grads(self):
@@ -370,8 +379,8 @@ class _ParamStore(object):
 class BlockTrainer(_ParamStore):
     """Train-mode forward/backward of ONE mvfnet_amd Bottleneck (with or without MVF) -- used by the parity tests."""
 
-    def __init__(self, block):
-        self._init_store(block)
+    def __init__(self, block, dtype=torch.float32):
+        self._init_store(block, dtype)
         self.blk = _TBlock(block, self)
 
     def forward(self, x_nchw):
@@ -379,7 +388,7 @@ class BlockTrainer(_ParamStore):
         self.nt = nt
         for cv in self.blk.convs():
             cv.pack()
-        x = x_nchw.permute(0, 2, 3, 1).contiguous().view(nt * h * w, c)
+        x = x_nchw.permute(0, 2, 3, 1).contiguous().view(nt * h * w, c).to(self.tdtype)
         out, ho, wo, co = self.blk.forward(x, nt, h, w, c, self)
         return out.view(nt, ho, wo, co).permute(0, 3, 1, 2)
 
@@ -387,7 +396,7 @@ class BlockTrainer(_ParamStore):
         nt, co, ho, wo = g_nchw.shape
         s = self.blk.saved
         h, w, c = s["h"], s["w"], s["c"]
-        g = g_nchw.permute(0, 2, 3, 1).contiguous().view(nt * ho * wo, co)
+        g = g_nchw.permute(0, 2, 3, 1).contiguous().view(nt * ho * wo, co).to(self.tdtype)
         dx = self.blk.backward(g, nt, self)
         self.join_side()
         return dx.view(nt, h, w, c).permute(0, 3, 1, 2)
@@ -396,8 +405,11 @@ class BlockTrainer(_ParamStore):
 class TrainEngine(_ParamStore):
     """One-GPU training step for a mvfnet_amd Recognizer2D (fp32)."""
 
-    def __init__(self, model, lr=0.015, momentum=0.9, weight_decay=1e-4, max_norm=40.0):
-        self._init_store(model)
+    def __init__(self, model, lr=0.015, momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype=torch.float32):
+        """dtype = storage type of activations and packed weights (float32 | bfloat16).  With bfloat16 the accumulation,
+        BatchNorm statistics, all parameter gradients, the master weights and the optimizer stay fp32 (what the
+        reference's own fp16 mode keeps in fp32, codes/core/fp16/hooks.py:12-136; no loss scaling is needed for bf16)."""
+        self._init_store(model, dtype)
         self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
         bb = model.backbone
         self.stem, self.stem_bn = _TConv(bb.conv1, self, stem=True), _BN(bb.bn1, self, "bn1")
@@ -421,14 +433,14 @@ class TrainEngine(_ParamStore):
             for cv in blk.convs():
                 cv.pack()
         hp, wp = h + 6, (w + 6 + 2 + 1) // 2 * 2
-        xp = torch.empty(nt, hp, wp, 4, device=x.device)
-        check(lib.mvf_stem_prep(_p(x), nt, 3, h, w, 3, wp, _p(xp), F32, _st()), "stem_prep")
+        xp = torch.empty(nt, hp, wp, 4, device=x.device, dtype=self.tdtype)
+        check(lib.mvf_stem_prep(_p(x), nt, 3, h, w, 3, wp, _p(xp), self.dt, _st()), "stem_prep")
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
         z0, _, _ = self.stem.forward(xp, nt, hp, wp, ho=ho, wo=wo)
         self.stem_bn.stats(z0, nt * ho * wo, self)
         h2, w2 = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
-        p0 = torch.empty(nt * h2 * w2, 64, device=x.device)
-        check(lib.mvf_maxpool_bn_relu_fwd(_p(z0), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(p0), F32, _st()), "maxpool fwd")
+        p0 = torch.empty(nt * h2 * w2, 64, device=x.device, dtype=self.tdtype)
+        check(lib.mvf_maxpool_bn_relu_fwd(_p(z0), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(p0), self.dt, _st()), "maxpool fwd")
         self.saved = dict(xp=xp, z0=z0, nt=nt, hp=hp, wp=wp, ho=ho, wo=wo, t=t, b=b)
         if stages is not None:
             stages["maxpool"] = p0.view(nt, h2, w2, 64)
@@ -454,7 +466,7 @@ class TrainEngine(_ParamStore):
         loss_part = torch.empty(b, device=dev)
         loss = torch.empty(1, device=dev)
         check(lib.mvf_head_train_fwd(_p(xcur), b, t, hc * wc, cc, _p(self.fc_w), _p(self.fc_b), self.num_classes, _p(lab), _p(mask), _p(pooled),
-                                     _p(scores), _p(dscores), _p(loss_part), _p(loss), F32, _st()), "head fwd")
+                                     _p(scores), _p(dscores), _p(loss_part), _p(loss), self.dt, _st()), "head fwd")
         self.saved.update(pooled=pooled, dscores=dscores, mask=mask, hw=hc * wc, c=cc, feat_shape=xcur.shape, scores=scores)
         return loss
 
@@ -462,14 +474,14 @@ class TrainEngine(_ParamStore):
         s = self.saved
         nt, b, t = s["nt"], s["b"], s["t"]
         dpool = torch.empty(b, s["c"], device=self.device)
-        g = torch.empty(s["feat_shape"], device=self.device)
+        g = torch.empty(s["feat_shape"], device=self.device, dtype=self.tdtype)
         check(lib.mvf_head_train_bwd(_p(s["dscores"]), _p(s["pooled"]), _p(self.fc_w), _p(s["mask"]), b, t, s["hw"], s["c"], self.num_classes,
-                                     _p(self.dfc_w), _p(self.dfc_b), _p(dpool), _p(g), F32, _st()), "head bwd")
+                                     _p(self.dfc_w), _p(self.dfc_b), _p(dpool), _p(g), self.dt, _st()), "head bwd")
         for blk in reversed(self.blocks):
             g = blk.backward(g, nt, self)
         ho, wo = s["ho"], s["wo"]
-        ga = torch.empty(nt * ho * wo, 64, device=self.device)
-        check(lib.mvf_maxpool_bn_relu_bwd(_p(s["z0"]), _p(g), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(ga), F32, _st()), "maxpool bwd")
+        ga = torch.empty(nt * ho * wo, 64, device=self.device, dtype=self.tdtype)
+        check(lib.mvf_maxpool_bn_relu_bwd(_p(s["z0"]), _p(g), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(ga), self.dt, _st()), "maxpool bwd")
         dz0 = self.stem_bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2)
         self.stem.wgrad(dz0, s["xp"], nt, s["hp"], s["wp"], ho, wo, self)
         self.join_side()
