@@ -44,3 +44,12 @@ def mvf_case_params(name, C, alpha, mode, share, use_hs, planes, net_kind):
     pre = "mvf/%s/" % name
     vals = synth.synth_state_dict({pre + k: v for k, v in shapes.items()})
     return {k: vals[pre + k] for k in shapes}
+
+
+def rel_l2(a, ref):
+    """||a-ref||_2 / ||ref||_2 -- for gradients under bf16 storage: a ReLU mask that flips on a near-zero activation moves
+    single elements by O(1) (max-norm useless) while leaving the gradient's energy essentially unchanged."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return float(np.sqrt(((a - ref) ** 2).sum()) / max(np.sqrt((ref ** 2).sum()), 1e-30))
