@@ -139,6 +139,151 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
     }
 }
 
+// ---- bf16 operands on the bf16 matrix cores --------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE contraction indices (= pixels) per lane, but both operands are pixel-major in
+// memory.  The tiles are staged in their natural layout ([pixel][channel], 16-B coalesced global loads, 16-B LDS stores)
+// and the transposition happens in the operand fetch: a lane gathers its 8 pixels with eight 2-byte LDS reads
+// (32 lanes read 32 consecutive channels of one pixel row -> 64 contiguous bytes, conflict-free; the two half-waves are 8
+// rows apart).  That is 8x the LDS instructions of a k-major tile, but this GEMM is L2/HBM-bound long before that (64 x
+// (128+128) x 2 B of operands per 16 MFMAs), and it is 4x fewer HBM bytes and 16x the matrix rate of widening to fp32.
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int BMR16 = 64;                            // pixels per chunk = 4 MFMA k-steps
+
+template <int TM, int TN>
+__global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
+    constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
+    constexpr int PA = BCO * 2 + 16, PB = BK * 2 + 16;              // LDS row pitches in bytes
+    constexpr int UA = BCO / 8, UB = BK / 8;                        // 16-B units (8 bf16) per row
+    constexpr int NA = BMR16 * UA / kThreads, NB = BMR16 * UB / kThreads;
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    char* Ds = smem16;                                              // [2][BMR16][PA]
+    char* Xs = smem16 + 2 * BMR16 * PA;                             // [2][BMR16][PB]
+    const int tile_k = blockIdx.x % a.tiles_k, tile_co = blockIdx.x / a.tiles_k;
+    const int co0 = tile_co * BCO, k0 = tile_k * BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int qa = tid % UA, ra0 = tid / UA, qb = tid % UB, rb0 = tid / UB;
+    const int co = co0 + qa * 8;
+    const bool co_ok = co < a.Cout;
+    const int kcol = k0 + qb * 8;
+    const bool k_ok = kcol < a.K;
+    const int tap = k_ok ? kcol / a.Cin : 0;
+    const int ci = k_ok ? kcol - tap * a.Cin : 0;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const bool from2 = a.split_c > 0 && ci < a.split_c;
+    const bf16_t* xb = reinterpret_cast<const bf16_t*>(from2 ? a.x2 : a.x);
+    const bf16_t* dzp = reinterpret_cast<const bf16_t*>(a.dz);
+    const int ps = from2 ? a.x2ps : a.xps;
+
+    const int m_begin = blockIdx.y * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nchunks = (m_end - m_begin + BMR16 - 1) / BMR16;
+
+    uint4 rd[NA], rx[NB];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m_begin + c * BMR16 + ra0 + (kThreads / UA) * i;
+            rd[i] = make_uint4(0, 0, 0, 0);
+            if (m < m_end && co_ok) rd[i] = *reinterpret_cast<const uint4*>(dzp + (long)m * a.Cout + co);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int m = m_begin + c * BMR16 + rb0 + (kThreads / UB) * i;
+            rx[i] = make_uint4(0, 0, 0, 0);
+            if (m < m_end && k_ok) {
+                const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+                const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+                if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+                    rx[i] = *reinterpret_cast<const uint4*>(xb + ((long)(img * a.H + ih) * a.W + iw) * ps + ci);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(Ds + (buf * BMR16 + ra0 + (kThreads / UA) * i) * PA + qa * 16) = rd[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(Xs + (buf * BMR16 + rb0 + (kThreads / UB) * i) * PB + qb * 16) = rx[i];
+    };
+    // 8 pixels (rows r0..r0+7) of one channel column -> the lane's MFMA operand
+    auto gather = [&](const char* base, int pitch) {
+        unsigned w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned lo = *reinterpret_cast<const unsigned short*>(base + (2 * t) * pitch);
+            const unsigned hi = *reinterpret_cast<const unsigned short*>(base + (2 * t + 1) * pitch);
+            w[t] = lo | (hi << 16);
+        }
+        bf16x8_t v;
+        __builtin_memcpy(&v, w, 16);
+        return v;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int lr = lane >> 5, lc = lane & 31;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nchunks;
+        if (more) load_chunk(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < BMR16 / 16; ++ks) {
+            const int r0 = buf * BMR16 + ks * 16 + 8 * lr;
+            bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = gather(Ds + r0 * PA + ((wm * TM + i) * 32 + lc) * 2, PA);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = gather(Xs + r0 * PB + ((wn * TN + j) * 32 + lc) * 2, PB);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = a.part + (long)blockIdx.y * a.Cout * a.K;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = k0 + (wn * TN + j) * 32 + lc;
+        if (col >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
+                if (row < a.Cout) out[(long)row * a.K + col] = acc[i][j][r];
+            }
+    }
+}
+
+template <int TM, int TN>
+int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
+    constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
+    const size_t lds = (size_t)2 * BMR16 * ((BCO * 2 + 16) + (BK * 2 + 16));
+    auto kern = wgrad_bf16_kernel<TM, TN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, nsplit), dim3(kThreads), lds, st, a);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
 // dW_oihw[co][ci][kh][kw] = sum_s part[s][co][(kh*KWP + kw)*CINP + ci]   (KWP/CINP = packed extents; stem: 8 / 4)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
                                     float* dw) {
@@ -189,7 +334,7 @@ __global__ void pack_dgrad_weight_kernel(const float* w, int cout, int cin, int 
 int plan_split(int M, int tiles) {
     int want = std::max(1, 1024 / std::max(tiles, 1));
     int rows = std::max((M + want - 1) / want, 256);
-    rows = (rows + BMR - 1) / BMR * BMR;
+    rows = (rows + 63) / 64 * 64;          // multiple of both chunk heights (32 fp32 / 64 bf16)
     return rows;
 }
 
@@ -240,7 +385,14 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
         if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
         else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
         else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
-    } else {
+    } else if (d->cin % 8 == 0 && d->cout % 8 == 0 && d->x_pix_stride % 4 == 0 && (d->split_c % 8) == 0 &&
+               ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0) {
+        int rc;
+        if (t.bco == 64) rc = launch_wgrad_bf16<1, 2>(a, tiles, nsplit, st);
+        else if (t.bk == 64) rc = launch_wgrad_bf16<2, 1>(a, tiles, nsplit, st);
+        else rc = launch_wgrad_bf16<2, 2>(a, tiles, nsplit, st);
+        if (rc) return rc;
+    } else {     // odd channel counts: widen to fp32 on the way into LDS
         if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
         else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 1>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
         else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
