@@ -8,9 +8,11 @@
 BASELINE.json's metric is "clips/sec (fwd+bwd) MVFNet-R50 8x8 224^2".  One "step" (default --mode train) = one full
 training iteration of the reference's hot path over one batch of synthetic clips already resident in HBM:
 forward with batch-statistics BatchNorm + MVF + head + cross-entropy, backward, [all-reduce of the flat gradient / world
-over RCCL when N > 1], clip_grad_norm_(40), SGD-nesterov update -- 32 clips of 8 x 3 x 224 x 224 per GPU, fp32
-(the reference trains in fp32: fp16 is commented out in its configs).  `--mode infer` is BASELINE configs[1]
-(eval-BN forward only, fp32 or bf16).
+over RCCL when N > 1], clip_grad_norm_(40), SGD-nesterov update -- 32 clips of 8 x 3 x 224 x 224 per GPU.
+Default dtype bf16 = BASELINE.json configs[2] ("batch 32/GPU bf16, DDP train step"): activations and packed weights are
+stored in bf16; accumulation, BatchNorm statistics, every parameter gradient, the master weights and the optimizer are
+fp32 (what the reference's own fp16 mode keeps in fp32).  `--dtype f32` runs the reference's shipped precision.
+`--mode infer` is BASELINE configs[1] (eval-BN forward only, fp32 by default).
 
 Clips are independent units: N GPUs hold N replicas and N disjoint batches (weak scaling); the only collective is the
 gradient all-reduce of the training step.  The timed region is bracketed by barrier + synchronize, MAX over ranks.
@@ -44,7 +46,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=None,
+                    help="activation / packed-weight storage (fp32 accumulate, statistics, gradients, master weights). Default: bf16 for "
+                         "--mode train (BASELINE.json configs[2]), f32 for --mode infer (configs[1])")
     ap.add_argument("--clips", type=int, default=32, help="clips per GPU per step")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,7 +184,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
             u()
         eng.overlap_wgrad = overlap
     r = _roof(totc, reps, dtype)
-    w = _roof(totw, reps, "f32")            # the weight gradient always contracts on the fp32 MFMA
+    w = _roof(totw, reps, dtype)
     r["wgrad"] = {k: w[k] for k in ("achieved", "frac", "launches_per_step", "avg_launch_us", "flop_per_launch", "ms_per_step")}
     r["wgrad"]["kernel"] = "wgrad_kernel"
     return r
@@ -295,6 +299,8 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=False):
 
 def main():
     args = parse()
+    if args.dtype is None:
+        args.dtype = "bf16" if args.mode == "train" else "f32"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
