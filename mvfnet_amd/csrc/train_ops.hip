@@ -33,7 +33,7 @@ ColPlan col_plan(long M, int C) {
     p.cqb = cqb;
     p.rl = kThreads / cqb;
     p.gx = (cq + cqb - 1) / cqb;
-    long want = std::max<long>(1, 512 / p.gx);                   // ~512 blocks in total (2 per CU)
+    long want = std::max<long>(1, 2048 / p.gx);                  // ~2048 blocks in total (8 per CU: these loops are latency-bound)
     long rows = std::max<long>((M + want - 1) / want, (long)p.rl * 8);
     rows = (rows + p.rl - 1) / p.rl * p.rl;
     p.rows = (int)rows;
@@ -74,12 +74,18 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const ET* z, long M,
     float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
     if (ok) {
-        for (long r = r0 + lane_r; r < r1; r += rl) {
-            float4 a = ld4(z + r * C + cq * 4);
+        auto accum = [&](float4 a) {
             a.x -= k4.x; a.y -= k4.y; a.z -= k4.z; a.w -= k4.w;
             v[0].x += a.x; v[0].y += a.y; v[0].z += a.z; v[0].w += a.w;
             v[1].x += a.x * a.x; v[1].y += a.y * a.y; v[1].z += a.z * a.z; v[1].w += a.w * a.w;
+        };
+        long r = r0 + lane_r;
+        for (; r + 3 * rl < r1; r += 4 * rl) {      // 4 independent 16-B loads in flight per lane
+            const float4 a0 = ld4(z + r * C + cq * 4), a1 = ld4(z + (r + rl) * C + cq * 4);
+            const float4 a2 = ld4(z + (r + 2 * rl) * C + cq * 4), a3 = ld4(z + (r + 3 * rl) * C + cq * 4);
+            accum(a0); accum(a1); accum(a2); accum(a3);
         }
+        for (; r < r1; r += rl) accum(ld4(z + r * C + cq * 4));
     }
     rowlane_reduce<2>(v, cqb, rl, red);
     if (ok && lane_r == 0) {
@@ -90,22 +96,23 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const ET* z, long M,
 
 // partial sums [nblk][C][2] -> per-channel (s1, s2) in fp64; 32 channels x 8 block-lanes per workgroup, fixed order
 __device__ __forceinline__ bool reduce_partials(const float* part, int C, int nblk, int& c, double& s1, double& s2) {
-    __shared__ double sh[2][8][32];
-    const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
-    c = blockIdx.x * 32 + cl;
+    constexpr int CH = 8, LN = 32;                       // channels per workgroup x block-lanes (256 threads)
+    __shared__ double sh[2][LN][CH];
+    const int cl = threadIdx.x % CH, bl = threadIdx.x / CH;
+    c = blockIdx.x * CH + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
         // 4 loads in flight per lane (the loop is latency-bound: nblk/8 dependent round trips otherwise); fixed order
         double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
         int k = bl;
-        for (; k + 24 < nblk; k += 32) {
+        for (; k + 3 * LN < nblk; k += 4 * LN) {
             const float2 v0 = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
-            const float2 v1 = *reinterpret_cast<const float2*>(part + ((long)(k + 8) * C + c) * 2);
-            const float2 v2 = *reinterpret_cast<const float2*>(part + ((long)(k + 16) * C + c) * 2);
-            const float2 v3 = *reinterpret_cast<const float2*>(part + ((long)(k + 24) * C + c) * 2);
+            const float2 v1 = *reinterpret_cast<const float2*>(part + ((long)(k + LN) * C + c) * 2);
+            const float2 v2 = *reinterpret_cast<const float2*>(part + ((long)(k + 2 * LN) * C + c) * 2);
+            const float2 v3 = *reinterpret_cast<const float2*>(part + ((long)(k + 3 * LN) * C + c) * 2);
             a += v0.x; b += v0.y; a1 += v1.x; b1 += v1.y; a2 += v2.x; b2 += v2.y; a3 += v3.x; b3 += v3.y;
         }
-        for (; k < nblk; k += 8) {
+        for (; k < nblk; k += LN) {
             const float2 v = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
             a += v.x;
             b += v.y;
@@ -118,7 +125,7 @@ __device__ __forceinline__ bool reduce_partials(const float* part, int C, int nb
     __syncthreads();
     if (bl != 0 || c >= C) return false;
     s1 = s2 = 0.0;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < LN; ++k) {
         s1 += sh[0][k][cl];
         s2 += sh[1][k][cl];
     }
@@ -197,12 +204,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const ET* g, in
     float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
     if (ok) {
-        for (long r = r0 + lane_r; r < r1; r += rl) {
+        auto body = [&](long r, float4 gv, const float4 zv, const float4 yv) {
             const long o = r * C + cq * 4;
-            float4 gv = ld4(g + r * g_pitch + cq * 4);
-            const float4 zv = ld4(z + o);
             if (mask_mode == 1) {
-                const float4 yv = ld4(ymask + o);
                 gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f; gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
             } else if (mask_mode == 2) {
                 gv.x = (zv.x * sc.x + sh.x) > 0.f ? gv.x : 0.f; gv.y = (zv.y * sc.y + sh.y) > 0.f ? gv.y : 0.f;
@@ -215,6 +219,20 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const ET* g, in
             v[0].x += gv.x; v[0].y += gv.y; v[0].z += gv.z; v[0].w += gv.w;
             v[1].x += gv.x * ((zv.x - mu.x) * rs.x); v[1].y += gv.y * ((zv.y - mu.y) * rs.y);
             v[1].z += gv.z * ((zv.z - mu.z) * rs.z); v[1].w += gv.w * ((zv.w - mu.w) * rs.w);
+        };
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        long r = r0 + lane_r;
+        for (; r + rl < r1; r += 2 * rl) {          // two rows per trip: 4-6 independent 16-B loads in flight per lane
+            const long o0 = r * C + cq * 4, o1 = (r + rl) * C + cq * 4;
+            const float4 g0 = ld4(g + r * g_pitch + cq * 4), g1 = ld4(g + (r + rl) * g_pitch + cq * 4);
+            const float4 z0 = ld4(z + o0), z1 = ld4(z + o1);
+            const float4 y0 = mask_mode == 1 ? ld4(ymask + o0) : zero4, y1 = mask_mode == 1 ? ld4(ymask + o1) : zero4;
+            body(r, g0, z0, y0);
+            body(r + rl, g1, z1, y1);
+        }
+        for (; r < r1; r += rl) {
+            const long o = r * C + cq * 4;
+            body(r, ld4(g + r * g_pitch + cq * 4), ld4(z + o), mask_mode == 1 ? ld4(ymask + o) : zero4);
         }
     }
     rowlane_reduce<2>(v, cqb, rl, red);
@@ -487,7 +505,7 @@ int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const f
     else
         hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const bf16_t*)z, m, c, running_mean, p.cqb, p.rows, part);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, st, c, p.gy, m, part, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 7) / 8), dim3(256), 0, st, c, p.gy, m, part, gamma, beta, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd, scale, shift);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
@@ -521,7 +539,7 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const bf16_t*)g, g_pitch, (const bf16_t*)z, (const bf16_t*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (bf16_t*)gm_out, p.cqb, p.rows, part);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, st, c, p.gy, part, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 7) / 8), dim3(256), 0, st, c, p.gy, part, dgamma, dbeta);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
