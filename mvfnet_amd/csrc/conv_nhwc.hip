@@ -26,6 +26,7 @@
 //  * XCD-aware tile order: the 8 XCDs get contiguous ranges of (m-tile, n-tile) pairs with n fastest, so the
 //    n-tiles that re-read one A row panel run on the same XCD and hit its L2.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -87,7 +88,9 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
     int units_base, units_rem, G;
 };
 
-template <typename ET, int WM, int WN, int TM, int TN>
+// LOWK = single-buffered A/B tiles and a two-pass (half-tile) epilogue: 36 KB of LDS instead of 72 KB -> 3-4 workgroups per CU.
+// Used for the small-K pointwise convs (1-2 K chunks), which are HBM-bound and need memory-level parallelism, not MFMA overlap.
+template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -97,8 +100,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     constexpr int A_ROWS_PT = BM / 32;      // rows per thread in the A loader (256 thr = 32 rows x 8 units)
     constexpr int B_ROWS_PT = BN / 32;
     __syncthreads();                                   // LDS hand-over from a previous segment of this workgroup
-    char* As = smem;                                   // [2][BM][kPitch]
-    char* Bs = smem + 2 * BM * kPitch;                 // [2][BN][kPitch]
+    constexpr int NBUF = LOWK ? 1 : 2;
+    char* As = smem;                                   // [NBUF][BM][kPitch]
+    char* Bs = smem + NBUF * BM * kPitch;              // [NBUF][BN][kPitch]
 
     const int tn_i = tile % a.tiles_n, tm_i = tile / a.tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
@@ -208,7 +212,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
 
     const int frag_off = (lane & 31) * kPitch + (lane >> 5) * 16;
     for (int kc = 0; kc < nseg; ++kc) {
-        const int buf = kc & 1;
+        const int buf = LOWK ? 0 : (kc & 1);
         const bool more = kc + 1 < nseg;
         if (more) load_chunk();
         const char* Ab = As + buf * BM * kPitch + (wm * TM * 32) * kPitch + frag_off;
@@ -243,7 +247,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     }
             }
         }
-        if (more) store_chunk(buf ^ 1);
+        if (LOWK) {
+            if (more) {
+                __syncthreads();                       // every wave is done reading the single buffer
+                store_chunk(0);
+            }
+        } else if (more) {
+            store_chunk(buf ^ 1);
+        }
         __syncthreads();
     }
 
@@ -297,48 +308,58 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // written out row-wise, 16 B (f32) / 8 B (bf16) per lane: whole 512-B / 256-B row segments per 32 lanes, and
     // the residual is read the same way.
     constexpr int CP = BN * 4 + 16;                      // C-tile pitch in bytes
-    static_assert(BM * CP <= 2 * (BM + BN) * kPitch, "C tile must fit in the A/B LDS buffers");
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = (wn * TN + j) * 32 + (lane & 31);
-                *reinterpret_cast<float*>(smem + row * CP + col * 4) = acc[i][j][r];
-            }
-    __syncthreads();
+    constexpr int NH = LOWK ? 2 : 1;                     // epilogue passes (row halves of the block tile)
+    constexpr int HR = BM / NH;                          // rows per pass
+    static_assert(HR * CP <= NBUF * (BM + BN) * kPitch, "C tile (or half) must fit in the A/B LDS buffers");
+    static_assert(!LOWK || (WM == 2 && TM == 2) || (WM == 4 && TM == 1), "half split follows the wave-row layout");
     constexpr int TPR = BN / 4, RPP = kThreads / TPR;   // threads per row, rows per pass
     const int cq = tid % TPR, r0 = tid / TPR;
     const int col = n0 + cq * 4;
-    if (col < a.Cout) {                                  // Cout % 4 == 0 (checked on the host)
-        ET* y = reinterpret_cast<ET*>(a.y);
-        const ET* res = reinterpret_cast<const ET*>(a.res);
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + col);
+    ET* y = reinterpret_cast<ET*>(a.y);
+    const ET* res = reinterpret_cast<const ET*>(a.res);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias && col < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + col);
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+        if (hf > 0) __syncthreads();                     // previous half fully read out
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = (wm * TM + i) * 32;
+                if (rbase / HR != hf) continue;          // this MFMA row-tile belongs to the other half
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase - hf * HR + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int cc2 = (wn * TN + j) * 32 + (lane & 31);
+                    *reinterpret_cast<float*>(smem + row * CP + cc2 * 4) = acc[i][j][r];
+                }
+            }
+        __syncthreads();
+        if (col < a.Cout) {                              // Cout % 4 == 0 (checked on the host)
 #pragma unroll 4
-        for (int ps = 0; ps < BM / RPP; ++ps) {
-            const int row = r0 + ps * RPP;
-            const int m = m0 + row;
-            if (m < a.M) {
-                float4 v = *reinterpret_cast<const float4*>(smem + row * CP + cq * 16);
-                long opix = m;
-                if (a.o_s > 0) {
-                    const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
-                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-                    opix = ((long)img * a.o_hfull + oh * a.o_s + a.o_ph) * a.o_wfull + ow * a.o_s + a.o_pw;
+            for (int ps = 0; ps < HR / RPP; ++ps) {
+                const int row = r0 + ps * RPP;
+                const int m = m0 + hf * HR + row;
+                if (m < a.M) {
+                    float4 v = *reinterpret_cast<const float4*>(smem + row * CP + cq * 16);
+                    long opix = m;
+                    if (a.o_s > 0) {
+                        const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+                        const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                        opix = ((long)img * a.o_hfull + oh * a.o_s + a.o_ph) * a.o_wfull + ow * a.o_s + a.o_pw;
+                    }
+                    const long o = opix * a.Cout + col;
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (res) {
+                        const float4 rv = ld4(res + o);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    if (a.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    st4(y + o, v);
                 }
-                const long o = opix * a.Cout + col;
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (res) {
-                    const float4 rv = ld4(res + o);
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                }
-                if (a.relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                st4(y + o, v);
             }
         }
     }
@@ -349,6 +370,13 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
     conv_tile<ET, WM, WN, TM, TN>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+template <typename ET, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<ET, WM, WN, TM, TN, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
 // Stream-K tail: the last, partial wave of tiles is NOT run one tile per workgroup (which leaves e.g. 47 % of the CUs idle
@@ -417,9 +445,13 @@ struct SkHost {
     size_t ws_bytes;
 };
 
+bool g_lowk_enabled = true;      // A/B switch for experiments (MVF_CONV_LOWK=0 disables)
+
 int sk_slots() {
     static int slots = 0;
     if (!slots) {
+        const char* e = getenv("MVF_CONV_LOWK");
+        if (e && e[0] == '0') g_lowk_enabled = false;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) {
             hipDeviceProp_t p;
@@ -441,6 +473,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     const size_t lds = (size_t)2 * (BM + BN) * kPitch;
     auto kern = conv_igemm_kernel<ET, WM, WN, TM, TN>;
     auto kern_sk = conv_streamk_kernel<ET, WM, WN, TM, TN>;
+    auto kern_lk = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN>;
     static bool attr_done = false;   // per instantiation; idempotent, so a benign race at worst
     if (!attr_done) {
         MVF_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -448,6 +481,11 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = a.tiles_m * a.tiles_n, slots = sk_slots();
+    if (a.nchunks <= 2 && g_lowk_enabled) {      // HBM-bound small-K conv: half the LDS, 3-4 workgroups per CU
+        hipLaunchKernelGGL(kern_lk, dim3(tiles), dim3(kThreads), lds / 2, st, a);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     const int full = tiles / slots * slots, tail = tiles - full;
     // stream-K pays when the last wave is substantially empty and there is enough K to cut (fix-up costs ~10 us)
     // one wave of tiles lasts ~nchunks x 3.9 us (fp32 MFMA, 2 workgroups per CU) / ~1 us (bf16); cutting the partial wave
