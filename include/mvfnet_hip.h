@@ -173,11 +173,12 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
 int mvf_bn_bwd_apply(const void* g, int g_pitch, const void* z, long m, int c, const float* gamma, const float* mean,
                      const float* invstd, const float* scale, const float* shift, const float* dgamma,
                      const float* dbeta, int mask_mode, void* dz, int dtype, void* stream);
-/* stem: y = maxpool3x3/2(relu(z*scale+shift)) and its backward w.r.t. relu(bn(z)) (resnet.py:482-484) */
+/* stem: y = maxpool3x3/2(relu(z*scale+shift)) (resnet.py:482-484).  argmax (optional, one byte per element of y) receives
+ * the window position dy*3+dx of the first maximum; the backward routes g to it: ga = dL/d relu(bn(z)). */
 int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,
-                            int dtype, void* stream);
-int mvf_maxpool_bn_relu_bwd(const void* z, const void* g, int n, int h, int w, int c, const float* scale,
-                            const float* shift, void* ga, int dtype, void* stream);
+                            unsigned char* argmax, int dtype, void* stream);
+int mvf_maxpool_bn_relu_bwd(const unsigned char* argmax, const void* g, int n, int h, int w, int c, void* ga, int dtype,
+                            void* stream);
 /* head: avg-pool per frame -> new_fc -> mean over the clip's t frames -> cross-entropy (mean over clips).
  * pooled (clips*t, c), scores (clips, classes), dscores = dloss/dscores, loss_part (clips), loss (1): all fp32. */
 int mvf_head_train_fwd(const void* feat, int clips, int t, int hw, int c, const float* fc_w, const float* fc_b, int classes,

@@ -84,9 +84,9 @@ def _load():
     lib.mvf_bn_bwd_apply.restype = i32
     lib.mvf_bn_bwd_apply.argtypes = [vp, i32, vp, i64, i32, fp, fp, fp, fp, fp, fp, fp, i32, vp, i32, vp]
     lib.mvf_maxpool_bn_relu_fwd.restype = i32
-    lib.mvf_maxpool_bn_relu_fwd.argtypes = [vp, i32, i32, i32, i32, fp, fp, vp, i32, vp]
+    lib.mvf_maxpool_bn_relu_fwd.argtypes = [vp, i32, i32, i32, i32, fp, fp, vp, vp, i32, vp]
     lib.mvf_maxpool_bn_relu_bwd.restype = i32
-    lib.mvf_maxpool_bn_relu_bwd.argtypes = [vp, vp, i32, i32, i32, i32, fp, fp, vp, i32, vp]
+    lib.mvf_maxpool_bn_relu_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp]
     lib.mvf_head_train_fwd.restype = i32
     lib.mvf_head_train_fwd.argtypes = [vp, i32, i32, i32, i32, fp, fp, i32, ll, fp, fp, fp, fp, fp, fp, i32, vp]
     lib.mvf_head_train_bwd.restype = i32

@@ -287,7 +287,7 @@ __global__ void bn_bwd_apply_kernel(const ET* g, int g_pitch, const ET* z, long 
 // ---- max-pool 3x3/2 pad 1 over relu(bn(z)) (stem), forward and backward (argmax recomputed: first max in scan order) ----
 template <typename ET>
 __global__ void maxpool_bn_fwd_kernel(const ET* z, int n, int h, int w, int c, int ho, int wo, const float* scale,
-                                      const float* shift, ET* y) {
+                                      const float* shift, ET* y, unsigned char* amax) {
     const int c4 = c >> 2;
     const long total = (long)n * ho * wo * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -298,6 +298,7 @@ __global__ void maxpool_bn_fwd_kernel(const ET* z, int n, int h, int w, int c, i
         const int img = (int)(t / ho);
         const float4 s = *reinterpret_cast<const float4*>(scale + cq * 4), b = *reinterpret_cast<const float4*>(shift + cq * 4);
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        unsigned am[4] = {0, 0, 0, 0};                    // window position (dy*3+dx) of the FIRST max, as ATen picks it
         for (int dy = 0; dy < 3; ++dy) {
             const int ih = oh * 2 - 1 + dy;
             if (ih < 0 || ih >= h) continue;
@@ -307,18 +308,24 @@ __global__ void maxpool_bn_fwd_kernel(const ET* z, int n, int h, int w, int c, i
                 float4 v = ld4(z + (((long)img * h + ih) * w + iw) * c + cq * 4);
                 v.x = fmaxf(v.x * s.x + b.x, 0.f); v.y = fmaxf(v.y * s.y + b.y, 0.f);
                 v.z = fmaxf(v.z * s.z + b.z, 0.f); v.w = fmaxf(v.w * s.w + b.w, 0.f);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                const unsigned code = dy * 3 + dx;
+                if (v.x > m.x) { m.x = v.x; am[0] = code; }
+                if (v.y > m.y) { m.y = v.y; am[1] = code; }
+                if (v.z > m.z) { m.z = v.z; am[2] = code; }
+                if (v.w > m.w) { m.w = v.w; am[3] = code; }
             }
         }
-        st4(y + (((long)img * ho + oh) * wo + ow) * c + cq * 4, m);
+        const long oidx = (((long)img * ho + oh) * wo + ow) * c + cq * 4;
+        st4(y + oidx, m);
+        if (amax) *reinterpret_cast<unsigned*>(amax + oidx) = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
     }
 }
 
-// ga[input pixel] = sum over the (<=4) windows containing it of g[window] * [this pixel is the window's first max];
-// gather form (no atomics): each input pixel re-evaluates the windows that cover it; 4 channels per thread.
+// ga[input pixel] = sum over the (<=4) windows containing it of g[window] * [this pixel is the window's arg-max].
+// Gather form (no atomics); the forward stored one byte per pooled element (window position of the first max), so the
+// backward reads 4 bytes + one 4-channel gradient per covering window instead of re-evaluating 9 activations.
 template <typename ET>
-__global__ void maxpool_bn_bwd_kernel(const ET* z, const ET* g, int n, int h, int w, int c, int ho, int wo,
-                                      const float* scale, const float* shift, ET* ga) {
+__global__ void maxpool_bn_bwd_kernel(const unsigned char* amax, const ET* g, int n, int h, int w, int c, int ho, int wo, ET* ga) {
     const int c4 = c >> 2;
     const long total = (long)n * h * w * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -327,35 +334,20 @@ __global__ void maxpool_bn_bwd_kernel(const ET* z, const ET* g, int n, int h, in
         const int iw = (int)(t % w); t /= w;
         const int ih = (int)(t % h);
         const int img = (int)(t / h);
-        const float4 s = *reinterpret_cast<const float4*>(scale + cq * 4), b = *reinterpret_cast<const float4*>(shift + cq * 4);
-        const ET* zi = z + (long)img * h * w * c + cq * 4;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {                 // windows with oh*2-1 <= ih <= oh*2+1
             if (oh >= ho) continue;
+            const unsigned dy = ih - (oh * 2 - 1);
             for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
                 if (ow >= wo) continue;
-                float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                int bidx[4] = {-1, -1, -1, -1};
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int y2 = oh * 2 - 1 + dy;
-                    if (y2 < 0 || y2 >= h) continue;
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int x2 = ow * 2 - 1 + dx;
-                        if (x2 < 0 || x2 >= w) continue;
-                        const float4 q = ld4(zi + ((long)y2 * w + x2) * c);
-                        const float v[4] = {fmaxf(q.x * s.x + b.x, 0.f), fmaxf(q.y * s.y + b.y, 0.f), fmaxf(q.z * s.z + b.z, 0.f), fmaxf(q.w * s.w + b.w, 0.f)};
-                        const int idx = y2 * w + x2;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (v[k] > best[k]) { best[k] = v[k]; bidx[k] = idx; }     // first max in scan order wins
-                    }
-                }
-                const float4 gv = ld4(g + (((long)img * ho + oh) * wo + ow) * c + cq * 4);
-                const int me = ih * w + iw;
-                if (bidx[0] == me) acc[0] += gv.x;
-                if (bidx[1] == me) acc[1] += gv.y;
-                if (bidx[2] == me) acc[2] += gv.z;
-                if (bidx[3] == me) acc[3] += gv.w;
+                const unsigned me = dy * 3 + (iw - (ow * 2 - 1));
+                const long oidx = (((long)img * ho + oh) * wo + ow) * c + cq * 4;
+                const unsigned am = *reinterpret_cast<const unsigned*>(amax + oidx);
+                const float4 gv = ld4(g + oidx);
+                if ((am & 255u) == me) acc[0] += gv.x;
+                if (((am >> 8) & 255u) == me) acc[1] += gv.y;
+                if (((am >> 16) & 255u) == me) acc[2] += gv.z;
+                if ((am >> 24) == me) acc[3] += gv.w;
             }
         }
         st4(ga + i * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
@@ -560,27 +552,26 @@ int mvf_bn_bwd_apply(const void* g, int g_pitch, const void* z, long m, int c, c
 }
 
 int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,
-                            int dtype, void* stream) {
+                            unsigned char* argmax, int dtype, void* stream) {
     MVF_REQUIRE(z && y && scale && shift && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool_bn_relu_fwd: bad argument");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
     const long total = (long)n * ho * wo * (c / 4);
     if (dtype == MVF_F32)
-        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (const float*)z, n, h, w, c, ho, wo, scale, shift, (float*)y);
+        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (const float*)z, n, h, w, c, ho, wo, scale, shift, (float*)y, argmax);
     else
-        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<bf16_t>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, n, h, w, c, ho, wo, scale, shift, (bf16_t*)y);
+        hipLaunchKernelGGL(maxpool_bn_fwd_kernel<bf16_t>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, n, h, w, c, ho, wo, scale, shift, (bf16_t*)y, argmax);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
 
-int mvf_maxpool_bn_relu_bwd(const void* z, const void* g, int n, int h, int w, int c, const float* scale, const float* shift,
-                            void* ga, int dtype, void* stream) {
-    MVF_REQUIRE(z && g && ga && scale && shift && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool_bn_relu_bwd: bad argument");
+int mvf_maxpool_bn_relu_bwd(const unsigned char* argmax, const void* g, int n, int h, int w, int c, void* ga, int dtype, void* stream) {
+    MVF_REQUIRE(argmax && g && ga && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool_bn_relu_bwd: bad argument");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
     const long total = (long)n * h * w * (c / 4);
     if (dtype == MVF_F32)
-        hipLaunchKernelGGL(maxpool_bn_bwd_kernel<float>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (const float*)z, (const float*)g, n, h, w, c, ho, wo, scale, shift, (float*)ga);
+        hipLaunchKernelGGL(maxpool_bn_bwd_kernel<float>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo, (float*)ga);
     else
-        hipLaunchKernelGGL(maxpool_bn_bwd_kernel<bf16_t>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (const bf16_t*)g, n, h, w, c, ho, wo, scale, shift, (bf16_t*)ga);
+        hipLaunchKernelGGL(maxpool_bn_bwd_kernel<bf16_t>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, argmax, (const bf16_t*)g, n, h, w, c, ho, wo, (bf16_t*)ga);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

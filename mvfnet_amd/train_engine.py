@@ -440,8 +440,9 @@ class TrainEngine(_ParamStore):
         self.stem_bn.stats(z0, nt * ho * wo, self)
         h2, w2 = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
         p0 = torch.empty(nt * h2 * w2, 64, device=x.device, dtype=self.tdtype)
-        check(lib.mvf_maxpool_bn_relu_fwd(_p(z0), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(p0), self.dt, _st()), "maxpool fwd")
-        self.saved = dict(xp=xp, z0=z0, nt=nt, hp=hp, wp=wp, ho=ho, wo=wo, t=t, b=b)
+        amax = torch.empty(nt * h2 * w2, 64, device=x.device, dtype=torch.uint8)
+        check(lib.mvf_maxpool_bn_relu_fwd(_p(z0), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(p0), _p(amax), self.dt, _st()), "maxpool fwd")
+        self.saved = dict(xp=xp, z0=z0, amax=amax, nt=nt, hp=hp, wp=wp, ho=ho, wo=wo, t=t, b=b)
         if stages is not None:
             stages["maxpool"] = p0.view(nt, h2, w2, 64)
         xcur, hc, wc, cc = p0, h2, w2, 64
@@ -481,7 +482,7 @@ class TrainEngine(_ParamStore):
             g = blk.backward(g, nt, self)
         ho, wo = s["ho"], s["wo"]
         ga = torch.empty(nt * ho * wo, 64, device=self.device, dtype=self.tdtype)
-        check(lib.mvf_maxpool_bn_relu_bwd(_p(s["z0"]), _p(g), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(ga), self.dt, _st()), "maxpool bwd")
+        check(lib.mvf_maxpool_bn_relu_bwd(_p(s["amax"]), _p(g), nt, ho, wo, 64, _p(ga), self.dt, _st()), "maxpool bwd")
         dz0 = self.stem_bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2)
         self.stem.wgrad(dz0, s["xp"], nt, s["hp"], s["wp"], ho, wo, self)
         self.join_side()

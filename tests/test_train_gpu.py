@@ -132,11 +132,12 @@ def test_stem_wgrad_maxpool_head_sgd_vs_oracle():
     pl.backward(gp)
     zg, scg, shg = nhwc(z.detach()).cuda(), sc.cuda(), sh.cuda()
     out = torch.empty(n, pl.shape[2], pl.shape[3], c, device="cuda")
-    check(lib.mvf_maxpool_bn_relu_fwd(P(zg), n, h, w, c, P(scg), P(shg), P(out), 0, None))
+    am = torch.empty(n, pl.shape[2], pl.shape[3], c, device="cuda", dtype=torch.uint8)
+    check(lib.mvf_maxpool_bn_relu_fwd(P(zg), n, h, w, c, P(scg), P(shg), P(out), P(am), 0, None))
     assert rel_err(out.cpu().permute(0, 3, 1, 2).numpy(), pl.detach().numpy()) < 1e-6
     ga = torch.empty(n, h, w, c, device="cuda")
     gpg = nhwc(gp).cuda()
-    check(lib.mvf_maxpool_bn_relu_bwd(P(zg), P(gpg), n, h, w, c, P(scg), P(shg), P(ga), 0, None))
+    check(lib.mvf_maxpool_bn_relu_bwd(P(am), P(gpg), n, h, w, c, P(ga), 0, None))
     # compare where the ReLU is active (ties among zeros route gradient to dead positions; see train_ops.hip)
     ref = a.grad * (a.detach() > 0)
     got = ga.cpu().permute(0, 3, 1, 2) * (a.detach() > 0)
