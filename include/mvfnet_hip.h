@@ -121,6 +121,12 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
 size_t mvf_conv2d_workspace_bytes(const mvf_conv_desc_t* d);
 int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                            const float* bias, const void* residual, void* y, void* ws, size_t ws_bytes, void* stream);
+/* Training forward: plain conv (no bias / residual / ReLU) whose epilogue also accumulates the BatchNorm batch statistics of
+ * the tensor it writes: stats_part [mvf_conv2d_stats_rows(d)][cout][2] = per-tile column sums of (y-K), (y-K)^2 with
+ * K = stats_shift[cout] (pass the BN's running_mean; NULL = 0).  Feed stats_part to mvf_bn_train_finalize. */
+int mvf_conv2d_stats_rows(const mvf_conv_desc_t* d);
+int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, void* y,
+                              float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes, void* stream);
 
 /* w_oihw fp32 (cout, cin, kh, kw) [x scale[cout]] -> packed [cout][kh][kw_pad][cin_pad] in `dtype`
  * (zero padded; kw_pad >= kw, cin_pad >= cin).  bias_out[co] = shift[co] (copied) when given.
@@ -160,6 +166,10 @@ size_t mvf_bn_workspace_bytes(long m, int c);
 int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
                        float* shift, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* second half of mvf_bn_train_stats for partial sums produced by mvf_conv2d_nhwc_fwd_stats (K must be the same running_mean) */
+int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                          float* scale, float* shift, void* stream);
 /* out = act(z*scale + shift [+ residual | + residual*rscale + rshift]); act: 0 none, 1 ReLU, 2 hard-swish */
 int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
                  const float* rscale, const float* rshift, int act, void* out, int dtype, void* stream);

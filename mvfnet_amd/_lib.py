@@ -60,6 +60,10 @@ def _load():
     lib.mvf_conv2d_workspace_bytes.argtypes = [cp]
     lib.mvf_conv2d_nhwc_fwd_ws.restype = i32
     lib.mvf_conv2d_nhwc_fwd_ws.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, sz, vp]
+    lib.mvf_conv2d_stats_rows.restype = i32
+    lib.mvf_conv2d_stats_rows.argtypes = [cp]
+    lib.mvf_conv2d_nhwc_fwd_stats.restype = i32
+    lib.mvf_conv2d_nhwc_fwd_stats.argtypes = [cp, vp, vp, vp, vp, fp, fp, vp, sz, vp]
     lib.mvf_pack_conv_weight.restype = i32
     lib.mvf_pack_conv_weight.argtypes = [fp, i32, i32, i32, i32, i32, i32, fp, vp, i32, vp]
     lib.mvf_bn_fold.restype = i32
@@ -77,6 +81,8 @@ def _load():
     lib.mvf_bn_workspace_bytes.argtypes = [i64, i32]
     lib.mvf_bn_train_stats.restype = i32
     lib.mvf_bn_train_stats.argtypes = [vp, i64, i32, fp, fp, f32, f32, fp, fp, fp, fp, fp, fp, vp, sz, i32, vp]
+    lib.mvf_bn_train_finalize.restype = i32
+    lib.mvf_bn_train_finalize.argtypes = [fp, i32, i64, i32, fp, fp, f32, f32, fp, fp, fp, fp, fp, fp, vp]
     lib.mvf_bn_apply.restype = i32
     lib.mvf_bn_apply.argtypes = [vp, i64, i32, fp, fp, vp, fp, fp, i32, vp, i32, vp]
     lib.mvf_bn_bwd_reduce.restype = i32

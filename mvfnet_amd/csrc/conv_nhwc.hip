@@ -52,6 +52,8 @@ struct ConvArgs {
     int pad_w;     // horizontal padding (pad = vertical)
     int w_kh0, w_kw0, w_ts, w_kwfull;   // weight tap (kh,kw) of this launch = full-pack tap (kh0 + kh*ts, kw0 + kw*ts)
     int o_s, o_ph, o_pw, o_hfull, o_wfull;   // o_s > 0: output pixel (oh,ow) lands at (oh*o_s+o_ph, ow*o_s+o_pw) of an o_hfull x o_wfull map
+    float* stats_part;         // optional [tiles_m][Cout][2]: per-tile column sums of (y - K), (y - K)^2 (BatchNorm batch statistics)
+    const float* stats_shift;  // K per output channel (the BN's old running mean; any K is exact, a close one avoids cancellation)
     int M;
     int cpt;       // chunks per tap = ceil(Cin*esz / 128)
     int nchunks;   // KH*KW*cpt
@@ -319,6 +321,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     const ET* res = reinterpret_cast<const ET*>(a.res);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias && col < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + col);
+    // fused BatchNorm statistics of the tensor being written (training): this thread's rows of its 4 columns
+    float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = st1, kk = st1;
+    if (a.stats_part && a.stats_shift && col < a.Cout) kk = *reinterpret_cast<const float4*>(a.stats_shift + col);
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
         if (hf > 0) __syncthreads();                     // previous half fully read out
@@ -359,8 +364,34 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                     st4(y + o, v);
+                    if (a.stats_part) {
+                        if (sizeof(ET) == 2) {           // statistics of what is STORED (bf16-rounded), as the consumers will read it
+                            v.x = bf16_to_f32(f32_to_bf16(v.x)); v.y = bf16_to_f32(f32_to_bf16(v.y));
+                            v.z = bf16_to_f32(f32_to_bf16(v.z)); v.w = bf16_to_f32(f32_to_bf16(v.w));
+                        }
+                        v.x -= kk.x; v.y -= kk.y; v.z -= kk.z; v.w -= kk.w;
+                        st1.x += v.x; st1.y += v.y; st1.z += v.z; st1.w += v.w;
+                        st2.x += v.x * v.x; st2.y += v.y * v.y; st2.z += v.z * v.z; st2.w += v.w * v.w;
+                    }
                 }
             }
+        }
+    }
+    if (a.stats_part) {                                  // column sums over the RPP row-threads, fixed order, one writer per column
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(smem);
+        red[(r0 * 2 + 0) * TPR + cq] = st1;
+        red[(r0 * 2 + 1) * TPR + cq] = st2;
+        __syncthreads();
+        if (r0 == 0 && col < a.Cout) {
+            float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+            for (int r = 0; r < RPP; ++r) {
+                const float4 p1 = red[(r * 2 + 0) * TPR + cq], p2 = red[(r * 2 + 1) * TPR + cq];
+                s1.x += p1.x; s1.y += p1.y; s1.z += p1.z; s1.w += p1.w;
+                s2.x += p2.x; s2.y += p2.y; s2.z += p2.z; s2.w += p2.w;
+            }
+            float* p = a.stats_part + ((long)tm_i * a.Cout + col) * 2;
+            p[0] = s1.x; p[1] = s2.x; p[2] = s1.y; p[3] = s2.y; p[4] = s1.z; p[5] = s2.z; p[6] = s1.w; p[7] = s2.w;
         }
     }
 }
@@ -528,8 +559,30 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
     return mvf_conv2d_nhwc_fwd_ws(d, x, x2, w_packed, bias, residual, y, nullptr, 0, stream);
 }
 
+static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
+                         const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
+                         void* stream);
+
 int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                            const float* bias, const void* residual, void* y, void* ws, size_t ws_bytes, void* stream) {
+    return conv_fwd_impl(d, x, x2, w_packed, bias, residual, y, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+int mvf_conv2d_stats_rows(const mvf_conv_desc_t* d) {
+    if (!d || d->n <= 0 || d->ho <= 0 || d->wo <= 0) return 0;
+    return (int)(((long)d->n * d->ho * d->wo + kBM - 1) / kBM);
+}
+
+int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, void* y,
+                              float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(stats_part, MVF_EINVAL, "conv2d_fwd_stats: stats_part is NULL");
+    MVF_REQUIRE(!d || d->in_dil <= 1, MVF_EINVAL, "conv2d_fwd_stats: not for data-gradient launches");
+    return conv_fwd_impl(d, x, x2, w_packed, nullptr, nullptr, y, stats_part, stats_shift, ws, ws_bytes, stream);
+}
+
+static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
+                         const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
+                         void* stream) {
     MVF_REQUIRE(d && x && w_packed && y, MVF_EINVAL, "conv2d: NULL argument");
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -567,6 +620,7 @@ int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* 
     a.wK = (long)d->kh * d->kw * d->cin;
     (void)esz;
     a.pad_w = d->pad; a.w_kh0 = 0; a.w_kw0 = 0; a.w_ts = 1; a.w_kwfull = d->kw;
+    a.stats_part = stats_part; a.stats_shift = stats_shift;
     hipStream_t st = (hipStream_t)stream;
     SkHost skh = {ws, ws_bytes};
     auto launch = [&](const ConvArgs& aa) -> int {

@@ -503,6 +503,17 @@ int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const f
     return MVF_OK;
 }
 
+// finalize from partial sums produced elsewhere (the conv epilogue: mvf_conv2d_nhwc_fwd_stats), layout [nblk][c][2]
+int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                          float* scale, float* shift, void* stream) {
+    MVF_REQUIRE(part && gamma && beta && save_mean && save_invstd && scale && shift && nblk > 0 && m > 0 && c > 0, MVF_EINVAL, "bn_train_finalize: bad argument");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 7) / 8), dim3(256), 0, (hipStream_t)stream, c, nblk, m, part, gamma, beta, eps, momentum,
+                       running_mean, running_var, save_mean, save_invstd, scale, shift);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
 int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
                  const float* rscale, const float* rshift, int relu, void* out, int dtype, void* stream) {
     MVF_REQUIRE(z && scale && shift && out && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_apply: bad argument");

@@ -61,6 +61,13 @@ class _BN(object):
                                      _p(self.shift), _p(ws), ws.numel(), eng.dt, _st()), "mvf_bn_train_stats")
         self.mod.num_batches_tracked += 1
 
+    def finalize(self, part, nblk, m):
+        """Batch statistics from the per-tile partial sums the conv epilogue produced (same K = old running mean)."""
+        check(lib.mvf_bn_train_finalize(_p(part), nblk, m, self.c, _p(self.gamma), _p(self.beta), C.c_float(self.eps), C.c_float(self.momentum),
+                                        _p(self.mod.running_mean), _p(self.mod.running_var), _p(self.mean), _p(self.invstd), _p(self.scale),
+                                        _p(self.shift), _st()), "mvf_bn_train_finalize")
+        self.mod.num_batches_tracked += 1
+
     def apply(self, z, m, act, residual=None, rbn=None):
         out = torch.empty_like(z)
         check(lib.mvf_bn_apply(_p(z), m, self.c, _p(self.scale), _p(self.shift), _p(residual), _p(rbn.scale if rbn else None),
@@ -118,13 +125,24 @@ class _TConv(object):
     def out_hw(self, h, w):
         return (h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1
 
-    def forward(self, x, n, h, w, x_pitch=None, x2=None, split_c=0, ho=None, wo=None):
+    def forward(self, x, n, h, w, x_pitch=None, x2=None, split_c=0, ho=None, wo=None, bn=None):
+        """z = conv(x); with `bn` the epilogue also accumulates that BatchNorm's batch statistics and they are finalised
+        right away (no separate pass over z)."""
         if ho is None:
             ho, wo = self.out_hw(h, w)
         d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
         z = torch.empty(n * ho * wo, self.cout, device=x.device, dtype=self.eng.tdtype)
         ws = _conv_ws(x.device)
-        check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(x), _p(x2), _p(self.wp), None, None, _p(z), _p(ws), ws.numel(), _st()), "conv fwd")
+        if bn is None or not self.eng.fuse_stats:
+            check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(x), _p(x2), _p(self.wp), None, None, _p(z), _p(ws), ws.numel(), _st()), "conv fwd")
+            if bn is not None:
+                bn.stats(z, n * ho * wo, self.eng)
+            return z, ho, wo
+        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        part = torch.empty(rows, self.cout, 2, device=x.device)
+        check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), _p(x), _p(x2), _p(self.wp), _p(z), _p(part), _p(bn.mod.running_mean), _p(ws), ws.numel(), _st()),
+              "conv fwd+stats")
+        bn.finalize(part, rows, n * ho * wo)
         return z, ho, wo
 
     def wgrad(self, dz, x, n, h, w, ho, wo, eng, x_pitch=None, x2=None, split_c=0):
@@ -232,25 +250,21 @@ class _TBlock(object):
             s["y"], o = self.mvf.forward(x, nt, h, w, c, eng)
             if self.split_ok:
                 s["o"] = o
-                z1, _, _ = self.c1.forward(x, nt, h, w, c, x2=o, split_c=self.mvf.cs)
+                z1, _, _ = self.c1.forward(x, nt, h, w, c, x2=o, split_c=self.mvf.cs, bn=self.b1)
             else:   # odd slice widths: materialise [o | x_rest]
                 xin = x.clone()
                 xin[:, : self.mvf.cs] = o
                 s["xin"] = xin
-                z1, _, _ = self.c1.forward(xin, nt, h, w, c)
+                z1, _, _ = self.c1.forward(xin, nt, h, w, c, bn=self.b1)
         else:
-            z1, _, _ = self.c1.forward(x, nt, h, w, c)
-        self.b1.stats(z1, m, eng)
+            z1, _, _ = self.c1.forward(x, nt, h, w, c, bn=self.b1)
         a1 = self.b1.apply(z1, m, 1)
-        z2, ho, wo = self.c2.forward(a1, nt, h, w)
+        z2, ho, wo = self.c2.forward(a1, nt, h, w, bn=self.b2)
         m2 = nt * ho * wo
-        self.b2.stats(z2, m2, eng)
         a2 = self.b2.apply(z2, m2, 1)
-        z3, _, _ = self.c3.forward(a2, nt, ho, wo)
-        self.b3.stats(z3, m2, eng)
+        z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3)
         if self.cd is not None:
-            zd, _, _ = self.cd.forward(x, nt, h, w)
-            self.bd.stats(zd, m2, eng)
+            zd, _, _ = self.cd.forward(x, nt, h, w, bn=self.bd)
             out = self.b3.apply(z3, m2, 1, residual=zd, rbn=self.bd)
             s["zd"] = zd
         else:
@@ -348,6 +362,7 @@ class _ParamStore(object):
         return ws
 
     overlap_wgrad = True
+    fuse_stats = True          # BatchNorm batch statistics accumulated in the producing conv's epilogue
 
     def side_stream(self):
         if not self.overlap_wgrad:
@@ -436,8 +451,7 @@ class TrainEngine(_ParamStore):
         xp = torch.empty(nt, hp, wp, 4, device=x.device, dtype=self.tdtype)
         check(lib.mvf_stem_prep(_p(x), nt, 3, h, w, 3, wp, _p(xp), self.dt, _st()), "stem_prep")
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
-        z0, _, _ = self.stem.forward(xp, nt, hp, wp, ho=ho, wo=wo)
-        self.stem_bn.stats(z0, nt * ho * wo, self)
+        z0, _, _ = self.stem.forward(xp, nt, hp, wp, ho=ho, wo=wo, bn=self.stem_bn)
         h2, w2 = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
         p0 = torch.empty(nt * h2 * w2, 64, device=x.device, dtype=self.tdtype)
         amax = torch.empty(nt * h2 * w2, 64, device=x.device, dtype=torch.uint8)
