@@ -149,7 +149,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
     tc, tw = _Timer(), _Timer()
     esz = 4 if dtype == "f32" else 2
 
-    def dfwd(self, out, x, n, h, w, x_pitch=None, x2=None, split_c=0, ho=None, wo=None):
+    def dfwd(self, out, x, n, h, w, x_pitch=None, x2=None, split_c=0, ho=None, wo=None, bn=None):
         z, ho, wo = out
         k_alg = 147 if self.stem else self.kh * self.kw * self.cin
         in_px = n * ho * wo if (self.kh == 1 and self.stride > 1) else n * h * w
