@@ -37,12 +37,16 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks (fp32-in / bf16)
-T_FRAMES, SIZE = 8, 224
+VIDEO = False
+T_FRAMES, SIZE = 8, 224     # overwritten from --frames / --mode video in main()
 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--mode", choices=["train", "infer", "video"], default="train",
+                    help="train = fwd+bwd+update (default, configs[2]); infer = eval forward (configs[1]); video = configs[4]: "
+                         "10 clips x 3 crops of 256^2 per video, fcn_testing head, average_clips='prob', one video per step")
+    ap.add_argument("--frames", type=int, default=8, help="frames per clip (T); 16 with --depth 101 --clips 16 is configs[3]")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -64,7 +68,8 @@ def parse():
 def build_model(depth, dtype, train):
     import mvfnet_amd
     from mvfnet_amd import synth
-    m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(depth, T_FRAMES), None, dict(average_clips=None))
+    m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(depth, T_FRAMES, fcn_testing=VIDEO), None,
+                                    dict(average_clips="prob" if VIDEO else None))
     sd = m.state_dict()
     pre = "r%d/" % depth
     vals = synth.synth_state_dict({pre + k: tuple(v.shape) for k, v in sd.items()})
@@ -298,9 +303,14 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=False):
 
 
 def main():
+    global T_FRAMES, SIZE, VIDEO
     args = parse()
     if args.dtype is None:
         args.dtype = "bf16" if args.mode == "train" else "f32"
+    T_FRAMES = args.frames
+    video = args.mode == "video"
+    if video:
+        SIZE, args.clips, args.mode, VIDEO = 256, 30, "infer", True   # 3 crops x 10 clips, ThreeCrop of a 256-short-side frame
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -320,6 +330,8 @@ def main():
     model = build_model(args.depth, args.dtype, train)
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     imgs = torch.randn(args.clips, T_FRAMES, 3, SIZE, SIZE, device="cuda", generator=gen)
+    if video:
+        imgs = imgs.reshape(1, args.clips * T_FRAMES, 3, SIZE, SIZE)      # [1, crops*clips*T, 3, 256, 256] as the test pipeline emits
     labels = torch.randint(0, 400, (args.clips, 1), device="cuda", generator=gen)
     if train:
         eng = model.train_engine(dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16)   # lr .015, mom .9, wd 1e-4, clip 40
@@ -362,19 +374,22 @@ def main():
         what = ("train step: fwd (batch-stat BN) + loss + bwd + %sclip + SGD-nesterov" % ("RCCL all-reduce + " if world > 1 else "")) if train \
             else "eval-BN forward (BASELINE.json configs[1])"
         res = {
-            "metric": "clips/sec (%s) MVFNet-R%d 8x8 224^2" % ("fwd+bwd" if train else "fwd", args.depth),
+            "metric": "clips/sec (%s) MVFNet-R%d %dx%d %d^2%s" % ("fwd+bwd" if train else "fwd", args.depth, T_FRAMES, 64 // T_FRAMES, SIZE,
+                                                                     " (30-clip videos, fcn_testing)" if video else ""),
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "MVFNet-ResNet%d 8x8, %d clips/GPU of 8x3x224x224, %s, %s; all through the HIP C ABI "
+            "config": {"workload": "MVFNet-ResNet%d %dx%d, %d clips/GPU of %dx3x%dx%d, %s, %s; all through the HIP C ABI "
                                    "(stem + %s bottlenecks + MVF + TSN head)" % (
-                                       args.depth, args.clips, "fp32" if args.dtype == "f32" else "bf16", what,
-                                       {50: 16, 101: 33, 152: 50}[args.depth]),
+                                       args.depth, T_FRAMES, 64 // T_FRAMES, args.clips, T_FRAMES, SIZE, SIZE,
+                                       "fp32" if args.dtype == "f32" else "bf16", what, {50: 16, 101: 33, 152: 50}[args.depth]),
                        "clips_per_gpu": args.clips, "frames_per_clip": T_FRAMES,
                        "parallelism": ("dp%d: replicas, one flat gradient all-reduce per step" % world) if train else
                                       ("replicas x%d (clips sharded, no collective)" % world)},
             "model_tflops": round(value * flop_clip / 1e12, 2),
         }
+        if video:
+            res["videos_per_s"] = round(value / 30.0, 2)
         if train:
             res["roofline"] = roofline_train(eng, imgs, labels, args.dtype, args.per_layer)
         else:
