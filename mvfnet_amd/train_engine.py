@@ -29,8 +29,25 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_STREAM = [None]      # cached HIP stream handle of the stream the engine is launching on (torch.cuda.current_stream() costs ~8 us)
+
+
 def _st():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _STREAM[0] if _STREAM[0] is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _on_stream(object):
+    """with _on_stream(torch_stream_or_None): every _st() inside returns that stream's handle."""
+
+    def __init__(self, stream=None):
+        self.h = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+    def __enter__(self):
+        self.old = _STREAM[0]
+        _STREAM[0] = self.h
+
+    def __exit__(self, *a):
+        _STREAM[0] = self.old
 
 
 def _conv_ws(device):
@@ -69,7 +86,7 @@ class _BN(object):
         self.mod.num_batches_tracked += 1
 
     def apply(self, z, m, act, residual=None, rbn=None):
-        out = torch.empty_like(z)
+        out = self.eng.buf((id(self), "apply"), z.shape, z.dtype)
         check(lib.mvf_bn_apply(_p(z), m, self.c, _p(self.scale), _p(self.shift), _p(residual), _p(rbn.scale if rbn else None),
                                _p(rbn.shift if rbn else None), act, _p(out), self.eng.dt, _st()), "mvf_bn_apply")
         return out
@@ -81,7 +98,7 @@ class _BN(object):
                                     _p(self.shift), mask_mode, _p(gm_out), _p(self.dgamma), _p(self.dbeta), _p(ws), ws.numel(), eng.dt, _st()),
               "mvf_bn_bwd_reduce")
         src, pitch, mode = (gm_out, self.c, 0) if gm_out is not None else (g, g_pitch, mask_mode if mask_mode != 1 else 0)
-        dz = torch.empty_like(z)
+        dz = eng.buf((id(self), "dz"), z.shape, z.dtype)
         check(lib.mvf_bn_bwd_apply(_p(src), pitch, _p(z), m, self.c, _p(self.gamma), _p(self.mean), _p(self.invstd), _p(self.scale),
                                    _p(self.shift), _p(self.dgamma), _p(self.dbeta), mode, _p(dz), eng.dt, _st()), "mvf_bn_bwd_apply")
         return dz
@@ -131,7 +148,7 @@ class _TConv(object):
         if ho is None:
             ho, wo = self.out_hw(h, w)
         d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
-        z = torch.empty(n * ho * wo, self.cout, device=x.device, dtype=self.eng.tdtype)
+        z = self.eng.buf((id(self), "z"), (n * ho * wo, self.cout))
         ws = _conv_ws(x.device)
         if bn is None or not self.eng.fuse_stats:
             check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(x), _p(x2), _p(self.wp), None, None, _p(z), _p(ws), ws.numel(), _st()), "conv fwd")
@@ -139,7 +156,7 @@ class _TConv(object):
                 bn.stats(z, n * ho * wo, self.eng)
             return z, ho, wo
         rows = lib.mvf_conv2d_stats_rows(C.byref(d))
-        part = torch.empty(rows, self.cout, 2, device=x.device)
+        part = self.eng.buf((id(self), "part"), (rows, self.cout, 2), torch.float32)
         check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), _p(x), _p(x2), _p(self.wp), _p(z), _p(part), _p(bn.mod.running_mean), _p(ws), ws.numel(), _st()),
               "conv fwd+stats")
         bn.finalize(part, rows, n * ho * wo)
@@ -156,20 +173,17 @@ class _TConv(object):
             ws = eng.workspace(nbytes)
             check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
             return
-        cur = torch.cuda.current_stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            ws = eng.workspace(nbytes, side=True)
+        side.wait_stream(eng.main_stream())
+        ws = eng.workspace(nbytes, side=True)
+        with _on_stream(side):
             check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
-        for t in (dz, x, x2):
-            if t is not None:
-                t.record_stream(side)
+        # dz / x / x2 are persistent engine buffers (eng.buf) or tensors the caller keeps alive until join_side()
 
     def dgrad(self, dz, n, ho, wo, h, w, residual=None):
         """dx (n*h*w, cin) from dz (n*ho*wo, cout): a conv of dz with the flipped/transposed weights."""
         d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, self.eng.dt, 0, 0, 0,
                      self.stride if self.stride > 1 else 0)
-        dx = torch.empty(n * h * w, self.cin, device=dz.device, dtype=self.eng.tdtype)
+        dx = self.eng.buf((id(self), "dx"), (n * h * w, self.cin))
         ws = _conv_ws(dz.device)
         check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(dx), _p(ws), ws.numel(), _st()), "conv dgrad")
         return dx
@@ -199,7 +213,7 @@ class _TMvf(object):
     def forward(self, x, nt, h, w, c, eng):
         m = nt * h * w
         d = self.desc(nt, h, w, c)
-        y = torch.empty(m, self.cs, device=x.device, dtype=self.eng.tdtype)
+        y = self.eng.buf((id(self), "y"), (m, self.cs))
         check(lib.mvf_nhwc_stencil(C.byref(d), _p(x), c, _p(y), self.cs, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 0, _st()), "mvf stencil")
         if not self.use_hs:
             return y, y
@@ -277,7 +291,7 @@ class _TBlock(object):
         s = self.saved
         h, w, c, ho, wo = s["h"], s["w"], s["c"], s["ho"], s["wo"]
         m, m2 = nt * h * w, nt * ho * wo
-        gm = torch.empty_like(g)
+        gm = eng.buf((id(self), "gm"), g.shape, g.dtype)
         # Order matters for the two-stream overlap: each weight-gradient GEMM is queued on the side stream AFTER the
         # data-gradient GEMM that shares its dz has been queued on the main stream, so it starts when the main stream
         # moves on to the (HBM-bound) BatchNorm-backward kernels of the next layer -- MFMA work under memory work --
@@ -309,7 +323,7 @@ class _TBlock(object):
             else:
                 self.c1.wgrad(dz1, s["xin"], nt, h, w, h, w, eng, x_pitch=c)
             self.mvf.backward(dxp, s["x"], s["y"], nt, h, w, c, eng)
-            dx = eng.add(dxp, resid)
+            dx = eng.add(dxp, resid, key=id(self))
         self.saved = None
         return dx
 
@@ -349,9 +363,22 @@ class _ParamStore(object):
         self.norm_out = torch.zeros(2, device=dev)
         self.steps = 0
         self._ones = {}
+        self._bufs = {}
 
     def grad_of(self, p):
         return self._grad_view[id(p)]
+
+    def buf(self, key, shape, dtype=None):
+        """Persistent per-call-site device buffer (activations, gradients, scratch): shapes are static from step to step, so
+        nothing goes through the caching allocator inside a step (torch.empty + record_stream bookkeeping cost ~60 us per
+        call here and made the host the bottleneck at 36 ms/step)."""
+        dt = dtype or self.tdtype
+        k = (key, tuple(shape), dt)
+        t = self._bufs.get(k)
+        if t is None:
+            t = torch.empty(tuple(shape), device=self.device, dtype=dt)
+            self._bufs[k] = t
+        return t
 
     def workspace(self, nbytes, side=False):
         key = "_ws_side" if side else "_ws"
@@ -371,17 +398,21 @@ class _ParamStore(object):
             self._side = torch.cuda.Stream()
         return self._side
 
+    def main_stream(self):
+        ms = getattr(self, "_main", None)
+        return ms if ms is not None else torch.cuda.current_stream()
+
     def join_side(self):
         if getattr(self, "_side", None) is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            self.main_stream().wait_stream(self._side)
 
-    def add(self, a, b):
+    def add(self, a, b, key=None):
         """a + b (elementwise) through mvf_bn_apply with unit scale / zero shift."""
         m, c = a.shape
         if c not in self._ones:
             self._ones[c] = (torch.ones(c, device=a.device), torch.zeros(c, device=a.device))
         one, zero = self._ones[c]
-        out = torch.empty_like(a)
+        out = self.buf((key or id(a), "add"), a.shape, a.dtype) if key is not None else torch.empty_like(a)
         check(lib.mvf_bn_apply(_p(a), m, c, _p(one), _p(zero), _p(b), None, None, 0, _p(out), self.dt, _st()), "add")
         return out
 
@@ -401,6 +432,7 @@ class BlockTrainer(_ParamStore):
     def forward(self, x_nchw):
         nt, c, h, w = x_nchw.shape
         self.nt = nt
+        self._main = torch.cuda.current_stream()
         for cv in self.blk.convs():
             cv.pack()
         x = x_nchw.permute(0, 2, 3, 1).contiguous().view(nt * h * w, c).to(self.tdtype)
@@ -440,6 +472,11 @@ class TrainEngine(_ParamStore):
         """imgs [B, T, 3, H, W] fp32, labels [B, 1] / [B] int64 (GPU) -> loss tensor (1,), keeps activations."""
         if not imgs.is_cuda or imgs.dtype != torch.float32:
             raise RuntimeError("TrainEngine.forward: float32 GPU input required")
+        self._main = torch.cuda.current_stream()
+        with _on_stream(self._main):
+            return self._forward(imgs, labels, stages)
+
+    def _forward(self, imgs, labels, stages=None):
         b, t = imgs.shape[0], imgs.shape[1]
         x = imgs.reshape((-1, 3) + tuple(imgs.shape[3:])).contiguous()
         nt, _, h, w = x.shape
@@ -448,13 +485,13 @@ class TrainEngine(_ParamStore):
             for cv in blk.convs():
                 cv.pack()
         hp, wp = h + 6, (w + 6 + 2 + 1) // 2 * 2
-        xp = torch.empty(nt, hp, wp, 4, device=x.device, dtype=self.tdtype)
+        xp = self.buf("xp", (nt, hp, wp, 4))
         check(lib.mvf_stem_prep(_p(x), nt, 3, h, w, 3, wp, _p(xp), self.dt, _st()), "stem_prep")
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
         z0, _, _ = self.stem.forward(xp, nt, hp, wp, ho=ho, wo=wo, bn=self.stem_bn)
         h2, w2 = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
-        p0 = torch.empty(nt * h2 * w2, 64, device=x.device, dtype=self.tdtype)
-        amax = torch.empty(nt * h2 * w2, 64, device=x.device, dtype=torch.uint8)
+        p0 = self.buf("p0", (nt * h2 * w2, 64))
+        amax = self.buf("amax", (nt * h2 * w2, 64), torch.uint8)
         check(lib.mvf_maxpool_bn_relu_fwd(_p(z0), nt, ho, wo, 64, _p(self.stem_bn.scale), _p(self.stem_bn.shift), _p(p0), _p(amax), self.dt, _st()), "maxpool fwd")
         self.saved = dict(xp=xp, z0=z0, amax=amax, nt=nt, hp=hp, wp=wp, ho=ho, wo=wo, t=t, b=b)
         if stages is not None:
@@ -475,27 +512,33 @@ class TrainEngine(_ParamStore):
             keep = 1.0 - self.dropout
             mask = (torch.rand(nt, cc, device=x.device) < keep).float().div_(keep)
         dev = x.device
-        pooled = torch.empty(nt, cc, device=dev)
-        scores = torch.empty(b, self.num_classes, device=dev)
-        dscores = torch.empty(b, self.num_classes, device=dev)
-        loss_part = torch.empty(b, device=dev)
-        loss = torch.empty(1, device=dev)
+        f32 = torch.float32
+        pooled = self.buf("pooled", (nt, cc), f32)
+        scores = self.buf("scores", (b, self.num_classes), f32)
+        dscores = self.buf("dscores", (b, self.num_classes), f32)
+        loss_part = self.buf("loss_part", (b,), f32)
+        loss = self.buf("loss", (1,), f32)
         check(lib.mvf_head_train_fwd(_p(xcur), b, t, hc * wc, cc, _p(self.fc_w), _p(self.fc_b), self.num_classes, _p(lab), _p(mask), _p(pooled),
                                      _p(scores), _p(dscores), _p(loss_part), _p(loss), self.dt, _st()), "head fwd")
         self.saved.update(pooled=pooled, dscores=dscores, mask=mask, hw=hc * wc, c=cc, feat_shape=xcur.shape, scores=scores)
-        return loss
+        return loss.clone()                      # `loss` itself is a persistent buffer that the next step overwrites
 
     def backward(self):
+        self._main = torch.cuda.current_stream()
+        with _on_stream(self._main):
+            self._backward()
+
+    def _backward(self):
         s = self.saved
         nt, b, t = s["nt"], s["b"], s["t"]
-        dpool = torch.empty(b, s["c"], device=self.device)
-        g = torch.empty(s["feat_shape"], device=self.device, dtype=self.tdtype)
+        dpool = self.buf("dpool", (b, s["c"]), torch.float32)
+        g = self.buf("gfeat", tuple(s["feat_shape"]))
         check(lib.mvf_head_train_bwd(_p(s["dscores"]), _p(s["pooled"]), _p(self.fc_w), _p(s["mask"]), b, t, s["hw"], s["c"], self.num_classes,
                                      _p(self.dfc_w), _p(self.dfc_b), _p(dpool), _p(g), self.dt, _st()), "head bwd")
         for blk in reversed(self.blocks):
             g = blk.backward(g, nt, self)
         ho, wo = s["ho"], s["wo"]
-        ga = torch.empty(nt * ho * wo, 64, device=self.device, dtype=self.tdtype)
+        ga = self.buf("ga0", (nt * ho * wo, 64))
         check(lib.mvf_maxpool_bn_relu_bwd(_p(s["amax"]), _p(g), nt, ho, wo, 64, _p(ga), self.dt, _st()), "maxpool bwd")
         dz0 = self.stem_bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2)
         self.stem.wgrad(dz0, s["xp"], nt, s["hp"], s["wp"], ho, wo, self)
@@ -514,6 +557,10 @@ class TrainEngine(_ParamStore):
     force_allreduce = False
 
     def step(self, lr=None):
+        with _on_stream(torch.cuda.current_stream()):
+            return self._step(lr)
+
+    def _step(self, lr=None):
         world = self.allreduce_grads()
         n = self.flat_params.numel()
         ws = self.workspace(lib.mvf_sgd_workspace_bytes(n))

@@ -1,0 +1,23 @@
+"""How long does the HOST need to enqueue one training step (no GPU sync inside)? If close to the GPU step time, the
+engine is launch-bound and needs a C++ plan / hipGraph."""
+import sys, time, torch
+sys.path.insert(0, '.')
+import bench
+bench.T_FRAMES = 8
+dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+m = bench.build_model(50, dtype, True)
+eng = m.train_engine(dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+imgs = torch.randn(32, 8, 3, 224, 224, device="cuda"); labels = torch.randint(0, 400, (32, 1), device="cuda")
+for _ in range(3): eng.train_step(imgs, labels)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5): eng.train_step(imgs, labels)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("dtype %s: host enqueue %.1f ms/step, total %.1f ms/step" % (dtype, (t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(3): eng.train_step(imgs, labels)
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
