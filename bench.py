@@ -190,12 +190,18 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
         eng.overlap_wgrad = overlap
     r = _roof(totc, reps, dtype)
     w = _roof(totw, reps, dtype)
-    r["wgrad"] = {k: w[k] for k in ("achieved", "frac", "launches_per_step", "avg_launch_us", "flop_per_launch", "ms_per_step")}
+    r["wgrad"] = {k: w[k] for k in ("bound", "achieved", "peak", "unit", "frac", "tflops", "mfma_frac", "launches_per_step", "avg_launch_us",
+                                    "flop_per_launch", "alg_bytes_per_launch", "ms_per_step")}
     r["wgrad"]["kernel"] = "wgrad_kernel"
     return r
 
 
+PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured ceiling)
+
+
 def _roof(tot, reps, dtype):
+    """fp32: the conv GEMMs are MFMA-bound (94 FLOP/B fused vs ~20 machine balance).  bf16: the same network is HBM-bound even
+    when perfectly fused (188 FLOP/B vs ~310), so the fraction is algorithmic bytes/s over the HBM peak."""
     ms, fl, by, n = tot
     achieved = fl / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
@@ -206,10 +212,15 @@ def _roof(tot, reps, dtype):
             traffic = json.load(open(pmc)).get(dtype)
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "alg_bytes_per_launch": round(by / n),
-            "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2), "flop_per_launch": round(fl / n),
-            "ms_per_step": round(ms / reps, 3)}
+    common = {"kernel": "conv_igemm_kernel", "traffic": traffic, "alg_bytes_per_launch": round(by / n),
+              "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2), "flop_per_launch": round(fl / n),
+              "ms_per_step": round(ms / reps, 3), "tflops": round(achieved, 2), "mfma_frac": round(achieved / peak, 4)}
+    if dtype == "bf16":
+        gbs = by / (ms * 1e-3) / 1e9
+        common.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
+    else:
+        common.update({"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4)})
+    return common
 
 
 def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=False):
