@@ -56,7 +56,6 @@ struct ConvArgs {
     const float* stats_shift;  // K per output channel (the BN's old running mean; any K is exact, a close one avoids cancellation)
     int M;
     int cpt;       // chunks per tap = ceil(Cin*esz / 128)
-    int ks_last;   // MFMA k-steps (of 4) that carry data in the LAST chunk of a tap (Cin not a multiple of the chunk)
     int nchunks;   // KH*KW*cpt
     long wK;       // packed weight row length in elements
     int tiles_m, tiles_n;
@@ -220,10 +219,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         if (more) load_chunk();
         const char* Ab = As + buf * BM * kPitch + (wm * TM * 32) * kPitch + frag_off;
         const char* Bb = Bs + buf * BN * kPitch + (wn * TN * 32) * kPitch + frag_off;
-        const int nks = ((c_begin + kc) % a.cpt == a.cpt - 1) ? a.ks_last : 4;     // skip all-zero k-steps of a ragged chunk
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks >= nks) break;
             uint4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(Ab + i * 32 * kPitch + ks * 32);
@@ -619,7 +616,6 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     a.split_c = d->split_c; a.x2ps = d->x2_pix_stride; a.relu = d->relu; a.dil = dil;
     a.M = d->n * d->ho * d->wo;
     a.cpt = (d->cin + ce - 1) / ce;
-    a.ks_last = ((d->cin - (a.cpt - 1) * ce) + ce / 4 - 1) / (ce / 4);
     a.nchunks = d->kh * d->kw * a.cpt;
     a.wK = (long)d->kh * d->kw * d->cin;
     (void)esz;
