@@ -62,7 +62,10 @@ class _MVFProper(torch.autograd.Function):
                 running_mean, running_var):
         _require_gpu(x, "MVF")
         layout = _layout_of(x)
-        if layout is None:
+        use_hs_ = gamma is not None
+        if layout is None or (layout == _lib.MVF_NHWC and ((use_hs_ and training) or any(ctx.needs_input_grad[:6]))):
+            # the public channels-last entry points cover inference; training / backward of a channels-last tensor goes
+            # through the NCHW kernels on a contiguous copy (the fused TrainEngine has its own NHWC training primitives)
             x = x.contiguous()
             layout = _lib.MVF_NCHW
         d = _desc(x, layout, n_segment, cs, mode_bits)

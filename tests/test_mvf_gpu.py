@@ -173,3 +173,16 @@ def test_mvf_abi_rejects_bad_arguments():
         m(torch.randn(10, 16, 4, 4, device="cuda"))
     with pytest.raises(RuntimeError):
         m.cpu()(torch.randn(8, 16, 4, 4))
+
+
+def test_mvf_channels_last_training_goes_through_nchw_kernels():
+    """A channels_last input in training mode (no public NHWC train entry yet) must still give reference numbers."""
+    case = MVF_CASES[0]
+    name, N, T, C, H, W, alpha, mode, share, use_hs, planes = case
+    g = golden("mvf_cases.npz")
+    m = _build(case, "id", True)
+    x = torch.from_numpy(synth.synth_tensor("mvf_x/" + name, (N * T, C, H, W))).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = m(x)
+    assert rel_err(y.detach().cpu().numpy(), g["%s/id/train/y" % name]) < TOL_F32
+    y.backward(torch.from_numpy(synth.synth_tensor("mvf_dy/%s/id" % name, tuple(y.shape))).cuda())
+    assert rel_err(x.grad.cpu().numpy(), g["%s/id/train/dx" % name]) < TOL_GRAD
