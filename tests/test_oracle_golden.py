@@ -231,3 +231,35 @@ def test_net_oracle_fcn_testing():
     assert rel_err(prob.numpy(), g["fcn/prob"]) < TOL
     assert rel_err(scores.numpy(), g["fcn/scores"]) < TOL
     assert prob.numpy().argmax() == g["fcn/prob"].argmax()
+
+
+@pytest.mark.parametrize("case", [c for c in MVF_CASES if int(c[3] * c[6]) and not c[8]], ids=lambda c: c[0])
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+def test_mvf_plain_c_oracle_matches_reference(case, train):
+    """oracle/mvf_ref.c (scalar C, double accumulation) against the reference's golden outputs and gradients."""
+    from oracle import mvf_c
+    name, N, T, C, H, W, alpha, mode, share, use_hs, planes = case
+    g = golden("mvf_cases.npz")
+    p = mvf_case_params(name, C, alpha, mode, share, use_hs, planes, "id")
+    cs = int(C * alpha)
+    x = synth.synth_tensor("mvf_x/" + name, (N * T, C, H, W))
+    tag = "%s/id/%s" % (name, "train" if train else "eval")
+    dy = synth.synth_tensor("mvf_dy/%s/id" % name, x.shape)
+    r = mvf_c.forward_backward(x, T, cs, {"T": 1, "TH": 3, "THW": 7}[mode], p["shift_conv.weight"].reshape(cs, 3),
+                               p["h_conv.weight"].reshape(cs, 3) if "h_conv.weight" in p else None,
+                               p["w_conv.weight"].reshape(cs, 3) if "w_conv.weight" in p else None, use_hs, train,
+                               p["bn.weight"], p["bn.bias"], p["bn.running_mean"], p["bn.running_var"], g=dy)
+    assert rel_err(r["out"], g[tag + "/y"]) < TOL
+    if name in DEGENERATE_BWD:
+        return
+    assert rel_err(r["dx"], g[tag + "/dx"]) < TOL
+    assert rel_err(r["dwt"].reshape(-1), g[tag + "/grad/shift_conv.weight"].reshape(-1)) < TOL
+    if mode in ("TH", "THW"):
+        assert rel_err(r["dwh"].reshape(-1), g[tag + "/grad/h_conv.weight"].reshape(-1)) < TOL
+    if mode == "THW":
+        assert rel_err(r["dww"].reshape(-1), g[tag + "/grad/w_conv.weight"].reshape(-1)) < TOL
+    if use_hs:
+        assert rel_err(r["dgamma"], g[tag + "/grad/bn.weight"]) < TOL and rel_err(r["dbeta"], g[tag + "/grad/bn.bias"]) < TOL
+        if train:
+            assert rel_err(r["running_mean"], g[tag + "/buf/bn.running_mean"]) < TOL
+            assert rel_err(r["running_var"], g[tag + "/buf/bn.running_var"]) < TOL
