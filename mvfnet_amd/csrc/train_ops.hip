@@ -10,6 +10,7 @@
 // finalize kernel that sums them in fp64 in block order -> deterministic run to run.
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -18,22 +19,23 @@ namespace {
 constexpr int kThreads = 256;
 
 struct ColPlan {
-    int cqb;     // channel quads handled by one block (threads along channels)
+    int cqb;     // channel groups (VN elements each) handled by one block (threads along channels)
     int rl;      // row lanes = 256 / cqb
     int gx;      // blocks along channels
     int gy;      // blocks along rows
     int rows;    // rows per block
 };
 
-ColPlan col_plan(long M, int C) {
+// vn = elements per lane vector (16 B: 4 fp32 or 8 bf16; 8 B: 4 bf16); blocks = total workgroups aimed at
+ColPlan col_plan(long M, int C, int vn = 4, int blocks = 2048) {
     ColPlan p;
-    const int cq = C / 4;
+    const int cq = C / vn;
     int cqb = 1;
     while (cqb < cq && cqb < 64) cqb <<= 1;
     p.cqb = cqb;
     p.rl = kThreads / cqb;
     p.gx = (cq + cqb - 1) / cqb;
-    long want = std::max<long>(1, 2048 / p.gx);                  // ~2048 blocks in total (8 per CU: these loops are latency-bound)
+    long want = std::max<long>(1, blocks / p.gx);                // ~8 blocks per CU: these loops are latency-bound
     long rows = std::max<long>((M + want - 1) / want, (long)p.rl * 8);
     rows = (rows + p.rl - 1) / p.rl * p.rl;
     p.rows = (int)rows;
@@ -41,84 +43,163 @@ ColPlan col_plan(long M, int C) {
     return p;
 }
 
-// reduce NV float4 accumulators over the row lanes of a block; result valid in row lane 0
-template <int NV>
-__device__ __forceinline__ void rowlane_reduce(float4 (&v)[NV], int cqb, int rl, float4* red) {
-    const int cq = threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
+// lane vectors: VN elements of ET <-> VN floats.  (float,4) and (bf16,8) are 16-byte accesses, (bf16,4) is 8 bytes.
+template <typename ET, int VN>
+__device__ __forceinline__ void ldv(const ET* p, float (&f)[VN]) {
+    if constexpr (sizeof(ET) == 4) {
+        static_assert(VN == 4, "fp32 lane vector is 4 wide");
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else if constexpr (VN == 4) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p);
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    } else {
+        static_assert(VN == 8, "bf16 lane vector is 4 or 8 wide");
+        const uint4 r = *reinterpret_cast<const uint4*>(p);
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+}
+template <typename ET, int VN>
+__device__ __forceinline__ void stv(ET* p, const float (&f)[VN]) {
+    if constexpr (sizeof(ET) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    } else if constexpr (VN == 4) {
+        uint2 r;
+        r.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+        r.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = r;
+    } else {
+        uint4 r;
+        r.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+        r.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+        r.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
+        r.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+        *reinterpret_cast<uint4*>(p) = r;
+    }
+}
+// per-channel fp32 parameters of the lane's VN channels (null -> fill)
+template <int VN>
+__device__ __forceinline__ void ldp(const float* p, int c, float (&f)[VN], float fill = 0.f) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) red[(i * rl + lane_r) * cqb + cq] = v[i];
+    for (int j = 0; j < VN; j += 4) {
+        const float4 v = p ? *reinterpret_cast<const float4*>(p + c + j) : make_float4(fill, fill, fill, fill);
+        f[j] = v.x; f[j + 1] = v.y; f[j + 2] = v.z; f[j + 3] = v.w;
+    }
+}
+
+// reduce 2*VN float accumulators over the row lanes of a block (fixed order); result valid in row lane 0 (threads < cqb).
+// In-wave butterfly over the lanes that share a channel group (lane stride cqb), then the 4 waves through LDS.
+// red: 2*VN*kThreads/64*64 floats are enough (4 waves x cqb<=64 lanes x 2*VN)
+template <int VN>
+__device__ __forceinline__ void rowlane_reduce(float (&a)[VN], float (&b)[VN], int cqb, int rl, float* red) {
+    (void)rl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cq = lane % cqb;
+    for (int off = cqb; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            a[j] += __shfl_xor(a[j], off, 64);
+            b[j] += __shfl_xor(b[j], off, 64);
+        }
+    }
+    if (lane < cqb) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            red[((wave * 2 * VN) + 2 * j) * cqb + cq] = a[j];
+            red[((wave * 2 * VN) + 2 * j + 1) * cqb + cq] = b[j];
+        }
+    }
     __syncthreads();
-    if (lane_r == 0) {
+    if (threadIdx.x < cqb) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r = 0; r < rl; ++r) {
-                const float4 t = red[(i * rl + r) * cqb + cq];
-                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        for (int j = 0; j < VN; ++j) {
+            float s = 0.f, t = 0.f;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) {
+                s += red[((w * 2 * VN) + 2 * j) * cqb + cq];
+                t += red[((w * 2 * VN) + 2 * j + 1) * cqb + cq];
             }
-            v[i] = s;
+            a[j] = s;
+            b[j] = t;
         }
     }
 }
 
 // ---- BN forward statistics: shifted sums  S1 = sum(z-K), S2 = sum((z-K)^2), K = running_mean (any K is exact) ----
-template <typename ET>
+template <typename ET, int VN>
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const ET* z, long M, int C, const float* kshift, int cqb, int rows,
                                                             float* part) {
-    __shared__ float4 red[2 * kThreads];
+    __shared__ float red[2 * VN * kThreads];
     const int rl = kThreads / cqb;
     const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
-    const bool ok = cq * 4 < C;
-    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok && kshift) k4 = *reinterpret_cast<const float4*>(kshift + cq * 4);
-    float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    const bool ok = cq * VN < C;
+    const int c = cq * VN;
+    float k[VN], s1[VN], s2[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) k[j] = s1[j] = s2[j] = 0.f;
+    if (ok && kshift) ldp<VN>(kshift, c, k);
     const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
     if (ok) {
-        auto accum = [&](float4 a) {
-            a.x -= k4.x; a.y -= k4.y; a.z -= k4.z; a.w -= k4.w;
-            v[0].x += a.x; v[0].y += a.y; v[0].z += a.z; v[0].w += a.w;
-            v[1].x += a.x * a.x; v[1].y += a.y * a.y; v[1].z += a.z * a.z; v[1].w += a.w * a.w;
+        auto accum = [&](const float (&a)[VN]) {
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                const float d = a[j] - k[j];
+                s1[j] += d;
+                s2[j] += d * d;
+            }
         };
         long r = r0 + lane_r;
-        for (; r + 3 * rl < r1; r += 4 * rl) {      // 4 independent 16-B loads in flight per lane
-            const float4 a0 = ld4(z + r * C + cq * 4), a1 = ld4(z + (r + rl) * C + cq * 4);
-            const float4 a2 = ld4(z + (r + 2 * rl) * C + cq * 4), a3 = ld4(z + (r + 3 * rl) * C + cq * 4);
+        for (; r + 3 * rl < r1; r += 4 * rl) {      // 4 independent loads in flight per lane
+            float a0[VN], a1[VN], a2[VN], a3[VN];
+            ldv<ET, VN>(z + r * C + c, a0); ldv<ET, VN>(z + (r + rl) * C + c, a1);
+            ldv<ET, VN>(z + (r + 2 * rl) * C + c, a2); ldv<ET, VN>(z + (r + 3 * rl) * C + c, a3);
             accum(a0); accum(a1); accum(a2); accum(a3);
         }
-        for (; r < r1; r += rl) accum(ld4(z + r * C + cq * 4));
+        for (; r < r1; r += rl) {
+            float a0[VN];
+            ldv<ET, VN>(z + r * C + c, a0);
+            accum(a0);
+        }
     }
-    rowlane_reduce<2>(v, cqb, rl, red);
+    rowlane_reduce<VN>(s1, s2, cqb, rl, red);
     if (ok && lane_r == 0) {
-        float* p = part + ((long)blockIdx.y * C + cq * 4) * 2;
-        p[0] = v[0].x; p[1] = v[1].x; p[2] = v[0].y; p[3] = v[1].y; p[4] = v[0].z; p[5] = v[1].z; p[6] = v[0].w; p[7] = v[1].w;
+        float* p = part + ((long)blockIdx.y * C + c) * 2;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { p[2 * j] = s1[j]; p[2 * j + 1] = s2[j]; }
     }
 }
 
-// partial sums [nblk][C][2] -> per-channel (s1, s2) in fp64; 32 channels x 8 block-lanes per workgroup, fixed order
+// partial sums [nblk][C][2] -> per-channel (s1, s2) in fp64; kFinCh channels x 64 block-lanes per workgroup, fixed order
+constexpr int kFinCh = 4;
 __device__ __forceinline__ bool reduce_partials(const float* part, int C, int nblk, int& c, double& s1, double& s2) {
-    constexpr int CH = 8, LN = 32;                       // channels per workgroup x block-lanes (256 threads)
+    constexpr int CH = kFinCh, LN = 256 / kFinCh;        // channels per workgroup x block-lanes (256 threads)
+    constexpr int U = 8;                                 // loads in flight per lane: the loop is pure L2 latency
     __shared__ double sh[2][LN][CH];
     const int cl = threadIdx.x % CH, bl = threadIdx.x / CH;
     c = blockIdx.x * CH + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        // 4 loads in flight per lane (the loop is latency-bound: nblk/8 dependent round trips otherwise); fixed order
-        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+        double aa[U], bb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) aa[u] = bb[u] = 0.0;
         int k = bl;
-        for (; k + 3 * LN < nblk; k += 4 * LN) {
-            const float2 v0 = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
-            const float2 v1 = *reinterpret_cast<const float2*>(part + ((long)(k + LN) * C + c) * 2);
-            const float2 v2 = *reinterpret_cast<const float2*>(part + ((long)(k + 2 * LN) * C + c) * 2);
-            const float2 v3 = *reinterpret_cast<const float2*>(part + ((long)(k + 3 * LN) * C + c) * 2);
-            a += v0.x; b += v0.y; a1 += v1.x; b1 += v1.y; a2 += v2.x; b2 += v2.y; a3 += v3.x; b3 += v3.y;
+        for (; k + (U - 1) * LN < nblk; k += U * LN) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float2*>(part + ((long)(k + u * LN) * C + c) * 2);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { aa[u] += v[u].x; bb[u] += v[u].y; }
         }
         for (; k < nblk; k += LN) {
             const float2 v = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
-            a += v.x;
-            b += v.y;
+            aa[0] += v.x;
+            bb[0] += v.y;
         }
-        a = (a + a1) + (a2 + a3);
-        b = (b + b1) + (b2 + b3);
+        a = ((aa[0] + aa[1]) + (aa[2] + aa[3])) + ((aa[4] + aa[5]) + (aa[6] + aa[7]));
+        b = ((bb[0] + bb[1]) + (bb[2] + bb[3])) + ((bb[4] + bb[5]) + (bb[6] + bb[7]));
     }
     sh[0][bl][cl] = a;
     sh[1][bl][cl] = b;
@@ -154,91 +235,118 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(int C, int nblk,
 }
 
 // ---- BN apply (+ residual) (+ ReLU):  out = act(z*scale + shift [+ r] [+ r*rscale + rshift]) ----
-template <typename ET>
-__global__ void bn_apply_kernel(const ET* z, long M, int C, const float* scale, const float* shift, const ET* r,
-                                const float* rscale, const float* rshift, int relu, ET* out) {
-    const int cq4 = C / 4;
-    const long total = M * cq4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cq = (int)(i % cq4);
-        const float4 s = *reinterpret_cast<const float4*>(scale + cq * 4), b = *reinterpret_cast<const float4*>(shift + cq * 4);
-        float4 v = ld4(z + i * 4);
-        v.x = v.x * s.x + b.x; v.y = v.y * s.y + b.y; v.z = v.z * s.z + b.z; v.w = v.w * s.w + b.w;
+// Column-tiled: a lane owns VN channels (its scale/shift live in registers) and walks rows; no per-element index math.
+template <typename ET, int VN>
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const ET* z, long M, int C, const float* scale, const float* shift, const ET* r,
+                                                            const float* rscale, const float* rshift, int act, ET* out, int cqb, int rows) {
+    const int rl = kThreads / cqb;
+    const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
+    if (cq * VN >= C) return;
+    const int c = cq * VN;
+    float s[VN], b[VN], rs[VN], rb[VN];
+    ldp<VN>(scale, c, s);
+    ldp<VN>(shift, c, b);
+    ldp<VN>(rscale, c, rs, 1.f);
+    ldp<VN>(rshift, c, rb, 0.f);
+    const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
+    auto one = [&](long row, float (&v)[VN], const float (&q)[VN]) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            float t = v[j] * s[j] + b[j];
+            if (r) t += q[j] * rs[j] + rb[j];
+            if (act == 1) t = fmaxf(t, 0.f);
+            else if (act == 2) t = hswish_f(t);             // MVF activation (se_module.py:5-24)
+            v[j] = t;
+        }
+        stv<ET, VN>(out + row * C + c, v);
+    };
+    long row = r0 + lane_r;
+    for (; row + rl < r1; row += 2 * rl) {                  // two rows per trip: 2-4 independent loads in flight per lane
+        float z0[VN], z1[VN], q0[VN], q1[VN];
+        ldv<ET, VN>(z + row * C + c, z0);
+        ldv<ET, VN>(z + (row + rl) * C + c, z1);
         if (r) {
-            float4 q = ld4(r + i * 4);
-            if (rscale) {
-                const float4 rs = *reinterpret_cast<const float4*>(rscale + cq * 4), rb = *reinterpret_cast<const float4*>(rshift + cq * 4);
-                q.x = q.x * rs.x + rb.x; q.y = q.y * rs.y + rb.y; q.z = q.z * rs.z + rb.z; q.w = q.w * rs.w + rb.w;
-            }
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            ldv<ET, VN>(r + row * C + c, q0);
+            ldv<ET, VN>(r + (row + rl) * C + c, q1);
         }
-        if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        else if (relu == 2) {   // hard-swish (MVF activation, se_module.py:5-24)
-            v.x = v.x * (fminf(fmaxf(v.x + 3.f, 0.f), 6.f) / 6.f); v.y = v.y * (fminf(fmaxf(v.y + 3.f, 0.f), 6.f) / 6.f);
-            v.z = v.z * (fminf(fmaxf(v.z + 3.f, 0.f), 6.f) / 6.f); v.w = v.w * (fminf(fmaxf(v.w + 3.f, 0.f), 6.f) / 6.f);
-        }
-        st4(out + i * 4, v);
+        one(row, z0, q0);
+        one(row + rl, z1, q1);
+    }
+    for (; row < r1; row += rl) {
+        float z0[VN], q0[VN];
+        ldv<ET, VN>(z + row * C + c, z0);
+        if (r) ldv<ET, VN>(r + row * C + c, q0);
+        one(row, z0, q0);
     }
 }
 
 // ---- BN backward reductions: gm = g * mask ; sums of gm and gm*xhat.  mask from y>0 (block output) or from
 // ---- scale*z+shift > 0 (recomputed ReLU of this BN's own output) or none.  Optionally writes gm. ----
-template <typename ET>
+template <typename ET, int VN>
+__device__ __forceinline__ void bn_mask(float (&gv)[VN], const float (&zv)[VN], const float (&yv)[VN], const float (&sc)[VN],
+                                        const float (&sh)[VN], int mask_mode) {
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+        if (mask_mode == 1) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+        else if (mask_mode == 2) gv[j] = (zv[j] * sc[j] + sh[j]) > 0.f ? gv[j] : 0.f;
+        else if (mask_mode == 3) gv[j] *= hswish_grad_f(zv[j] * sc[j] + sh[j]);   // MVF: o = hswish(bn(y))
+    }
+}
+
+template <typename ET, int VN>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const ET* g, int g_pitch, const ET* z, const ET* ymask, long M, int C,
                                                                  const float* mean, const float* invstd, const float* scale,
                                                                  const float* shift, int mask_mode, ET* gm_out, int cqb, int rows,
                                                                  float* part) {
-    __shared__ float4 red[2 * kThreads];
+    __shared__ float red[2 * VN * kThreads];
     const int rl = kThreads / cqb;
     const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
-    const bool ok = cq * 4 < C;
-    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, sc = mu, sh = mu;
+    const bool ok = cq * VN < C;
+    const int c = cq * VN;
+    float mu[VN], rs[VN], sc[VN], sh[VN], s1[VN], s2[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) mu[j] = rs[j] = sc[j] = sh[j] = s1[j] = s2[j] = 0.f;
     if (ok) {
-        mu = *reinterpret_cast<const float4*>(mean + cq * 4);
-        rs = *reinterpret_cast<const float4*>(invstd + cq * 4);
+        ldp<VN>(mean, c, mu);
+        ldp<VN>(invstd, c, rs);
         if (mask_mode >= 2) {
-            sc = *reinterpret_cast<const float4*>(scale + cq * 4);
-            sh = *reinterpret_cast<const float4*>(shift + cq * 4);
+            ldp<VN>(scale, c, sc);
+            ldp<VN>(shift, c, sh);
         }
     }
-    float4 v[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
     if (ok) {
-        auto body = [&](long r, float4 gv, const float4 zv, const float4 yv) {
-            const long o = r * C + cq * 4;
-            if (mask_mode == 1) {
-                gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f; gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
-            } else if (mask_mode == 2) {
-                gv.x = (zv.x * sc.x + sh.x) > 0.f ? gv.x : 0.f; gv.y = (zv.y * sc.y + sh.y) > 0.f ? gv.y : 0.f;
-                gv.z = (zv.z * sc.z + sh.z) > 0.f ? gv.z : 0.f; gv.w = (zv.w * sc.w + sh.w) > 0.f ? gv.w : 0.f;
-            } else if (mask_mode == 3) {   // hard-swish derivative (MVF: o = hswish(bn(y)))
-                gv.x *= hswish_grad_f(zv.x * sc.x + sh.x); gv.y *= hswish_grad_f(zv.y * sc.y + sh.y);
-                gv.z *= hswish_grad_f(zv.z * sc.z + sh.z); gv.w *= hswish_grad_f(zv.w * sc.w + sh.w);
+        auto body = [&](long r, float (&gv)[VN], const float (&zv)[VN], const float (&yv)[VN]) {
+            bn_mask<ET, VN>(gv, zv, yv, sc, sh, mask_mode);
+            if (gm_out) stv<ET, VN>(gm_out + r * C + c, gv);
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                s1[j] += gv[j];
+                s2[j] += gv[j] * ((zv[j] - mu[j]) * rs[j]);
             }
-            if (gm_out) st4(gm_out + o, gv);
-            v[0].x += gv.x; v[0].y += gv.y; v[0].z += gv.z; v[0].w += gv.w;
-            v[1].x += gv.x * ((zv.x - mu.x) * rs.x); v[1].y += gv.y * ((zv.y - mu.y) * rs.y);
-            v[1].z += gv.z * ((zv.z - mu.z) * rs.z); v[1].w += gv.w * ((zv.w - mu.w) * rs.w);
         };
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         long r = r0 + lane_r;
-        for (; r + rl < r1; r += 2 * rl) {          // two rows per trip: 4-6 independent 16-B loads in flight per lane
-            const long o0 = r * C + cq * 4, o1 = (r + rl) * C + cq * 4;
-            const float4 g0 = ld4(g + r * g_pitch + cq * 4), g1 = ld4(g + (r + rl) * g_pitch + cq * 4);
-            const float4 z0 = ld4(z + o0), z1 = ld4(z + o1);
-            const float4 y0 = mask_mode == 1 ? ld4(ymask + o0) : zero4, y1 = mask_mode == 1 ? ld4(ymask + o1) : zero4;
+        for (; r + rl < r1; r += 2 * rl) {          // two rows per trip: 4-6 independent loads in flight per lane
+            float g0[VN], g1[VN], z0[VN], z1[VN], y0[VN], y1[VN];
+            ldv<ET, VN>(g + r * g_pitch + c, g0); ldv<ET, VN>(g + (r + rl) * g_pitch + c, g1);
+            ldv<ET, VN>(z + r * C + c, z0); ldv<ET, VN>(z + (r + rl) * C + c, z1);
+            if (mask_mode == 1) { ldv<ET, VN>(ymask + r * C + c, y0); ldv<ET, VN>(ymask + (r + rl) * C + c, y1); }
             body(r, g0, z0, y0);
             body(r + rl, g1, z1, y1);
         }
         for (; r < r1; r += rl) {
-            const long o = r * C + cq * 4;
-            body(r, ld4(g + r * g_pitch + cq * 4), ld4(z + o), mask_mode == 1 ? ld4(ymask + o) : zero4);
+            float g0[VN], z0[VN], y0[VN];
+            ldv<ET, VN>(g + r * g_pitch + c, g0);
+            ldv<ET, VN>(z + r * C + c, z0);
+            if (mask_mode == 1) ldv<ET, VN>(ymask + r * C + c, y0);
+            body(r, g0, z0, y0);
         }
     }
-    rowlane_reduce<2>(v, cqb, rl, red);
+    rowlane_reduce<VN>(s1, s2, cqb, rl, red);
     if (ok && lane_r == 0) {
-        float* p = part + ((long)blockIdx.y * C + cq * 4) * 2;
-        p[0] = v[0].x; p[1] = v[1].x; p[2] = v[0].y; p[3] = v[1].y; p[4] = v[0].z; p[5] = v[1].z; p[6] = v[0].w; p[7] = v[1].w;
+        float* p = part + ((long)blockIdx.y * C + c) * 2;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { p[2 * j] = s1[j]; p[2 * j + 1] = s2[j]; }
     }
 }
 
@@ -251,36 +359,53 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nblk, c
 }
 
 // dz = gamma*invstd * (gm - dbeta/M - xhat*dgamma/M); gm = g*mask recomputed as above (mask_mode 0: g is already masked)
-template <typename ET>
-__global__ void bn_bwd_apply_kernel(const ET* g, int g_pitch, const ET* z, long M, int C, const float* gamma, const float* mean,
-                                    const float* invstd, const float* scale, const float* shift, const float* dgamma,
-                                    const float* dbeta, int mask_mode, ET* dz) {
-    const int cq4 = C / 4;
-    const long total = M * cq4;
+// Column-tiled like bn_apply_kernel: the six per-channel coefficients are folded once per lane into registers.
+template <typename ET, int VN>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const ET* g, int g_pitch, const ET* z, long M, int C, const float* gamma,
+                                                                const float* mean, const float* invstd, const float* scale,
+                                                                const float* shift, const float* dgamma, const float* dbeta,
+                                                                int mask_mode, ET* dz, int cqb, int rows) {
+    const int rl = kThreads / cqb;
+    const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
+    if (cq * VN >= C) return;
+    const int c = cq * VN;
     const float inv_m = 1.0f / (float)M;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cq4) * 4;
-        const float4 ga = *reinterpret_cast<const float4*>(gamma + c), mu = *reinterpret_cast<const float4*>(mean + c);
-        const float4 rs = *reinterpret_cast<const float4*>(invstd + c);
-        const float4 dg = *reinterpret_cast<const float4*>(dgamma + c), db = *reinterpret_cast<const float4*>(dbeta + c);
-        float4 gv = ld4(g + (i / cq4) * g_pitch + c);
-        const float4 zv = ld4(z + i * 4);
-        if (mask_mode >= 2) {
-            const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
-            if (mask_mode == 2) {
-                gv.x = (zv.x * sc.x + sh.x) > 0.f ? gv.x : 0.f; gv.y = (zv.y * sc.y + sh.y) > 0.f ? gv.y : 0.f;
-                gv.z = (zv.z * sc.z + sh.z) > 0.f ? gv.z : 0.f; gv.w = (zv.w * sc.w + sh.w) > 0.f ? gv.w : 0.f;
-            } else {
-                gv.x *= hswish_grad_f(zv.x * sc.x + sh.x); gv.y *= hswish_grad_f(zv.y * sc.y + sh.y);
-                gv.z *= hswish_grad_f(zv.z * sc.z + sh.z); gv.w *= hswish_grad_f(zv.w * sc.w + sh.w);
-            }
+    float a[VN], d0[VN], kx[VN], mu[VN], sc[VN], sh[VN];
+    {
+        float ga[VN], rs[VN], dg[VN], db[VN];
+        ldp<VN>(gamma, c, ga); ldp<VN>(invstd, c, rs); ldp<VN>(dgamma, c, dg); ldp<VN>(dbeta, c, db);
+        ldp<VN>(mean, c, mu);
+        ldp<VN>(mask_mode >= 2 ? scale : nullptr, c, sc);
+        ldp<VN>(mask_mode >= 2 ? shift : nullptr, c, sh);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            a[j] = ga[j] * rs[j];
+            d0[j] = db[j] * inv_m;
+            kx[j] = rs[j] * dg[j] * inv_m;
         }
-        float4 o;
-        o.x = ga.x * rs.x * (gv.x - db.x * inv_m - ((zv.x - mu.x) * rs.x) * dg.x * inv_m);
-        o.y = ga.y * rs.y * (gv.y - db.y * inv_m - ((zv.y - mu.y) * rs.y) * dg.y * inv_m);
-        o.z = ga.z * rs.z * (gv.z - db.z * inv_m - ((zv.z - mu.z) * rs.z) * dg.z * inv_m);
-        o.w = ga.w * rs.w * (gv.w - db.w * inv_m - ((zv.w - mu.w) * rs.w) * dg.w * inv_m);
-        st4(dz + i * 4, o);
+    }
+    const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
+    auto one = [&](long row, float (&gv)[VN], const float (&zv)[VN]) {
+        bn_mask<ET, VN>(gv, zv, zv, sc, sh, mask_mode == 1 ? 0 : mask_mode);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) gv[j] = a[j] * (gv[j] - d0[j] - (zv[j] - mu[j]) * kx[j]);
+        stv<ET, VN>(dz + row * C + c, gv);
+    };
+    long row = r0 + lane_r;
+    for (; row + rl < r1; row += 2 * rl) {
+        float g0[VN], g1[VN], z0[VN], z1[VN];
+        ldv<ET, VN>(g + row * g_pitch + c, g0);
+        ldv<ET, VN>(g + (row + rl) * g_pitch + c, g1);
+        ldv<ET, VN>(z + row * C + c, z0);
+        ldv<ET, VN>(z + (row + rl) * C + c, z1);
+        one(row, g0, z0);
+        one(row + rl, g1, z1);
+    }
+    for (; row < r1; row += rl) {
+        float g0[VN], z0[VN];
+        ldv<ET, VN>(g + row * g_pitch + c, g0);
+        ldv<ET, VN>(z + row * C + c, z0);
+        one(row, g0, z0);
     }
 }
 
@@ -480,24 +605,44 @@ extern "C" {
 
 size_t mvf_bn_workspace_bytes(long m, int c) {
     if (m <= 0 || c <= 0 || c % 4) return 0;
-    ColPlan p = col_plan(m, c);
-    return align_up((size_t)p.gy * c * 2 * sizeof(float), 256);
+    int gy = col_plan(m, c, 4).gy;
+    if (c % 8 == 0) gy = std::max(gy, col_plan(m, c, 8).gy);       // bf16 runs 8-wide lanes when it can
+    return align_up((size_t)gy * c * 2 * sizeof(float), 256);
 }
+
+// DISPATCH(kernel, plan-blocks, args...): picks <float,4>, <bf16_t,8> (16-byte lanes: c, pitches % 8 == 0 and 16-B aligned
+// pointers) or <bf16_t,4>, builds the column plan `p` for that width and launches on `st`.
+#define MVF_BN_DISPATCH(KERNEL, WIDE_OK, BLOCKS, ...)                                                                        \
+    do {                                                                                                                     \
+        if (dtype == MVF_F32) {                                                                                              \
+            using ET = float;                                                                                                \
+            const ColPlan p = col_plan(m, c, 4, BLOCKS);                                                                     \
+            hipLaunchKernelGGL((KERNEL<float, 4>), dim3(p.gx, p.gy), dim3(kThreads), 0, st, __VA_ARGS__);                    \
+        } else if (WIDE_OK) {                                                                                                \
+            using ET = bf16_t;                                                                                               \
+            const ColPlan p = col_plan(m, c, 8, BLOCKS);                                                                     \
+            hipLaunchKernelGGL((KERNEL<bf16_t, 8>), dim3(p.gx, p.gy), dim3(kThreads), 0, st, __VA_ARGS__);                   \
+        } else {                                                                                                             \
+            using ET = bf16_t;                                                                                               \
+            const ColPlan p = col_plan(m, c, 4, BLOCKS);                                                                     \
+            hipLaunchKernelGGL((KERNEL<bf16_t, 4>), dim3(p.gx, p.gy), dim3(kThreads), 0, st, __VA_ARGS__);                   \
+        }                                                                                                                    \
+    } while (0)
+
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
                        float* shift, void* ws, size_t ws_bytes, int dtype, void* stream) {
     MVF_REQUIRE(z && gamma && beta && save_mean && save_invstd && scale && shift && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_train_stats: bad argument (c %% 4?)");
     MVF_REQUIRE(ws && ws_bytes >= mvf_bn_workspace_bytes(m, c), MVF_EWS, "bn_train_stats: workspace too small");
-    ColPlan p = col_plan(m, c);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)ws;
-    if (dtype == MVF_F32)
-        hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const float*)z, m, c, running_mean, p.cqb, p.rows, part);
-    else
-        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const bf16_t*)z, m, c, running_mean, p.cqb, p.rows, part);
+    const bool wide = c % 8 == 0 && al16(z);
+    const int gy = col_plan(m, c, (dtype != MVF_F32 && wide) ? 8 : 4).gy;
+    MVF_BN_DISPATCH(bn_stats_kernel, wide, 2048, (const ET*)z, m, c, running_mean, p.cqb, p.rows, part);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 7) / 8), dim3(256), 0, st, c, p.gy, m, part, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, st, c, gy, m, part, gamma, beta, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd, scale, shift);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
@@ -508,7 +653,7 @@ int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const floa
                           float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                           float* scale, float* shift, void* stream) {
     MVF_REQUIRE(part && gamma && beta && save_mean && save_invstd && scale && shift && nblk > 0 && m > 0 && c > 0, MVF_EINVAL, "bn_train_finalize: bad argument");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 7) / 8), dim3(256), 0, (hipStream_t)stream, c, nblk, m, part, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, (hipStream_t)stream, c, nblk, m, part, gamma, beta, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd, scale, shift);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
@@ -519,11 +664,8 @@ int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* 
     MVF_REQUIRE(z && scale && shift && out && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_apply: bad argument");
     MVF_REQUIRE((rscale == nullptr) == (rshift == nullptr), MVF_EINVAL, "bn_apply: rscale/rshift must come together");
     hipStream_t st = (hipStream_t)stream;
-    const long total = m * (c / 4);
-    if (dtype == MVF_F32)
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)z, m, c, scale, shift, (const float*)residual, rscale, rshift, relu, (float*)out);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)z, m, c, scale, shift, (const bf16_t*)residual, rscale, rshift, relu, (bf16_t*)out);
+    const bool wide = c % 8 == 0 && al16(z) && al16(out) && al16(residual);
+    MVF_BN_DISPATCH(bn_apply_kernel, wide, 4096, (const ET*)z, m, c, scale, shift, (const ET*)residual, rscale, rshift, relu, (ET*)out, p.cqb, p.rows);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -534,15 +676,13 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
     MVF_REQUIRE(g && z && mean && invstd && dgamma && dbeta && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_bwd_reduce: bad argument");
     MVF_REQUIRE(mask_mode >= 0 && mask_mode <= 3 && (mask_mode != 1 || ymask) && (mask_mode < 2 || (scale && shift)) && g_pitch >= c && g_pitch % 4 == 0, MVF_EINVAL, "bn_bwd_reduce: bad mask_mode / pitch");
     MVF_REQUIRE(ws && ws_bytes >= mvf_bn_workspace_bytes(m, c), MVF_EWS, "bn_bwd_reduce: workspace too small");
-    ColPlan p = col_plan(m, c);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)ws;
-    if (dtype == MVF_F32)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const float*)g, g_pitch, (const float*)z, (const float*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (float*)gm_out, p.cqb, p.rows, part);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(p.gx, p.gy), dim3(kThreads), 0, st, (const bf16_t*)g, g_pitch, (const bf16_t*)z, (const bf16_t*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (bf16_t*)gm_out, p.cqb, p.rows, part);
+    const bool wide = false;                 // measured: the 8-byte-lane variant is ~7% faster for this kernel (more rows in flight per wave)
+    const int gy = col_plan(m, c, (dtype != MVF_F32 && wide) ? 8 : 4).gy;
+    MVF_BN_DISPATCH(bn_bwd_reduce_kernel, wide, 2048, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (ET*)gm_out, p.cqb, p.rows, part);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 7) / 8), dim3(256), 0, st, c, p.gy, part, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, st, c, gy, part, dgamma, dbeta);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -552,12 +692,9 @@ int mvf_bn_bwd_apply(const void* g, int g_pitch, const void* z, long m, int c, c
                      int dtype, void* stream) {
     MVF_REQUIRE(g && z && gamma && mean && invstd && dgamma && dbeta && dz && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_bwd_apply: bad argument");
     MVF_REQUIRE((mask_mode == 0 || ((mask_mode == 2 || mask_mode == 3) && scale && shift)) && g_pitch >= c && g_pitch % 4 == 0, MVF_EINVAL, "bn_bwd_apply: mask_mode must be 0, 2 or 3");
-    const long total = m * (c / 4);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MVF_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)g, g_pitch, (const float*)z, m, c, gamma, mean, invstd, scale, shift, dgamma, dbeta, mask_mode, (float*)dz);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)g, g_pitch, (const bf16_t*)z, m, c, gamma, mean, invstd, scale, shift, dgamma, dbeta, mask_mode, (bf16_t*)dz);
+    const bool wide = c % 8 == 0 && g_pitch % 8 == 0 && al16(g) && al16(z) && al16(dz);
+    MVF_BN_DISPATCH(bn_bwd_apply_kernel, wide, 4096, (const ET*)g, g_pitch, (const ET*)z, m, c, gamma, mean, invstd, scale, shift, dgamma, dbeta, mask_mode, (ET*)dz, p.cqb, p.rows);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
