@@ -40,12 +40,17 @@ struct bf16_t {
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// round-to-nearest-even via the gfx950 packed converter (v_cvt_pk_bf16_f32): one instruction per PAIR of values
+typedef __bf16 mvf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mvf_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const mvf_f32x2 v = {lo, hi};
+    const mvf_bf16x2 b = __builtin_convertvector(v, mvf_bf16x2);
+    uint32_t u;
+    __builtin_memcpy(&u, &b, 4);
+    return u;
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(p->v); }
@@ -62,8 +67,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 r;
-    r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-    r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    r.x = pack_bf16x2(v.x, v.y);
+    r.y = pack_bf16x2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = r;
 }
 

@@ -59,6 +59,7 @@ struct ConvArgs {
     int nchunks;   // KH*KW*cpt
     long wK;       // packed weight row length in elements
     int tiles_m, tiles_n;
+    unsigned fd_hw_mul, fd_hw_shr, fd_w_mul, fd_w_shr;   // magic numbers: n / (Ho*Wo) and n / Wo for n < 2^31 (set by launch_conv)
 };
 
 template <typename ET>
@@ -71,6 +72,15 @@ template <>
 struct TT<bf16_t> {
     static constexpr int ESZ = 2, UE = 8, CE = 64;
 };
+
+// n / d for 0 <= n < 2^31 with host-made magic: l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, q = (mulhi(n, mul) + n) >> l
+__device__ __forceinline__ int fd_div(int n, unsigned mul, unsigned shr) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shr); }
+inline void fd_make(unsigned d, unsigned& mul, unsigned& shr) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    shr = l;
+}
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     // bijective remap: XCD x (= bid % 8) owns the contiguous logical range starting at base(x)
@@ -92,7 +102,7 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
 
 // LOWK = single-buffered A/B tiles and a two-pass (half-tile) epilogue: 36 KB of LDS instead of 72 KB -> 3-4 workgroups per CU.
 // Used for the small-K pointwise convs (1-2 K chunks), which are HBM-bound and need memory-level parallelism, not MFMA overlap.
-template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false>
+template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -113,73 +123,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     const int lrow = tid >> 3, q = tid & 7;            // loader: row-in-32, 16-B unit within the 128-B chunk
 
     // ---- per-thread loader state (rows are fixed for the whole K loop) ----
-    int a_pix0[A_ROWS_PT], a_ih0[A_ROWS_PT], a_iw0[A_ROWS_PT];
-#pragma unroll
-    for (int i = 0; i < A_ROWS_PT; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        if (m < a.M) {
-            const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
-            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-            a_ih0[i] = oh * a.stride - a.pad;
-            a_iw0[i] = ow * a.stride - a.pad_w;
-            a_pix0[i] = a.dil > 1 ? img * a.H * a.W : (img * a.H + a_ih0[i]) * a.W + a_iw0[i];
-        } else {
-            a_ih0[i] = -100000;   // never in bounds
-            a_iw0[i] = -100000;
-            a_pix0[i] = 0;
-        }
-    }
-    const char* b_ptr[B_ROWS_PT];
-    bool b_ok[B_ROWS_PT];
-#pragma unroll
-    for (int i = 0; i < B_ROWS_PT; ++i) {
-        const int co = n0 + lrow + 32 * i;
-        b_ok[i] = co < a.Cout;
-        b_ptr[i] = a.w + ((long)(b_ok[i] ? co : 0) * a.wK + q * UE) * ESZ;
-    }
-
-    uint4 ra[A_ROWS_PT], rb[B_ROWS_PT];
+    struct Stage {                       // one K chunk of this thread's loader rows, in registers
+        uint4 a[A_ROWS_PT], b[B_ROWS_PT];
+    };
+    Stage s0, s1;
     int cc = c_begin % a.cpt, kw, kh;    // position of the NEXT chunk to load
     {
         const int tap = c_begin / a.cpt;
         kh = tap / (a.KW > 0 ? a.KW : 1);
         kw = tap - kh * a.KW;
     }
-
-    auto load_chunk = [&]() {
-        const int ci = cc * CE + q * UE;                       // first channel of this thread's unit
-        const bool cok = ci < a.Cin;
-        const bool from2 = (a.split_c > 0) && (cc * CE < a.split_c);
-        const char* xb = from2 ? a.x2 : a.x;
-        const int ps = from2 ? a.x2ps : a.xps;
-#pragma unroll
-        for (int i = 0; i < A_ROWS_PT; ++i) {
-            int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (a.dil > 1) {
-                // zero-upsampled view: only positions that are multiples of dil carry data
-                bool ok = cok && ih >= 0 && iw >= 0 && (ih % a.dil == 0) && (iw % a.dil == 0);
-                ih /= a.dil;
-                iw /= a.dil;
-                ok = ok && ih < a.H && iw < a.W;
-                if (ok) {
-                    const long pix = (long)a_pix0[i] + ih * a.W + iw;
-                    ra[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
-                }
-            } else {
-                const bool ok = cok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
-                if (ok) {
-                    const long pix = (long)a_pix0[i] + kh * a.W + kw;
-                    ra[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
-                }
-            }
-        }
-        const long koff = ((long)((a.w_kh0 + kh * a.w_ts) * a.w_kwfull + (a.w_kw0 + kw * a.w_ts)) * a.Cin + cc * CE) * ESZ;
-#pragma unroll
-        for (int i = 0; i < B_ROWS_PT; ++i) {
-            rb[i] = make_uint4(0, 0, 0, 0);
-            if (b_ok[i] && cok) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + koff);
-        }
+    auto advance = [&]() {
         if (++cc == a.cpt) {
             cc = 0;
             if (++kw == a.KW) {
@@ -188,13 +142,140 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             }
         }
     };
-    auto store_chunk = [&](int buf) {
+
+    // GEN (generic fallback: dilated input, huge images): 64-bit flat addressing with per-row bounds tests.
+    int a_pix0[A_ROWS_PT], a_ih0[A_ROWS_PT], a_iw0[A_ROWS_PT];
+    const char* b_ptr[B_ROWS_PT];
+    bool b_ok[B_ROWS_PT];
+    // fast path: buffer loads (hardware zero-fill for an out-of-range offset -> branch-free padding / tails), 32-bit byte
+    // offsets relative to the first image of the tile, and per-row bit masks of the valid kh / kw taps.
+    constexpr unsigned kOOB = 0x80000000u;
+    unsigned a_off[A_ROWS_PT], a_off2[A_ROWS_PT], hmask[A_ROWS_PT], wmask[A_ROWS_PT], b_off[B_ROWS_PT];
+    __amdgpu_buffer_rsrc_t rs_x, rs_x2, rs_w;
+    if constexpr (GEN) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PT; ++i) {
+            const int m = m0 + lrow + 32 * i;
+            if (m < a.M) {
+                const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+                const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                a_ih0[i] = oh * a.stride - a.pad;
+                a_iw0[i] = ow * a.stride - a.pad_w;
+                a_pix0[i] = a.dil > 1 ? img * a.H * a.W : (img * a.H + a_ih0[i]) * a.W + a_iw0[i];
+            } else {
+                a_ih0[i] = -100000;   // never in bounds
+                a_iw0[i] = -100000;
+                a_pix0[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PT; ++i) {
+            const int co = n0 + lrow + 32 * i;
+            b_ok[i] = co < a.Cout;
+            b_ptr[i] = a.w + ((long)(b_ok[i] ? co : 0) * a.wK + q * UE) * ESZ;
+        }
+    } else {
+        const int hw_o = a.Ho * a.Wo;
+        const int img0 = fd_div(m0, a.fd_hw_mul, a.fd_hw_shr);         // wave-uniform (tile index comes from blockIdx)
+        const long img_px = (long)a.H * a.W;
+        auto span = [&](int ps) {                                      // bytes from the tile's first image to the tensor's end
+            const long bytes = (long)(a.N - img0) * img_px * ps * ESZ;
+            return (unsigned)(bytes < 0x7ffffff0L ? bytes : 0x7ffffff0L);
+        };
+        rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long)img0 * img_px * a.xps * ESZ), 0, span(a.xps), 0x00020000);
+        rs_x2 = rs_x;
+        if (a.split_c > 0) rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 + (long)img0 * img_px * a.x2ps * ESZ), 0, span(a.x2ps), 0x00020000);
+        rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)((long)a.Cout * a.wK * ESZ), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PT; ++i) {
+            const int m = m0 + lrow + 32 * i;
+            const int img = fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * hw_o;
+            const int oh = fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
+            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad_w;
+            const int pix = ((img - img0) * a.H + ih0) * a.W + iw0;    // may be negative for a padded corner; valid taps land >= 0
+            a_off[i] = (unsigned)(pix * a.xps + q * UE) * ESZ;
+            a_off2[i] = (unsigned)(pix * a.x2ps + q * UE) * ESZ;
+            // bit k of hmask: 0 <= ih0 + k < H  (k in [lo, hi)); all zero for rows past M
+            auto range_mask = [](int x0, int lim) {
+                const int lo = x0 < 0 ? -x0 : 0, hi = lim - x0;          // valid k in [lo, hi)
+                const unsigned up = hi >= 32 ? 0xffffffffu : (hi <= 0 ? 0u : ((1u << hi) - 1u));
+                const unsigned dn = lo >= 32 ? 0xffffffffu : ((1u << lo) - 1u);
+                return up & ~dn;
+            };
+            hmask[i] = m < a.M ? range_mask(ih0, a.H) : 0u;
+            wmask[i] = range_mask(iw0, a.W);
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PT; ++i) {
+            const int co = n0 + lrow + 32 * i;
+            b_off[i] = co < a.Cout ? (unsigned)((long)co * a.wK + q * UE) * ESZ : kOOB;
+        }
+    }
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto load_chunk = [&](Stage& st) {
+        const int ci = cc * CE + q * UE;                       // first channel of this thread's unit
+        const bool cok = ci < a.Cin;
+        const bool from2 = (a.split_c > 0) && (cc * CE < a.split_c);
+        if constexpr (GEN) {
+            const char* xb = from2 ? a.x2 : a.x;
+            const int ps = from2 ? a.x2ps : a.xps;
+#pragma unroll
+            for (int i = 0; i < A_ROWS_PT; ++i) {
+                int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                st.a[i] = make_uint4(0, 0, 0, 0);
+                if (a.dil > 1) {
+                    // zero-upsampled view: only positions that are multiples of dil carry data
+                    bool ok = cok && ih >= 0 && iw >= 0 && (ih % a.dil == 0) && (iw % a.dil == 0);
+                    ih /= a.dil;
+                    iw /= a.dil;
+                    ok = ok && ih < a.H && iw < a.W;
+                    if (ok) {
+                        const long pix = (long)a_pix0[i] + ih * a.W + iw;
+                        st.a[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
+                    }
+                } else {
+                    const bool ok = cok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
+                    if (ok) {
+                        const long pix = (long)a_pix0[i] + kh * a.W + kw;
+                        st.a[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
+                    }
+                }
+            }
+            const long koff = ((long)((a.w_kh0 + kh * a.w_ts) * a.w_kwfull + (a.w_kw0 + kw * a.w_ts)) * a.Cin + cc * CE) * ESZ;
+#pragma unroll
+            for (int i = 0; i < B_ROWS_PT; ++i) {
+                st.b[i] = make_uint4(0, 0, 0, 0);
+                if (b_ok[i] && cok) st.b[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + koff);
+            }
+        } else {
+            const unsigned cbad = cok ? 0u : kOOB;                          // channel tail of the last chunk of a tap
+            const int ps = from2 ? a.x2ps : a.xps;
+            const unsigned toff = (unsigned)((kh * a.W + kw) * ps + cc * CE) * ESZ;     // wave-uniform
+            const __amdgpu_buffer_rsrc_t rs = from2 ? rs_x2 : rs_x;
+#pragma unroll
+            for (int i = 0; i < A_ROWS_PT; ++i) {
+                const bool ok = ((hmask[i] >> kh) & (wmask[i] >> kw) & 1u) != 0u;
+                const unsigned off = ((from2 ? a_off2[i] : a_off[i]) + toff) | cbad;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : kOOB, 0, 0);
+                st.a[i] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+            const unsigned koff = (unsigned)(((a.w_kh0 + kh * a.w_ts) * a.w_kwfull + (a.w_kw0 + kw * a.w_ts)) * a.Cin + cc * CE) * ESZ;
+#pragma unroll
+            for (int i = 0; i < B_ROWS_PT; ++i) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (b_off[i] + koff) | cbad, 0, 0);
+                st.b[i] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+        advance();
+    };
+    auto store_chunk = [&](int buf, const Stage& st) {
         char* ad = As + buf * BM * kPitch + lrow * kPitch + q * 16;
 #pragma unroll
-        for (int i = 0; i < A_ROWS_PT; ++i) *reinterpret_cast<uint4*>(ad + 32 * i * kPitch) = ra[i];
+        for (int i = 0; i < A_ROWS_PT; ++i) *reinterpret_cast<uint4*>(ad + 32 * i * kPitch) = st.a[i];
         char* bd = Bs + buf * BN * kPitch + lrow * kPitch + q * 16;
 #pragma unroll
-        for (int i = 0; i < B_ROWS_PT; ++i) *reinterpret_cast<uint4*>(bd + 32 * i * kPitch) = rb[i];
+        for (int i = 0; i < B_ROWS_PT; ++i) *reinterpret_cast<uint4*>(bd + 32 * i * kPitch) = st.b[i];
     };
 
     f32x16 acc[TM][TN];
@@ -206,17 +287,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nseg = c_end - c_begin;
-    if (nseg > 0) {
-        load_chunk();
-        store_chunk(0);
-    }
-    __syncthreads();
-
     const int frag_off = (lane & 31) * kPitch + (lane >> 5) * 16;
-    for (int kc = 0; kc < nseg; ++kc) {
-        const int buf = LOWK ? 0 : (kc & 1);
-        const bool more = kc + 1 < nseg;
-        if (more) load_chunk();
+    auto compute = [&](int buf) {
         const char* Ab = As + buf * BM * kPitch + (wm * TM * 32) * kPitch + frag_off;
         const char* Bb = Bs + buf * BN * kPitch + (wn * TN * 32) * kPitch + frag_off;
 #pragma unroll
@@ -235,7 +307,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                         for (int j = 0; j < TN; ++j) {
                             const float av = __uint_as_float(e == 0 ? fa[i].x : e == 1 ? fa[i].y : e == 2 ? fa[i].z : fa[i].w);
                             const float bv = __uint_as_float(e == 0 ? fb[j].x : e == 1 ? fb[j].y : e == 2 ? fb[j].z : fb[j].w);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[i][j], 0, 0, 0);   // D^T: see the epilogue
                         }
             } else {
 #pragma unroll
@@ -245,19 +317,65 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                         bf16x8 av, bv;
                         __builtin_memcpy(&av, &fa[i], 16);
                         __builtin_memcpy(&bv, &fb[j], 16);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[i][j], 0, 0, 0);
                     }
             }
         }
-        if (LOWK) {
-            if (more) {
-                __syncthreads();                       // every wave is done reading the single buffer
-                store_chunk(0);
-            }
-        } else if (more) {
-            store_chunk(buf ^ 1);
+    };
+    if constexpr (LOWK) {
+        // single LDS buffer, one chunk ahead in registers
+        if (nseg > 0) {
+            load_chunk(s0);
+            store_chunk(0, s0);
         }
         __syncthreads();
+        for (int kc = 0; kc < nseg; ++kc) {
+            const bool more = kc + 1 < nseg;
+            if (more) load_chunk(s0);
+            compute(0);
+            if (more) {
+                __syncthreads();                       // every wave is done reading the single buffer
+                store_chunk(0, s0);
+            }
+            __syncthreads();
+        }
+    } else if constexpr (PF2) {
+        // two LDS buffers and TWO chunks ahead in registers (s0: even chunks, s1: odd chunks): the short-K pointwise layers are
+        // bound by the global-load round trip per chunk, not by MFMA, so keep two round trips in flight per workgroup
+        if (nseg > 0) load_chunk(s0);                  // chunk 0
+        if (nseg > 1) load_chunk(s1);                  // chunk 1
+        if (nseg > 0) store_chunk(0, s0);
+        __syncthreads();
+        if (nseg > 2) load_chunk(s0);                  // chunk 2
+        int kc = 0;
+        for (; kc + 1 < nseg; kc += 2) {
+            compute(0);                                // chunk kc
+            store_chunk(1, s1);                        // chunk kc+1
+            if (kc + 3 < nseg) load_chunk(s1);         // chunk kc+3
+            __syncthreads();
+            compute(1);                                // chunk kc+1
+            if (kc + 2 < nseg) store_chunk(0, s0);     // chunk kc+2
+            if (kc + 4 < nseg) load_chunk(s0);         // chunk kc+4
+            __syncthreads();
+        }
+        if (kc < nseg) {
+            compute(0);
+            __syncthreads();
+        }
+    } else {
+        if (nseg > 0) {
+            load_chunk(s0);
+            store_chunk(0, s0);
+        }
+        __syncthreads();
+        for (int kc = 0; kc < nseg; ++kc) {
+            const int buf = kc & 1;
+            const bool more = kc + 1 < nseg;
+            if (more) load_chunk(s0);
+            compute(buf);
+            if (more) store_chunk(buf ^ 1, s0);
+            __syncthreads();
+        }
     }
 
     // ---- stream-K hand-over of partial accumulators (inter-workgroup, placement independent: agent-scope release on
@@ -304,11 +422,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------
-    // The 32x32 MFMA C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) gives each lane single
-    // floats of 16 different rows: stored directly that is 64 dword stores (and 64 dword residual loads) per wave.
-    // Instead the block tile is transposed through LDS (the A/B buffers are dead after the last barrier) and
-    // written out row-wise, 16 B (f32) / 8 B (bf16) per lane: whole 512-B / 256-B row segments per 32 lanes, and
-    // the residual is read the same way.
+    // The MFMAs are issued with the operands swapped (weights as the row operand), so the 32x32 C/D layout gives each lane
+    // FOUR CONSECUTIVE OUTPUT CHANNELS of one pixel per register quad: pixel = lane&31, channel = 8*(r>>2) + 4*(lane>>5) + (r&3).
+    // The block tile is staged through LDS (the A/B buffers are dead after the last barrier) with 16-byte writes and read
+    // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
+    // residual loads.
     constexpr int CP = BN * 4 + 16;                      // C-tile pitch in bytes
     constexpr int NH = LOWK ? 2 : 1;                     // epilogue passes (row halves of the block tile)
     constexpr int HR = BM / NH;                          // rows per pass
@@ -333,42 +451,48 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             for (int i = 0; i < TM; ++i) {
                 const int rbase = (wm * TM + i) * 32;
                 if (rbase / HR != hf) continue;          // this MFMA row-tile belongs to the other half
+                char* cp = smem + (rbase - hf * HR + (lane & 31)) * CP + ((wn * TN + j) * 32 + 4 * (lane >> 5)) * 4;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase - hf * HR + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int cc2 = (wn * TN + j) * 32 + (lane & 31);
-                    *reinterpret_cast<float*>(smem + row * CP + cc2 * 4) = acc[i][j][r];
-                }
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(cp + g * 32) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
             }
         __syncthreads();
         if (col < a.Cout) {                              // Cout % 4 == 0 (checked on the host)
+            const int mrow0 = m0 + hf * HR + r0;
+            const long ostep = (long)RPP * a.Cout;       // contiguous output: consecutive passes are RPP rows apart
+            long o = (long)mrow0 * a.Cout + col;
 #pragma unroll 4
-            for (int ps = 0; ps < HR / RPP; ++ps) {
-                const int row = r0 + ps * RPP;
-                const int m = m0 + hf * HR + row;
+            for (int ps = 0; ps < HR / RPP; ++ps, o += ostep) {
+                const int m = mrow0 + ps * RPP;
                 if (m < a.M) {
-                    float4 v = *reinterpret_cast<const float4*>(smem + row * CP + cq * 16);
-                    long opix = m;
-                    if (a.o_s > 0) {
-                        const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
-                        const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-                        opix = ((long)img * a.o_hfull + oh * a.o_s + a.o_ph) * a.o_wfull + ow * a.o_s + a.o_pw;
+                    float4 v = *reinterpret_cast<const float4*>(smem + (r0 + ps * RPP) * CP + cq * 16);
+                    long oo = o;
+                    if (a.o_s > 0) {                     // strided data-gradient class: scatter into the full-resolution map
+                        const int img = fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * (a.Ho * a.Wo);
+                        const int oh = fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
+                        oo = (((long)img * a.o_hfull + oh * a.o_s + a.o_ph) * a.o_wfull + ow * a.o_s + a.o_pw) * a.Cout + col;
                     }
-                    const long o = opix * a.Cout + col;
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     if (res) {
-                        const float4 rv = ld4(res + o);
+                        const float4 rv = ld4(res + oo);
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
                     if (a.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    st4(y + o, v);
+                    if constexpr (sizeof(ET) == 2) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(v.x, v.y);
+                        pk.y = pack_bf16x2(v.z, v.w);
+                        *reinterpret_cast<uint2*>(y + oo) = pk;
+                        // statistics of what is STORED (bf16-rounded), as the consumers will read it
+                        v = make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                                        __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u));
+                    } else {
+                        st4(y + oo, v);
+                    }
                     if (a.stats_part) {
-                        if (sizeof(ET) == 2) {           // statistics of what is STORED (bf16-rounded), as the consumers will read it
-                            v.x = bf16_to_f32(f32_to_bf16(v.x)); v.y = bf16_to_f32(f32_to_bf16(v.y));
-                            v.z = bf16_to_f32(f32_to_bf16(v.z)); v.w = bf16_to_f32(f32_to_bf16(v.w));
-                        }
                         v.x -= kk.x; v.y -= kk.y; v.z -= kk.z; v.w -= kk.w;
                         st1.x += v.x; st1.y += v.y; st1.z += v.z; st1.w += v.w;
                         st2.x += v.x * v.x; st2.y += v.y * v.y; st2.z += v.z * v.z; st2.w += v.w * v.w;
@@ -401,6 +525,22 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
     conv_tile<ET, WM, WN, TM, TN>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+// generic fallback (conv_tile GEN): input dilation or images too large for 32-bit tile-relative offsets
+template <typename ET, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(kThreads) void conv_igemm_gen_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<ET, WM, WN, TM, TN, false, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+// two chunks ahead in registers (see conv_tile PF2): the latency-bound variant of conv_igemm_kernel
+template <typename ET, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(kThreads) void conv_igemm_pf2_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<ET, WM, WN, TM, TN, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
 template <typename ET, int WM, int WN, int TM, int TN>
@@ -477,12 +617,15 @@ struct SkHost {
 };
 
 bool g_lowk_enabled = true;      // A/B switch for experiments (MVF_CONV_LOWK=0 disables)
+int g_pf2_mode = 1;              // two-chunk register prefetch: 0 off, 1 bf16 only, 2 both dtypes (MVF_CONV_PF2)
 
 int sk_slots() {
     static int slots = 0;
     if (!slots) {
         const char* e = getenv("MVF_CONV_LOWK");
         if (e && e[0] == '0') g_lowk_enabled = false;
+        e = getenv("MVF_CONV_PF2");
+        if (e && e[0] >= '0' && e[0] <= '2') g_pf2_mode = e[0] - '0';
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) {
             hipDeviceProp_t p;
@@ -501,17 +644,51 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
+    fd_make((unsigned)(a.Ho * a.Wo), a.fd_hw_mul, a.fd_hw_shr);
+    fd_make((unsigned)a.Wo, a.fd_w_mul, a.fd_w_shr);
     const size_t lds = (size_t)2 * (BM + BN) * kPitch;
     auto kern = conv_igemm_kernel<ET, WM, WN, TM, TN>;
     auto kern_sk = conv_streamk_kernel<ET, WM, WN, TM, TN>;
     auto kern_lk = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN>;
+    auto kern_pf = conv_igemm_pf2_kernel<ET, WM, WN, TM, TN>;
     static bool attr_done = false;   // per instantiation; idempotent, so a benign race at worst
     if (!attr_done) {
         MVF_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)kern_pf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MVF_HIP_OK(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     const int tiles = a.tiles_m * a.tiles_n, slots = sk_slots();
+    // the fast loader addresses a tile with 32-bit byte offsets relative to its first image (a tile spans <= 128 + 1 images)
+    const long img_bytes = (long)a.H * a.W * std::max(a.xps, a.x2ps) * (long)sizeof(ET);
+    const long span_imgs = std::min<long>(a.N, 128L / std::max(1, a.Ho * a.Wo) + 2);
+    if (a.dil > 1 || img_bytes * span_imgs >= 0x7ffffff0L || (long)a.Cout * a.wK * (long)sizeof(ET) >= 0x7ffffff0L) {
+        auto kern_gen = conv_igemm_gen_kernel<ET, WM, WN, TM, TN>;
+        static bool gen_attr = false;
+        if (!gen_attr) {
+            MVF_HIP_OK(hipFuncSetAttribute((const void*)kern_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            gen_attr = true;
+        }
+        hipLaunchKernelGGL(kern_gen, dim3(tiles), dim3(kThreads), lds, st, a);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
+    static const bool sk_all = getenv("MVF_CONV_SKALL") != nullptr;     // experiment: persistent launch of every tile
+    if (sk_all && skh.ws && skh.ws_bytes >= sk_ws_bytes() && tiles > slots) {
+        SkArgs sk;
+        const long units = (long)tiles * a.nchunks;
+        sk.G = slots;
+        sk.units_base = (int)(units / sk.G);
+        sk.units_rem = (int)(units % sk.G);
+        sk.tile0 = 0;
+        sk.ws = (float*)skh.ws;
+        sk.flags = (unsigned*)((char*)skh.ws + (size_t)slots * (128 * 128 * sizeof(float)));
+        sk.err = sk.flags + slots;
+        MVF_HIP_OK(hipMemsetAsync(sk.flags, 0, (size_t)(slots + 1) * sizeof(unsigned), st));
+        hipLaunchKernelGGL(kern_sk, dim3(sk.G), dim3(kThreads), lds, st, a, sk);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     if (a.nchunks <= 2 && g_lowk_enabled) {      // HBM-bound small-K conv: half the LDS, 3-4 workgroups per CU
         hipLaunchKernelGGL(kern_lk, dim3(tiles), dim3(kThreads), lds / 2, st, a);
         MVF_LAUNCH_CHECK();
@@ -525,7 +702,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     const bool use_sk = skh.ws && skh.ws_bytes >= sk_ws_bytes() && tail > 0 && (long)tail * a.nchunks >= slots &&
                         (1.0f - (float)tail / slots) * wave_us > 60.0f;
     if (!use_sk) {
-        hipLaunchKernelGGL(kern, dim3(tiles), dim3(kThreads), lds, st, a);
+        const bool pf2 = g_pf2_mode == 2 || (g_pf2_mode == 1 && sizeof(ET) == 2);
+        hipLaunchKernelGGL(pf2 ? kern_pf : kern, dim3(tiles), dim3(kThreads), lds, st, a);
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }

@@ -69,15 +69,15 @@ __device__ __forceinline__ void stv(ET* p, const float (&f)[VN]) {
         *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
     } else if constexpr (VN == 4) {
         uint2 r;
-        r.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
-        r.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+        r.x = pack_bf16x2(f[0], f[1]);
+        r.y = pack_bf16x2(f[2], f[3]);
         *reinterpret_cast<uint2*>(p) = r;
     } else {
         uint4 r;
-        r.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
-        r.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
-        r.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
-        r.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+        r.x = pack_bf16x2(f[0], f[1]);
+        r.y = pack_bf16x2(f[2], f[3]);
+        r.z = pack_bf16x2(f[4], f[5]);
+        r.w = pack_bf16x2(f[6], f[7]);
         *reinterpret_cast<uint4*>(p) = r;
     }
 }
