@@ -442,6 +442,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // fused BatchNorm statistics of the tensor being written (training): this thread's rows of its 4 columns
     float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = st1, kk = st1;
     if (a.stats_part && a.stats_shift && col < a.Cout) kk = *reinterpret_cast<const float4*>(a.stats_shift + col);
+    // output / residual descriptors: tile-relative 32-bit offsets (contiguous rows from m0, or the full-resolution images
+    // from the tile's first image for a scattered data-gradient class)
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int eimg0 = fd_div(m0, a.fd_hw_mul, a.fd_hw_shr);
+    __amdgpu_buffer_rsrc_t rs_y, rs_res;
+    {
+        const long total = (a.o_s > 0 ? (long)a.N * a.o_hfull * a.o_wfull : (long)a.M) * a.Cout * ESZ;
+        const long base = (a.o_s > 0 ? (long)eimg0 * a.o_hfull * a.o_wfull : (long)m0) * a.Cout * ESZ;
+        const long left = total - base;
+        const unsigned nrec = (unsigned)(left < 0x7ffffff0L ? left : 0x7ffffff0L);
+        rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + base), 0, nrec, 0x00020000);
+        rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + base : a.y + base), 0, nrec, 0x00020000);
+    }
+    (void)y; (void)res;
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
         if (hf > 0) __syncthreads();                     // previous half fully read out
@@ -458,45 +472,59 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                         make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
             }
         __syncthreads();
-        if (col < a.Cout) {                              // Cout % 4 == 0 (checked on the host)
+        {
+            // branch-free rows: out-of-range rows / columns get an out-of-range buffer offset (loads return 0, stores are dropped),
+            // so the residual loads of the unrolled rows can all be issued ahead of their use
             const int mrow0 = m0 + hf * HR + r0;
-            const long ostep = (long)RPP * a.Cout;       // contiguous output: consecutive passes are RPP rows apart
-            long o = (long)mrow0 * a.Cout + col;
+            const bool cok2 = col < a.Cout;              // Cout % 4 == 0 (checked on the host)
 #pragma unroll 4
-            for (int ps = 0; ps < HR / RPP; ++ps, o += ostep) {
+            for (int ps = 0; ps < HR / RPP; ++ps) {
                 const int m = mrow0 + ps * RPP;
-                if (m < a.M) {
-                    float4 v = *reinterpret_cast<const float4*>(smem + (r0 + ps * RPP) * CP + cq * 16);
-                    long oo = o;
-                    if (a.o_s > 0) {                     // strided data-gradient class: scatter into the full-resolution map
-                        const int img = fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * (a.Ho * a.Wo);
-                        const int oh = fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
-                        oo = (((long)img * a.o_hfull + oh * a.o_s + a.o_ph) * a.o_wfull + ow * a.o_s + a.o_pw) * a.Cout + col;
-                    }
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    if (res) {
-                        const float4 rv = ld4(res + oo);
-                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                    }
-                    if (a.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
+                const bool ok = cok2 && m < a.M;
+                float4 v = *reinterpret_cast<const float4*>(smem + (r0 + ps * RPP) * CP + cq * 16);
+                unsigned off;
+                if (a.o_s > 0) {                         // strided data-gradient class: scatter into the full-resolution map
+                    const int img = fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * (a.Ho * a.Wo);
+                    const int oh = fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
+                    off = (unsigned)((((img - eimg0) * a.o_hfull + oh * a.o_s + a.o_ph) * a.o_wfull + ow * a.o_s + a.o_pw) * a.Cout + col) * ESZ;
+                } else {
+                    off = (unsigned)((m - m0) * a.Cout + col) * ESZ;
+                }
+                off = ok ? off : kOOB;
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (a.res) {
+                    float4 rv;
                     if constexpr (sizeof(ET) == 2) {
-                        uint2 pk;
-                        pk.x = pack_bf16x2(v.x, v.y);
-                        pk.y = pack_bf16x2(v.z, v.w);
-                        *reinterpret_cast<uint2*>(y + oo) = pk;
-                        // statistics of what is STORED (bf16-rounded), as the consumers will read it
-                        v = make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
-                                        __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u));
+                        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0);
+                        rv = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+                                         __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
                     } else {
-                        st4(y + oo, v);
+                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
+                        rv = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
                     }
-                    if (a.stats_part) {
-                        v.x -= kk.x; v.y -= kk.y; v.z -= kk.z; v.w -= kk.w;
-                        st1.x += v.x; st1.y += v.y; st1.z += v.z; st1.w += v.w;
-                        st2.x += v.x * v.x; st2.y += v.y * v.y; st2.z += v.z * v.z; st2.w += v.w * v.w;
-                    }
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if constexpr (sizeof(ET) == 2) {
+                    u32x2 pk;
+                    pk.x = pack_bf16x2(v.x, v.y);
+                    pk.y = pack_bf16x2(v.z, v.w);
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, rs_y, off, 0, 0);
+                    // statistics of what is STORED (bf16-rounded), as the consumers will read it
+                    v = make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                                    __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u));
+                } else {
+                    u32x4 pk;
+                    pk.x = __float_as_uint(v.x); pk.y = __float_as_uint(v.y); pk.z = __float_as_uint(v.z); pk.w = __float_as_uint(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, off, 0, 0);
+                }
+                if (a.stats_part) {
+                    if (!ok) v = kk;                     // rows past M contribute nothing
+                    v.x -= kk.x; v.y -= kk.y; v.z -= kk.z; v.w -= kk.w;
+                    st1.x += v.x; st1.y += v.y; st1.z += v.z; st1.w += v.w;
+                    st2.x += v.x * v.x; st2.y += v.y * v.y; st2.z += v.z * v.z; st2.w += v.w * v.w;
                 }
             }
         }
@@ -662,6 +690,9 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     // the fast loader addresses a tile with 32-bit byte offsets relative to its first image (a tile spans <= 128 + 1 images)
     const long img_bytes = (long)a.H * a.W * std::max(a.xps, a.x2ps) * (long)sizeof(ET);
     const long span_imgs = std::min<long>(a.N, 128L / std::max(1, a.Ho * a.Wo) + 2);
+    // the epilogue addresses the output the same way (only a scattered data-gradient class can span whole images)
+    MVF_REQUIRE(a.o_s <= 0 || (long)a.o_hfull * a.o_wfull * a.Cout * (long)sizeof(ET) * span_imgs < 0x7ffffff0L, MVF_EUNSUPPORTED,
+                "conv2d: output image too large for tile-relative 32-bit addressing");
     if (a.dil > 1 || img_bytes * span_imgs >= 0x7ffffff0L || (long)a.Cout * a.wK * (long)sizeof(ET) >= 0x7ffffff0L) {
         auto kern_gen = conv_igemm_gen_kernel<ET, WM, WN, TM, TN>;
         static bool gen_attr = false;
