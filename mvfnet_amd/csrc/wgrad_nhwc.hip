@@ -27,7 +27,17 @@ struct WgArgs {
     float* part;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, xps, split_c, x2ps;
     int M, K, rows_per_split, tiles_k;
+    unsigned fd_hw_mul, fd_hw_shr, fd_w_mul, fd_w_shr;   // magic numbers for n / (Ho*Wo) and n / Wo, n < 2^31 (bf16 kernel)
 };
+
+// n / d for 0 <= n < 2^31 with host-made magic: l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, q = (mulhi(n, mul) + n) >> l
+__device__ __forceinline__ int wg_fd_div(int n, unsigned mul, unsigned shr) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shr); }
+inline void wg_fd_make(unsigned d, unsigned& mul, unsigned& shr) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    shr = l;
+}
 
 // Output tile BCO x BK = (2*TM*32) x (2*TN*32): 128x128 (TM=TN=2), 64x128 for Cout <= 64 (TM=1), 128x64 for K <= 64 (TN=1)
 // ET = storage type of dz / x (fp32 or bf16).  bf16 operands are widened to fp32 on the way into LDS and the contraction
@@ -147,12 +157,24 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
 // rows apart).  That is 8x the LDS instructions of a k-major tile, but this GEMM is L2/HBM-bound long before that (64 x
 // (128+128) x 2 B of operands per 16 MFMAs), and it is 4x fewer HBM bytes and 16x the matrix rate of widening to fp32.
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+// XOR swizzle of the 16-byte units of an LDS row with U units (U = 16: 256-B rows, U = 8: 128-B rows), see wgrad_bf16_kernel
+template <int U>
+__device__ __forceinline__ int swz16(int row) {
+    static_assert(U == 8 || U == 16, "64- or 128-channel tile rows");
+    return U == 16 ? (row & 3) << 2 : ((row >> 1) & 1) << 2;
+}
 constexpr int BMR16 = 64;                            // pixels per chunk = 4 MFMA k-steps
 
 template <int TM, int TN>
 __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
     constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
-    constexpr int PA = BCO * 2 + 16, PB = BK * 2 + 16;              // LDS row pitches in bytes
+    // LDS images stay in the natural [pixel][channel] layout (16-byte coalesced staging writes, no padding); the MFMA
+    // operands (8 consecutive PIXELS of one channel per lane) come out of it with the gfx950 transpose read
+    // ds_read_b64_tr_b16: every 16-lane group hands in a [4 pixel][16 channel] block (lane i: pixel i>>2, channels
+    // 4*(i&3)..+3, 8 bytes) and lane i gets channel i of the 4 pixels (mapping probed in tools/probes/tr_b16_probe.hip).
+    // Bank conflicts: a 32-lane half reads 4 pixel rows x 64 B; the 16-byte units of a row are XOR-swizzled by the row
+    // (swz16) so that those four 64-B pieces fall into four different 16-bank ranges.
+    constexpr int PA = BCO * 2, PB = BK * 2;                        // LDS row pitches in bytes
     constexpr int UA = BCO / 8, UB = BK / 8;                        // 16-B units (8 bf16) per row
     constexpr int NA = BMR16 * UA / kThreads, NB = BMR16 * UB / kThreads;
     extern __shared__ __attribute__((aligned(16))) char smem16[];
@@ -179,44 +201,74 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     const int nchunks = (m_end - m_begin + BMR16 - 1) / BMR16;
 
-    uint4 rd[NA], rx[NB];
-    auto load_chunk = [&](int c) {
+    struct Stage {                        // one chunk of this thread's loader rows, in registers
+        uint4 d[NA], x[NB];
+        unsigned okx;                     // bit i: x row i is a real tap (else it is stored as zeros)
+    };
+    Stage s0, s1;
+    // dz: buffer loads relative to the split's first row (rows past the split / channel tails get an out-of-range offset ->
+    // the hardware returns 0).  x: the source tensor (x or x2 for the MVF split) and the tap differ per lane, so these are
+    // flat loads, kept branch-free by reading the tensor base for padding / out-of-range taps and zeroing at the LDS write.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned kOOB = 0x80000000u;
+    const int hw_o = a.Ho * a.Wo;
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(dzp + (long)m_begin * a.Cout), 0, (unsigned)min((long)(m_end - m_begin) * a.Cout * 2, 0x7ffffff0L), 0x00020000);
+    auto load_chunk = [&](int c, Stage& st) {
+        const int mc = m_begin + c * BMR16;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int m = m_begin + c * BMR16 + ra0 + (kThreads / UA) * i;
-            rd[i] = make_uint4(0, 0, 0, 0);
-            if (m < m_end && co_ok) rd[i] = *reinterpret_cast<const uint4*>(dzp + (long)m * a.Cout + co);
+            const int r = c * BMR16 + ra0 + (kThreads / UA) * i;                       // row within the split
+            const unsigned off = co_ok ? (unsigned)(r * a.Cout + qa * 8 + co0) * 2u : kOOB;   // past m_end -> past num_records
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_dz, off, 0, 0);
+            st.d[i] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+        st.okx = 0u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int m = mc + rb0 + (kThreads / UB) * i;
+            const int img = wg_fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * hw_o;
+            const int oh = wg_fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
+            const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+            const bool ok = m < m_end && k_ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const long off = ok ? ((long)((img * a.H + ih) * a.W + iw) * ps + ci) : 0L;
+            st.x[i] = *reinterpret_cast<const uint4*>(xb + off);
+            st.okx |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto store_chunk = [&](int buf, const Stage& st) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = ra0 + (kThreads / UA) * i;
+            *reinterpret_cast<uint4*>(Ds + (buf * BMR16 + row) * PA + ((qa ^ swz16<UA>(row)) * 16)) = st.d[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int m = m_begin + c * BMR16 + rb0 + (kThreads / UB) * i;
-            rx[i] = make_uint4(0, 0, 0, 0);
-            if (m < m_end && k_ok) {
-                const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
-                const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-                const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
-                if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-                    rx[i] = *reinterpret_cast<const uint4*>(xb + ((long)(img * a.H + ih) * a.W + iw) * ps + ci);
-            }
+            const int row = rb0 + (kThreads / UB) * i;
+            const bool ok = (st.okx >> i) & 1u;
+            const uint4 v = st.x[i];
+            *reinterpret_cast<uint4*>(Xs + (buf * BMR16 + row) * PB + ((qb ^ swz16<UB>(row)) * 16)) =
+                make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
         }
     };
-    auto store_chunk = [&](int buf) {
+    // per-lane byte offsets of the transpose reads: group g = lane>>4 supplies pixel rows (i>>2) + 8*(g>>1) and channel
+    // quad 16*(g&1) + 4*(i&3) of a 32-channel block; k-steps / the second 4-pixel half / the buffer are immediates on top
+    const int tg = lane >> 4, ti = lane & 15;
+    const int trow = (ti >> 2) + 8 * (tg >> 1);
+    const int tunit = 2 * (tg & 1) + ((ti & 3) >> 1), thalf = ti & 1;
+    int offA[TM], offB[TN];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(Ds + (buf * BMR16 + ra0 + (kThreads / UA) * i) * PA + qa * 16) = rd[i];
+    for (int i = 0; i < TM; ++i) offA[i] = trow * PA + ((((wm * TM + i) * 4 + tunit) ^ swz16<UA>(trow)) * 16) + thalf * 8;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(Xs + (buf * BMR16 + rb0 + (kThreads / UB) * i) * PB + qb * 16) = rx[i];
-    };
-    // 8 pixels (rows r0..r0+7) of one channel column -> the lane's MFMA operand
-    auto gather = [&](const char* base, int pitch) {
-        unsigned w[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const unsigned lo = *reinterpret_cast<const unsigned short*>(base + (2 * t) * pitch);
-            const unsigned hi = *reinterpret_cast<const unsigned short*>(base + (2 * t + 1) * pitch);
-            w[t] = lo | (hi << 16);
-        }
+    for (int j = 0; j < TN; ++j) offB[j] = trow * PB + ((((wn * TN + j) * 4 + tunit) ^ swz16<UB>(trow)) * 16) + thalf * 8;
+    auto gather = [&](const char* p, int pitch) {          // rows +0..3 and +4..7 of the lane's channel
+        typedef short v4s __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s* lds_v4s;
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p + 4 * pitch));
         bf16x8_t v;
-        __builtin_memcpy(&v, w, 16);
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         return v;
     };
 
@@ -228,32 +280,41 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
-    }
-    __syncthreads();
     const int lr = lane >> 5, lc = lane & 31;
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        const bool more = c + 1 < nchunks;
-        if (more) load_chunk(c + 1);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < BMR16 / 16; ++ks) {
-            const int r0 = buf * BMR16 + ks * 16 + 8 * lr;
+            const int r0 = buf * BMR16 + ks * 16;
             bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = gather(Ds + r0 * PA + ((wm * TM + i) * 32 + lc) * 2, PA);
+            for (int i = 0; i < TM; ++i) fa[i] = gather(Ds + r0 * PA + offA[i], PA);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = gather(Xs + r0 * PB + ((wn * TN + j) * 32 + lc) * 2, PB);
+            for (int j = 0; j < TN; ++j) fb[j] = gather(Xs + r0 * PB + offB[j], PB);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_chunk(buf ^ 1);
+    };
+    // two chunks ahead in registers (s0: even chunks, s1: odd chunks), two LDS buffers: the loop is bound by the global-load
+    // round trip per chunk (16 MFMAs = 0.25 us of matrix work against ~2 us of latency), so keep two round trips in flight
+    if (nchunks > 0) load_chunk(0, s0);
+    if (nchunks > 1) load_chunk(1, s1);
+    if (nchunks > 0) store_chunk(0, s0);
+    __syncthreads();
+    if (nchunks > 2) load_chunk(2, s0);
+    int c = 0;
+    for (; c + 1 < nchunks; c += 2) {
+        compute(0);                                    // chunk c
+        store_chunk(1, s1);                            // chunk c+1
+        if (c + 3 < nchunks) load_chunk(c + 3, s1);
+        __syncthreads();
+        compute(1);                                    // chunk c+1
+        if (c + 2 < nchunks) store_chunk(0, s0);       // chunk c+2
+        if (c + 4 < nchunks) load_chunk(c + 4, s0);
         __syncthreads();
     }
+    if (c < nchunks) compute(0);
     float* out = a.part + (long)blockIdx.y * a.Cout * a.K;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -272,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
 template <int TM, int TN>
 int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
     constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
-    const size_t lds = (size_t)2 * BMR16 * ((BCO * 2 + 16) + (BK * 2 + 16));
+    const size_t lds = (size_t)2 * BMR16 * (BCO * 2 + BK * 2);
     auto kern = wgrad_bf16_kernel<TM, TN>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -380,6 +441,8 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     const int tiles = ((d->cout + t.bco - 1) / t.bco) * a.tiles_k;
     a.rows_per_split = plan_split(a.M, tiles);
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+    wg_fd_make((unsigned)(a.Ho * a.Wo), a.fd_hw_mul, a.fd_hw_shr);
+    wg_fd_make((unsigned)a.Wo, a.fd_w_mul, a.fd_w_shr);
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == MVF_F32) {
         if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
