@@ -342,20 +342,23 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     } else if constexpr (PF2) {
         // two LDS buffers and TWO chunks ahead in registers (s0: even chunks, s1: odd chunks): the short-K pointwise layers are
         // bound by the global-load round trip per chunk, not by MFMA, so keep two round trips in flight per workgroup
-        if (nseg > 0) load_chunk(s0);                  // chunk 0
-        if (nseg > 1) load_chunk(s1);                  // chunk 1
+        // The prefetch loads are issued UNCONDITIONALLY, also past the last chunk: a conditional load would force the compiler
+        // to assume "no younger load in flight" at every s_waitcnt (a static count), i.e. vmcnt(0), which drains the prefetch.
+        // Past-the-end loads are harmless: buffer loads are range-checked (zero fill) and their data is never stored.
+        load_chunk(s0);                                // chunk 0
+        load_chunk(s1);                                // chunk 1
         if (nseg > 0) store_chunk(0, s0);
         __syncthreads();
-        if (nseg > 2) load_chunk(s0);                  // chunk 2
+        load_chunk(s0);                                // chunk 2
         int kc = 0;
         for (; kc + 1 < nseg; kc += 2) {
             compute(0);                                // chunk kc
             store_chunk(1, s1);                        // chunk kc+1
-            if (kc + 3 < nseg) load_chunk(s1);         // chunk kc+3
+            load_chunk(s1);                            // chunk kc+3
             __syncthreads();
             compute(1);                                // chunk kc+1
             if (kc + 2 < nseg) store_chunk(0, s0);     // chunk kc+2
-            if (kc + 4 < nseg) load_chunk(s0);         // chunk kc+4
+            load_chunk(s0);                            // chunk kc+4
             __syncthreads();
         }
         if (kc < nseg) {

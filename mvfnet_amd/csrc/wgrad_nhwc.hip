@@ -298,20 +298,22 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
     };
     // two chunks ahead in registers (s0: even chunks, s1: odd chunks), two LDS buffers: the loop is bound by the global-load
     // round trip per chunk (16 MFMAs = 0.25 us of matrix work against ~2 us of latency), so keep two round trips in flight
-    if (nchunks > 0) load_chunk(0, s0);
-    if (nchunks > 1) load_chunk(1, s1);
+    // The prefetch loads are UNCONDITIONAL (also past the last chunk: rows >= m_end read zeros / the tensor base): a conditional
+    // load forces the compiler to assume no younger load is in flight at each static s_waitcnt, i.e. vmcnt(0) everywhere.
+    load_chunk(0, s0);
+    load_chunk(1, s1);
     if (nchunks > 0) store_chunk(0, s0);
     __syncthreads();
-    if (nchunks > 2) load_chunk(2, s0);
+    load_chunk(2, s0);
     int c = 0;
     for (; c + 1 < nchunks; c += 2) {
         compute(0);                                    // chunk c
         store_chunk(1, s1);                            // chunk c+1
-        if (c + 3 < nchunks) load_chunk(c + 3, s1);
+        load_chunk(c + 3, s1);
         __syncthreads();
         compute(1);                                    // chunk c+1
         if (c + 2 < nchunks) store_chunk(0, s0);       // chunk c+2
-        if (c + 4 < nchunks) load_chunk(c + 4, s0);
+        load_chunk(c + 4, s0);
         __syncthreads();
     }
     if (c < nchunks) compute(0);
