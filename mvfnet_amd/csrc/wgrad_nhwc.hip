@@ -27,11 +27,23 @@ struct WgArgs {
     float* part;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, xps, split_c, x2ps;
     int M, K, rows_per_split, tiles_k;
+    int tiles, nsplit;   // output tiles and pixel splits; the 1-D grid is 8 * ceil(nsplit / 8) * tiles (see wg_map)
     unsigned fd_hw_mul, fd_hw_shr, fd_w_mul, fd_w_shr;   // magic numbers for n / (Ho*Wo) and n / Wo, n < 2^31 (bf16 kernel)
 };
 
 // n / d for 0 <= n < 2^31 with host-made magic: l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, q = (mulhi(n, mul) + n) >> l
 __device__ __forceinline__ int wg_fd_div(int n, unsigned mul, unsigned shr) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shr); }
+// Workgroup -> (output tile, pixel split).  All tiles of one split read the SAME dz / x rows, so they are placed on the same
+// XCD (consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2): split s lives on XCD s % 8 and its tiles
+// are consecutive there.  With the plain (tile, split) grid every XCD re-fetched every row: 2-4x the algorithmic HBM reads
+// (rocprofv3 FETCH_SIZE, profiles/r01_pmc_summary_bf16_train.json before/after).
+__device__ __forceinline__ bool wg_map(const int tiles, const int nsplit, int& tile, int& split) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int sl = idx / tiles;
+    tile = idx - sl * tiles;
+    split = sl * 8 + xcd;
+    return split < nsplit;
+}
 inline void wg_fd_make(unsigned d, unsigned& mul, unsigned& shr) {
     unsigned l = 0;
     while ((1ull << l) < d) ++l;
@@ -50,7 +62,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
     constexpr int PA = BMR * UA / kThreads, PB = BMR * UB / kThreads;   // units per thread per chunk
     __shared__ __attribute__((aligned(16))) float Ds[2][BMR][BCO];
     __shared__ __attribute__((aligned(16))) float Xs[2][BMR][BK];
-    const int tile_k = blockIdx.x % a.tiles_k, tile_co = blockIdx.x / a.tiles_k;
+    int wg_tile, wg_split;
+    if (!wg_map(a.tiles, a.nsplit, wg_tile, wg_split)) return;
+    const int tile_k = wg_tile % a.tiles_k, tile_co = wg_tile / a.tiles_k;
     const int co0 = tile_co * BCO, k0 = tile_k * BK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
     const ET* dzp = reinterpret_cast<const ET*>(a.dz);
     const int ps = from2 ? a.x2ps : a.xps;
 
-    const int m_begin = blockIdx.y * a.rows_per_split;
+    const int m_begin = wg_split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     const int nchunks = (m_end - m_begin + BMR - 1) / BMR;
 
@@ -134,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
         __syncthreads();
     }
     // partial[split][co][kcol]
-    float* out = a.part + (long)blockIdx.y * a.Cout * a.K;
+    float* out = a.part + (long)wg_split * a.Cout * a.K;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = k0 + (wn * TN + j) * 32 + lc;
@@ -180,7 +194,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     char* Ds = smem16;                                              // [2][BMR16][PA]
     char* Xs = smem16 + 2 * BMR16 * PA;                             // [2][BMR16][PB]
-    const int tile_k = blockIdx.x % a.tiles_k, tile_co = blockIdx.x / a.tiles_k;
+    int wg_tile, wg_split;
+    if (!wg_map(a.tiles, a.nsplit, wg_tile, wg_split)) return;
+    const int tile_k = wg_tile % a.tiles_k, tile_co = wg_tile / a.tiles_k;
     const int co0 = tile_co * BCO, k0 = tile_k * BK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
     const bf16_t* dzp = reinterpret_cast<const bf16_t*>(a.dz);
     const int ps = from2 ? a.x2ps : a.xps;
 
-    const int m_begin = blockIdx.y * a.rows_per_split;
+    const int m_begin = wg_split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     const int nchunks = (m_end - m_begin + BMR16 - 1) / BMR16;
 
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
         __syncthreads();
     }
     if (c < nchunks) compute(0);
-    float* out = a.part + (long)blockIdx.y * a.Cout * a.K;
+    float* out = a.part + (long)wg_split * a.Cout * a.K;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = k0 + (wn * TN + j) * 32 + lc;
@@ -342,7 +358,7 @@ int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
         MVF_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, nsplit), dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), lds, st, a);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -443,13 +459,15 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     const int tiles = ((d->cout + t.bco - 1) / t.bco) * a.tiles_k;
     a.rows_per_split = plan_split(a.M, tiles);
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+    a.tiles = tiles;
+    a.nsplit = nsplit;
     wg_fd_make((unsigned)(a.Ho * a.Wo), a.fd_hw_mul, a.fd_hw_shr);
     wg_fd_make((unsigned)a.Wo, a.fd_w_mul, a.fd_w_shr);
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == MVF_F32) {
-        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
-        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
+        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
     } else if (d->cin % 8 == 0 && d->cout % 8 == 0 && d->x_pix_stride % 4 == 0 && (d->split_c % 8) == 0 &&
                ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0) {
         int rc;
@@ -458,9 +476,9 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
         else rc = launch_wgrad_bf16<2, 2>(a, tiles, nsplit, st);
         if (rc) return rc;
     } else {     // odd channel counts: widen to fp32 on the way into LDS
-        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
-        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 1>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 2>), dim3(tiles, nsplit), dim3(kThreads), 0, st, a);
+        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 2>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
+        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 1>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 2>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
     }
     MVF_LAUNCH_CHECK();
     const long total = (long)d->cout * d->kh * d->kw * d->cin;
