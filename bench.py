@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="train mode: keep the weight-gradient GEMMs on the launch stream (profiling: every kernel runs alone, as in "
+                         "the roofline pass)")
     ap.add_argument("--eager-compare", action="store_true",
                     help="also time the same restatement under PyTorch-ROCm eager on this GPU (cudnn.benchmark=True as the reference "
                          "config sets it; MIOpen's kernel search makes this take 3-25 minutes, so it is opt-in)")
@@ -99,6 +102,22 @@ class _Timer(object):
 
         setattr(cls, name, timed)
         return lambda: setattr(cls, name, orig)
+
+
+def event_pair_overhead_ms(n=64):
+    """What an EMPTY HIP-event bracket reads on the launch stream (record, record, elapsed): the two event packets themselves
+    cost a few microseconds of queue time, which matters against ~100 us bf16 launches.  Median of n pairs."""
+    import torch
+    torch.cuda.synchronize()
+    pairs = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    v = sorted(a.elapsed_time(b) for a, b in pairs)
+    return v[len(v) // 2]
 
 
 def _summ(rec, per_layer, tag):
@@ -146,7 +165,7 @@ def roofline_infer(model, imgs, dtype, per_layer):
     finally:
         undo()
         model.backbone.engine().streams = streams
-    return _roof(tot, reps, dtype)
+    return _roof(tot, reps, dtype, event_pair_overhead_ms(), dtype + "_infer")
 
 
 def roofline_train(eng, imgs, labels, dtype, per_layer):
@@ -154,8 +173,8 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
     tc, tw = _Timer(), _Timer()
     esz = 4 if dtype == "f32" else 2
 
-    def dfwd(self, out, x, n, h, w, x_pitch=None, x2=None, split_c=0, ho=None, wo=None, bn=None):
-        z, ho, wo = out
+    def dfwd(self, out, d, x, x2, z, ws, part, shift):
+        n, h, w, ho, wo = d.n, d.h, d.w, d.ho, d.wo
         k_alg = 147 if self.stem else self.kh * self.kw * self.cin
         in_px = n * ho * wo if (self.kh == 1 and self.stride > 1) else n * h * w
         nbytes = esz * (in_px * (4 if self.stem else self.cin) + n * ho * wo * self.cout + self.w.numel())
@@ -171,7 +190,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * (4 if self.stem else self.cin)) + 4 * self.w.numel()
         return (2.0 * n * ho * wo * self.cout * k_alg, "wgrad M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)
 
-    undo = [tc.wrap(TE._TConv, "forward", dfwd), tc.wrap(TE._TConv, "dgrad", ddgr), tw.wrap(TE._TConv, "wgrad", dwgr)]
+    undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "dgrad", ddgr), tw.wrap(TE._TConv, "wgrad", dwgr)]
     overlap = eng.overlap_wgrad
     eng.overlap_wgrad = False          # time every kernel alone on the launch stream (the timed steps overlap wgrad on a side stream)
     try:
@@ -188,32 +207,35 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
         for u in undo:
             u()
         eng.overlap_wgrad = overlap
-    r = _roof(totc, reps, dtype)
-    w = _roof(totw, reps, dtype)
-    r["wgrad"] = {k: w[k] for k in ("bound", "achieved", "peak", "unit", "frac", "tflops", "mfma_frac", "launches_per_step", "avg_launch_us",
-                                    "flop_per_launch", "alg_bytes_per_launch", "ms_per_step")}
-    r["wgrad"]["kernel"] = "wgrad_kernel"
+    ovh = event_pair_overhead_ms()
+    r = _roof(totc, reps, dtype, ovh, dtype + "_train")
+    w = _roof(totw, reps, dtype, ovh, dtype + "_train_wgrad")
+    r["wgrad"] = {k: w[k] for k in ("traffic", "bound", "achieved", "peak", "unit", "frac", "tflops", "mfma_frac", "launches_per_step", "avg_launch_us",
+                                    "avg_launch_us_raw", "flop_per_launch", "alg_bytes_per_launch", "ms_per_step")}
+    r["wgrad"]["kernel"] = "wgrad_kernel (+ its partial-slab reduce)"
     return r
 
 
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured ceiling)
 
 
-def _roof(tot, reps, dtype):
+def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None):
     """fp32: the conv GEMMs are MFMA-bound (94 FLOP/B fused vs ~20 machine balance).  bf16: the same network is HBM-bound even
     when perfectly fused (188 FLOP/B vs ~310), so the fraction is algorithmic bytes/s over the HBM peak."""
-    ms, fl, by, n = tot
+    ms_raw, fl, by, n = tot
+    ms = max(ms_raw - n * event_overhead_ms, 1e-6)     # net of the empty-bracket reading (see event_pair_overhead_ms)
     achieved = fl / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
     traffic = None
     pmc = os.path.join(REPO, "profiles", "pmc_conv_bytes_per_launch.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(dtype)
+            traffic = json.load(open(pmc)).get(pmc_key)
         except Exception:
             traffic = None
     common = {"kernel": "conv_igemm_kernel", "traffic": traffic, "alg_bytes_per_launch": round(by / n),
-              "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2), "flop_per_launch": round(fl / n),
+              "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2), "avg_launch_us_raw": round(ms_raw * 1e3 / n, 2),
+              "event_pair_overhead_us": round(event_overhead_ms * 1e3, 2), "flop_per_launch": round(fl / n),
               "ms_per_step": round(ms / reps, 3), "tflops": round(achieved, 2), "mfma_frac": round(achieved / peak, 4)}
     if dtype == "bf16":
         gbs = by / (ms * 1e-3) / 1e9
@@ -346,6 +368,8 @@ def main():
     labels = torch.randint(0, 400, (args.clips, 1), device="cuda", generator=gen)
     if train:
         eng = model.train_engine(dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16)   # lr .015, mom .9, wd 1e-4, clip 40
+        if args.no_overlap:
+            eng.overlap_wgrad = False
         eng.dropout = 0.5
         eng.force_allreduce = dist is not None
 
