@@ -112,6 +112,9 @@ typedef struct {
     int32_t x2_pix_stride;    /*   compact MVF slice, pitch x2_pix_stride); 1x1 convs only           */
     int32_t in_dil;           /* 0/1, or s > 1: x is read as if zero-upsampled by s (data-gradient of a       */
                               /*   stride-s conv: y = dgrad needs stride == 1 here; ho,wo up to (h-1)*s+1+... ) */
+    int32_t res_c0;           /* the residual is added to output channels >= res_c0 only (multiple of 4; 0 = all).   */
+                              /*   MVF block backward: channels [0, cs) of the conv1 data gradient go through the    */
+                              /*   transposed stencil first, which adds their share (mvf_nhwc_stencil addend)        */
 } mvf_conv_desc_t;
 
 int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
@@ -208,8 +211,10 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
 int mvf_pack_conv_weight_dgrad(const float* w_oihw, int cout, int cin, int kh, int kw, void* w_packed, int dtype,
                                void* stream);
 /* MVF training primitives, channels-last (the engine composes MVF fwd/bwd from these + the BN calls above) */
+/* out[..., :cs] = f(stencil(x[..., :cs])) [+ addend[..., :cs] (pitch addend_c; NULL = none)]; flip = transposed stencil */
 int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t,
-                     const float* w_h, const float* w_w, const float* scale, const float* shift, int flip, void* stream);
+                     const float* w_h, const float* w_w, const float* scale, const float* shift, int flip,
+                     const void* addend, int addend_c, void* stream);
 size_t mvf_nhwc_tapgrad_workspace_bytes(const mvf_desc_t* d);
 int mvf_nhwc_tapgrad(const mvf_desc_t* d, const void* x, int x_c, const void* dy, int dy_c, float* dw_t, float* dw_h,
                      float* dw_w, void* ws, size_t ws_bytes, void* stream);

@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("ho", C.c_int32), ("wo", C.c_int32), ("x_pix_stride", C.c_int32),
-                ("dtype", C.c_int32), ("relu", C.c_int32), ("split_c", C.c_int32), ("x2_pix_stride", C.c_int32), ("in_dil", C.c_int32)]
+                ("dtype", C.c_int32), ("relu", C.c_int32), ("split_c", C.c_int32), ("x2_pix_stride", C.c_int32), ("in_dil", C.c_int32),
+                ("res_c0", C.c_int32)]
 
 
 def _load():
@@ -104,7 +105,7 @@ def _load():
     lib.mvf_pack_conv_weight_dgrad.restype = i32
     lib.mvf_pack_conv_weight_dgrad.argtypes = [fp, i32, i32, i32, i32, vp, i32, vp]
     lib.mvf_nhwc_stencil.restype = i32
-    lib.mvf_nhwc_stencil.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, fp, fp, i32, vp]
+    lib.mvf_nhwc_stencil.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, fp, fp, i32, vp, i32, vp]
     lib.mvf_nhwc_tapgrad_workspace_bytes.restype = sz
     lib.mvf_nhwc_tapgrad_workspace_bytes.argtypes = [dp]
     lib.mvf_nhwc_tapgrad.restype = i32

@@ -48,6 +48,7 @@ struct ConvArgs {
     char* y;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int xps, split_c, x2ps, relu;
+    int res_c0;    // residual only for output channels >= res_c0
     int dil;       // input dilation (generic fallback; the strided data-gradient is normally decomposed into parity classes)
     int pad_w;     // horizontal padding (pad = vertical)
     int w_kh0, w_kw0, w_ts, w_kwfull;   // weight tap (kh,kw) of this launch = full-pack tap (kh0 + kh*ts, kw0 + kw*ts)
@@ -497,12 +498,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 if (a.res) {
                     float4 rv;
+                    const unsigned roff = col >= a.res_c0 ? off : kOOB;       // skipped columns read zeros
                     if constexpr (sizeof(ET) == 2) {
-                        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0);
+                        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_res, roff, 0, 0);
                         rv = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
                                          __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
                     } else {
-                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
+                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0);
                         rv = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
                     }
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
@@ -826,6 +828,7 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw;
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->ho; a.Wo = d->wo; a.xps = d->x_pix_stride;
     a.split_c = d->split_c; a.x2ps = d->x2_pix_stride; a.relu = d->relu; a.dil = dil;
+    a.res_c0 = d->res_c0 > 0 ? d->res_c0 : 0;
     a.M = d->n * d->ho * d->wo;
     a.cpt = (d->cin + ce - 1) / ce;
     a.nchunks = d->kh * d->kw * a.cpt;

@@ -186,10 +186,11 @@ class _TConv(object):
             check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
         # dz / x / x2 are persistent engine buffers (eng.buf) or tensors the caller keeps alive until join_side()
 
-    def dgrad(self, dz, n, ho, wo, h, w, residual=None):
-        """dx (n*h*w, cin) from dz (n*ho*wo, cout): a conv of dz with the flipped/transposed weights."""
+    def dgrad(self, dz, n, ho, wo, h, w, residual=None, res_c0=0):
+        """dx (n*h*w, cin) from dz (n*ho*wo, cout): a conv of dz with the flipped/transposed weights (+ residual, on output
+        channels >= res_c0)."""
         d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, self.eng.dt, 0, 0, 0,
-                     self.stride if self.stride > 1 else 0)
+                     self.stride if self.stride > 1 else 0, res_c0)
         dx = self.eng.buf((id(self), "dx"), (n * h * w, self.cin))
         ws = _conv_ws(dz.device)
         check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(dx), _p(ws), ws.numel(), _st()), "conv dgrad")
@@ -221,14 +222,15 @@ class _TMvf(object):
         m = nt * h * w
         d = self.desc(nt, h, w, c)
         y = self.eng.buf((id(self), "y"), (m, self.cs))
-        check(lib.mvf_nhwc_stencil(C.byref(d), _p(x), c, _p(y), self.cs, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 0, _st()), "mvf stencil")
+        check(lib.mvf_nhwc_stencil(C.byref(d), _p(x), c, _p(y), self.cs, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 0, None, 0, _st()), "mvf stencil")
         if not self.use_hs:
             return y, y
         self.bn.stats(y, m, eng)
         return y, self.bn.apply(y, m, 2)
 
-    def backward(self, dxp, x, y, nt, h, w, c, eng):
-        """dxp (m, c): grad w.r.t. the conv input [o | x_rest]; on return its first cs channels hold the grad w.r.t. x's slice."""
+    def backward(self, dxp, x, y, nt, h, w, c, eng, addend=None):
+        """dxp (m, c): grad w.r.t. the conv input [o | x_rest]; on return its first cs channels hold the grad w.r.t. x's slice
+        (+ addend[:, :cs], the skip-connection gradient, when given: the conv epilogue added it to channels >= cs only)."""
         m = nt * h * w
         d = self.desc(nt, h, w, c)
         if self.use_hs:
@@ -241,7 +243,8 @@ class _TMvf(object):
         check(lib.mvf_nhwc_tapgrad(C.byref(d), _p(x), c, _p(dy), self.cs, _p(self.dwt), _p(dwh), _p(dww), _p(ws), ws.numel(), _st()), "mvf tapgrad")
         if self.share:   # one weight tensor serves every view (MVF.py:114-116): gradients add up
             self.dwt.view(self.cs, 3).add_(dwh.view(self.cs, 3) if self.mode & 2 else 0).add_(dww.view(self.cs, 3) if self.mode & 4 else 0)
-        check(lib.mvf_nhwc_stencil(C.byref(d), _p(dy), self.cs, _p(dxp), c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 1, _st()), "mvf stencil^T")
+        check(lib.mvf_nhwc_stencil(C.byref(d), _p(dy), self.cs, _p(dxp), c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 1,
+                                   _p(addend), c if addend is not None else 0, _st()), "mvf stencil^T")
 
 
 class _TBlock(object):
@@ -324,13 +327,16 @@ class _TBlock(object):
             dx = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid)
             self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c)
         else:
-            dxp = self.c1.dgrad(dz1, nt, h, w, h, w)
+            # skip-connection gradient without a separate add pass: the data-gradient epilogue adds it to the pass-through
+            # channels (>= cs); the slice [0, cs) first goes back through the MVF, whose transposed stencil adds its share
+            fuse = self.mvf.cs % 4 == 0
+            dxp = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid if fuse else None, res_c0=self.mvf.cs)
             if self.split_ok:
                 self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c, x2=s["o"], split_c=self.mvf.cs)
             else:
                 self.c1.wgrad(dz1, s["xin"], nt, h, w, h, w, eng, x_pitch=c)
-            self.mvf.backward(dxp, s["x"], s["y"], nt, h, w, c, eng)
-            dx = eng.add(dxp, resid, key=id(self))
+            self.mvf.backward(dxp, s["x"], s["y"], nt, h, w, c, eng, addend=resid if fuse else None)
+            dx = dxp if fuse else eng.add(dxp, resid, key=id(self))
         self.saved = None
         return dx
 
