@@ -76,14 +76,22 @@ class _BN(object):
         check(lib.mvf_bn_train_stats(_p(z), m, self.c, _p(self.gamma), _p(self.beta), C.c_float(self.eps), C.c_float(self.momentum),
                                      _p(self.mod.running_mean), _p(self.mod.running_var), _p(self.mean), _p(self.invstd), _p(self.scale),
                                      _p(self.shift), _p(ws), ws.numel(), eng.dt, _st()), "mvf_bn_train_stats")
-        self.mod.num_batches_tracked += 1
+        self._count()
 
     def finalize(self, part, nblk, m):
         """Batch statistics from the per-tile partial sums the conv epilogue produced (same K = old running mean)."""
         check(lib.mvf_bn_train_finalize(_p(part), nblk, m, self.c, _p(self.gamma), _p(self.beta), C.c_float(self.eps), C.c_float(self.momentum),
                                         _p(self.mod.running_mean), _p(self.mod.running_var), _p(self.mean), _p(self.invstd), _p(self.scale),
                                         _p(self.shift), _st()), "mvf_bn_train_finalize")
-        self.mod.num_batches_tracked += 1
+        self._count()
+
+    def _count(self):
+        """num_batches_tracked += 1 -- batched by the engine into one launch per step when it collects them (TrainEngine)."""
+        pend = getattr(self.eng, "_nbt_pending", None)
+        if pend is None:
+            self.mod.num_batches_tracked += 1
+        else:
+            pend.append(self.mod.num_batches_tracked)
 
     def apply(self, z, m, act, residual=None, rbn=None):
         out = self.eng.buf((id(self), "apply"), z.shape, z.dtype)
@@ -132,6 +140,10 @@ class _TConv(object):
         if self.wp is not self.w:
             check(lib.mvf_pack_conv_weight(_p(self.w), self.cout, self.cin, self.kh, self.kw, self.kw, self.cin, None, _p(self.wp), self.eng.dt, _st()), "pack")
         if need_dgrad:
+            self.pack_dgrad()
+
+    def pack_dgrad(self):
+        if not self.stem:
             check(lib.mvf_pack_conv_weight_dgrad(_p(self.w), self.cout, self.cin, self.kh, self.kw, _p(self.wd), self.eng.dt, _st()), "pack_dgrad")
 
     def desc(self, n, h, w, ho, wo, x_pitch, split_c=0):
@@ -237,12 +249,22 @@ class _TMvf(object):
             dy = self.bn.backward(dxp, c, y, m, eng, 3)
         else:
             dy = dxp[:, : self.cs].contiguous()
-        ws = eng.workspace(lib.mvf_nhwc_tapgrad_workspace_bytes(C.byref(d)))
+        nbytes = lib.mvf_nhwc_tapgrad_workspace_bytes(C.byref(d))
         dwh = self.dwh if self.dwh is not None else self.tmp_h
         dww = self.dww if self.dww is not None else self.tmp_w
-        check(lib.mvf_nhwc_tapgrad(C.byref(d), _p(x), c, _p(dy), self.cs, _p(self.dwt), _p(dwh), _p(dww), _p(ws), ws.numel(), _st()), "mvf tapgrad")
-        if self.share:   # one weight tensor serves every view (MVF.py:114-116): gradients add up
-            self.dwt.view(self.cs, 3).add_(dwh.view(self.cs, 3) if self.mode & 2 else 0).add_(dww.view(self.cs, 3) if self.mode & 4 else 0)
+        side = eng.side_stream() if (self.use_hs and not self.share) else None
+        if side is None:
+            ws = eng.workspace(nbytes)
+            check(lib.mvf_nhwc_tapgrad(C.byref(d), _p(x), c, _p(dy), self.cs, _p(self.dwt), _p(dwh), _p(dww), _p(ws), ws.numel(), _st()), "mvf tapgrad")
+            if self.share:   # one weight tensor serves every view (MVF.py:114-116): gradients add up
+                self.dwt.view(self.cs, 3).add_(dwh.view(self.cs, 3) if self.mode & 2 else 0).add_(dww.view(self.cs, 3) if self.mode & 4 else 0)
+        else:
+            # the tap gradients only feed the optimizer: off the critical path, on the weight-gradient stream (x and dy are
+            # persistent engine buffers, untouched until join_side())
+            side.wait_stream(eng.main_stream())
+            ws = eng.workspace(nbytes, side=True)
+            with _on_stream(side):
+                check(lib.mvf_nhwc_tapgrad(C.byref(d), _p(x), c, _p(dy), self.cs, _p(self.dwt), _p(dwh), _p(dww), _p(ws), ws.numel(), _st()), "mvf tapgrad")
         check(lib.mvf_nhwc_stencil(C.byref(d), _p(dy), self.cs, _p(dxp), c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 1,
                                    _p(addend), c if addend is not None else 0, _st()), "mvf stencil^T")
 
@@ -479,6 +501,7 @@ class TrainEngine(_ParamStore):
         self.dfc_w, self.dfc_b = self.grad_of(head.new_fc.weight), self.grad_of(head.new_fc.bias)
         self.dropout = head.dropout_ratio if head.dropout is not None else 0.0
         self.num_classes = head.num_classes
+        self._nbt_pending = []                     # BatchNorm step counters touched in this forward (see _BN._count)
 
     # ---- one step -----------------------------------------------------------------------------------------------
     def forward(self, imgs, labels, stages=None):
@@ -496,7 +519,16 @@ class TrainEngine(_ParamStore):
         self.stem.pack()
         for blk in self.blocks:
             for cv in blk.convs():
-                cv.pack()
+                cv.pack(need_dgrad=False)
+        # the data-gradient packs are not needed before backward: off the critical path, on the side stream
+        side = self.side_stream()
+        if side is not None:
+            side.wait_stream(self.main_stream())           # after the previous step's parameter update
+        with _on_stream(side if side is not None else self.main_stream()):
+            for blk in self.blocks:
+                for cv in blk.convs():
+                    cv.pack_dgrad()
+        self._packs_on_side = side is not None
         hp, wp = h + 6, (w + 6 + 2 + 1) // 2 * 2
         xp = self.buf("xp", (nt, hp, wp, 4))
         check(lib.mvf_stem_prep(_p(x), nt, 3, h, w, 3, wp, _p(xp), self.dt, _st()), "stem_prep")
@@ -534,6 +566,9 @@ class TrainEngine(_ParamStore):
         check(lib.mvf_head_train_fwd(_p(xcur), b, t, hc * wc, cc, _p(self.fc_w), _p(self.fc_b), self.num_classes, _p(lab), _p(mask), _p(pooled),
                                      _p(scores), _p(dscores), _p(loss_part), _p(loss), self.dt, _st()), "head fwd")
         self.saved.update(pooled=pooled, dscores=dscores, mask=mask, hw=hc * wc, c=cc, feat_shape=xcur.shape, scores=scores)
+        if self._nbt_pending:                     # one launch for every BatchNorm's step counter
+            torch._foreach_add_(self._nbt_pending, 1)
+            del self._nbt_pending[:]
         return loss.clone()                      # `loss` itself is a persistent buffer that the next step overwrites
 
     def backward(self):
@@ -543,6 +578,8 @@ class TrainEngine(_ParamStore):
 
     def _backward(self):
         s = self.saved
+        if getattr(self, "_packs_on_side", False):
+            self.main_stream().wait_stream(self._side)     # data-gradient weight packs (queued at the start of forward)
         nt, b, t = s["nt"], s["b"], s["t"]
         dpool = self.buf("dpool", (b, s["c"]), torch.float32)
         g = self.buf("gfeat", tuple(s["feat_shape"]))
