@@ -180,7 +180,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
         nbytes = esz * (in_px * (4 if self.stem else self.cin) + n * ho * wo * self.cout + self.w.numel())
         return (2.0 * n * ho * wo * self.cout * k_alg, "fwd   M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)
 
-    def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0):
+    def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
         fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin          # algorithmic = the forward conv's MACs
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * (2 if residual is not None else 1) + self.w.numel())
         return (fl, "dgrad M%d N%d K%d s%d" % (n * h * w, self.cin, self.kh * self.kw * self.cout, self.stride), nbytes)

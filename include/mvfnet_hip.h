@@ -124,6 +124,10 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
 size_t mvf_conv2d_workspace_bytes(const mvf_conv_desc_t* d);
 int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                            const float* bias, const void* residual, void* y, void* ws, size_t ws_bytes, void* stream);
+/* ... with the residual gated per element by sign bits ([n*ho*wo][cout/4] bytes, see mvf_bn_apply_bits); stride-1 launches */
+int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
+                                const float* bias, const void* residual, const unsigned char* res_sign_bits, void* y,
+                                void* ws, size_t ws_bytes, void* stream);
 /* Training forward: plain conv (no bias / residual / ReLU) whose epilogue also accumulates the BatchNorm batch statistics of
  * the tensor it writes: stats_part [mvf_conv2d_stats_rows(d)][cout][2] = per-tile column sums of (y-K), (y-K)^2 with
  * K = stats_shift[cout] (pass the BN's running_mean; NULL = 0).  Feed stats_part to mvf_bn_train_finalize. */
@@ -177,7 +181,8 @@ int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const floa
 int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
                  const float* rscale, const float* rshift, int act, void* out, int dtype, void* stream);
 /* gm = g * act'(.) ; dbeta = sum gm ; dgamma = sum gm * xhat.  mask_mode: 0 none, 1 ReLU via ymask > 0 (ymask = the
- * forward output), 2 ReLU via scale*z+shift > 0, 3 hard-swish'(scale*z+shift).  g rows are g_pitch apart (>= c).
+ * forward output), 2 ReLU via scale*z+shift > 0, 3 hard-swish'(scale*z+shift), 4 sign bits (see mvf_bn_apply_bits).
+ * g rows are g_pitch apart (>= c).
  * gm_out (optional, pitch c) receives gm. */
 int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* mean,
                       const float* invstd, const float* scale, const float* shift, int mask_mode, void* gm_out,
@@ -186,6 +191,17 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
 int mvf_bn_bwd_apply(const void* g, int g_pitch, const void* z, long m, int c, const float* gamma, const float* mean,
                      const float* invstd, const float* scale, const float* shift, const float* dgamma,
                      const float* dbeta, int mask_mode, void* dz, int dtype, void* stream);
+/* The same with the ReLU mask of a block output kept as SIGN BITS instead of re-reading the tensor (1/8 of its bf16 bytes):
+ * mvf_bn_apply_bits also writes sign_bits [m][c/4] bytes (bit j of byte k <=> out[.., 4k+j] > 0); mask_mode 4 of
+ * mvf_bn_bwd_reduce / mvf_bn_bwd_apply_masked takes them as ymask (mask_mode 1 there = the tensor itself).  The skip-connection
+ * gradient g*mask is then never materialised: mvf_conv2d_nhwc_fwd_resmask / mvf_nhwc_stencil gate their residual / addend
+ * with the same bits (torch autograd's relu backward, Bottleneck.forward codes/models/backbones/resnet.py:238-244). */
+int mvf_bn_apply_bits(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
+                      const float* rscale, const float* rshift, int relu, void* out, unsigned char* sign_bits, int dtype,
+                      void* stream);
+int mvf_bn_bwd_apply_masked(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* gamma,
+                            const float* mean, const float* invstd, const float* scale, const float* shift,
+                            const float* dgamma, const float* dbeta, int mask_mode, void* dz, int dtype, void* stream);
 /* stem: y = maxpool3x3/2(relu(z*scale+shift)) (resnet.py:482-484).  argmax (optional, one byte per element of y) receives
  * the window position dy*3+dx of the first maximum; the backward routes g to it: ga = dL/d relu(bn(z)). */
 int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,
@@ -211,10 +227,11 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
 int mvf_pack_conv_weight_dgrad(const float* w_oihw, int cout, int cin, int kh, int kw, void* w_packed, int dtype,
                                void* stream);
 /* MVF training primitives, channels-last (the engine composes MVF fwd/bwd from these + the BN calls above) */
-/* out[..., :cs] = f(stencil(x[..., :cs])) [+ addend[..., :cs] (pitch addend_c; NULL = none)]; flip = transposed stencil */
+/* out[..., :cs] = f(stencil(x[..., :cs])) [+ addend[..., :cs] (pitch addend_c; NULL = none), gated per channel by
+ * addend_sign_bits ([pixels][addend_c/4] bytes as written by mvf_bn_apply_bits; NULL = ungated)]; flip = transposed stencil */
 int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t,
                      const float* w_h, const float* w_w, const float* scale, const float* shift, int flip,
-                     const void* addend, int addend_c, void* stream);
+                     const void* addend, int addend_c, const unsigned char* addend_sign_bits, void* stream);
 size_t mvf_nhwc_tapgrad_workspace_bytes(const mvf_desc_t* d);
 int mvf_nhwc_tapgrad(const mvf_desc_t* d, const void* x, int x_c, const void* dy, int dy_c, float* dw_t, float* dw_h,
                      float* dw_w, void* ws, size_t ws_bytes, void* stream);

@@ -61,6 +61,8 @@ def _load():
     lib.mvf_conv2d_workspace_bytes.argtypes = [cp]
     lib.mvf_conv2d_nhwc_fwd_ws.restype = i32
     lib.mvf_conv2d_nhwc_fwd_ws.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, sz, vp]
+    lib.mvf_conv2d_nhwc_fwd_resmask.restype = i32
+    lib.mvf_conv2d_nhwc_fwd_resmask.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, vp, sz, vp]
     lib.mvf_conv2d_stats_rows.restype = i32
     lib.mvf_conv2d_stats_rows.argtypes = [cp]
     lib.mvf_conv2d_nhwc_fwd_stats.restype = i32
@@ -86,6 +88,10 @@ def _load():
     lib.mvf_bn_train_finalize.argtypes = [fp, i32, i64, i32, fp, fp, f32, f32, fp, fp, fp, fp, fp, fp, vp]
     lib.mvf_bn_apply.restype = i32
     lib.mvf_bn_apply.argtypes = [vp, i64, i32, fp, fp, vp, fp, fp, i32, vp, i32, vp]
+    lib.mvf_bn_apply_bits.restype = i32
+    lib.mvf_bn_apply_bits.argtypes = [vp, i64, i32, fp, fp, vp, fp, fp, i32, vp, vp, i32, vp]
+    lib.mvf_bn_bwd_apply_masked.restype = i32
+    lib.mvf_bn_bwd_apply_masked.argtypes = [vp, i32, vp, vp, i64, i32, fp, fp, fp, fp, fp, fp, fp, i32, vp, i32, vp]
     lib.mvf_bn_bwd_reduce.restype = i32
     lib.mvf_bn_bwd_reduce.argtypes = [vp, i32, vp, vp, i64, i32, fp, fp, fp, fp, i32, vp, fp, fp, vp, sz, i32, vp]
     lib.mvf_bn_bwd_apply.restype = i32
@@ -105,7 +111,7 @@ def _load():
     lib.mvf_pack_conv_weight_dgrad.restype = i32
     lib.mvf_pack_conv_weight_dgrad.argtypes = [fp, i32, i32, i32, i32, vp, i32, vp]
     lib.mvf_nhwc_stencil.restype = i32
-    lib.mvf_nhwc_stencil.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, fp, fp, i32, vp, i32, vp]
+    lib.mvf_nhwc_stencil.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, fp, fp, i32, vp, i32, vp, vp]
     lib.mvf_nhwc_tapgrad_workspace_bytes.restype = sz
     lib.mvf_nhwc_tapgrad_workspace_bytes.argtypes = [dp]
     lib.mvf_nhwc_tapgrad.restype = i32

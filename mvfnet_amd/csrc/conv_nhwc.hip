@@ -49,6 +49,7 @@ struct ConvArgs {
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
     int xps, split_c, x2ps, relu;
     int res_c0;    // residual only for output channels >= res_c0
+    const unsigned char* res_mask;   // optional [M][Cout/4] bytes: bit j of byte k gates residual channel 4k+j (ReLU sign bits)
     int dil;       // input dilation (generic fallback; the strided data-gradient is normally decomposed into parity classes)
     int pad_w;     // horizontal padding (pad = vertical)
     int w_kh0, w_kw0, w_ts, w_kwfull;   // weight tap (kh,kw) of this launch = full-pack tap (kh0 + kh*ts, kw0 + kw*ts)
@@ -459,6 +460,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + base), 0, nrec, 0x00020000);
         rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + base : a.y + base), 0, nrec, 0x00020000);
     }
+    // residual gate bits (contiguous outputs only): one byte per 4 channels, addressed like the output / (4 * ESZ)
+    const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.res_mask ? a.res_mask + (long)m0 * (a.Cout / 4) : (const unsigned char*)a.y), 0,
+        (unsigned)min((long)(a.M - m0) * (a.Cout / 4), 0x7ffffff0L), 0x00020000);
     (void)y; (void)res;
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
@@ -506,6 +511,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     } else {
                         const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0);
                         rv = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+                    }
+                    if (a.res_mask) {
+                        const unsigned mb = __builtin_amdgcn_raw_buffer_load_b8(rs_mask, roff == kOOB ? kOOB : roff / (4 * ESZ), 0, 0);
+                        rv.x = (mb & 1u) ? rv.x : 0.f; rv.y = (mb & 2u) ? rv.y : 0.f;
+                        rv.z = (mb & 4u) ? rv.z : 0.f; rv.w = (mb & 8u) ? rv.w : 0.f;
                     }
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                 }
@@ -775,7 +785,14 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
 
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream);
+                         void* stream, const unsigned char* res_mask = nullptr);
+
+int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
+                                const void* residual, const unsigned char* res_sign_bits, void* y, void* ws, size_t ws_bytes,
+                                void* stream) {
+    MVF_REQUIRE(!res_sign_bits || (residual && d && d->in_dil <= 1), MVF_EINVAL, "conv2d_resmask: needs a residual and a stride-1 / non-dilated launch");
+    return conv_fwd_impl(d, x, x2, w_packed, bias, residual, y, nullptr, nullptr, ws, ws_bytes, stream, res_sign_bits);
+}
 
 int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                            const float* bias, const void* residual, void* y, void* ws, size_t ws_bytes, void* stream) {
@@ -796,7 +813,7 @@ int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const voi
 
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream) {
+                         void* stream, const unsigned char* res_mask) {
     MVF_REQUIRE(d && x && w_packed && y, MVF_EINVAL, "conv2d: NULL argument");
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -829,6 +846,7 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->ho; a.Wo = d->wo; a.xps = d->x_pix_stride;
     a.split_c = d->split_c; a.x2ps = d->x2_pix_stride; a.relu = d->relu; a.dil = dil;
     a.res_c0 = d->res_c0 > 0 ? d->res_c0 : 0;
+    a.res_mask = res_mask;
     a.M = d->n * d->ho * d->wo;
     a.cpt = (d->cin + ce - 1) / ce;
     a.nchunks = d->kh * d->kw * a.cpt;

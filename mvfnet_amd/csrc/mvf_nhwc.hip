@@ -35,6 +35,7 @@ struct NhwcArgs {
     int flip;      // use taps reversed (transposed stencil: the data-gradient of the views)
     const void* add;   // optional addend (same pixels, channel pitch add_c), added after the activation
     int add_c;
+    const unsigned char* add_mask;   // optional gate bits of the addend: [pixels][add_c/4] bytes, bit j of byte k = channel 4k+j
 };
 
 template <typename ET, int VEC>
@@ -115,9 +116,12 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply(NhwcArgs a) {
             }
             if (a.add) {
                 float ad[VEC];
-                Vec<ET, VEC>::load(reinterpret_cast<const ET*>(a.add) + (((long)n * T + t) * HW + pix) * a.add_c + c0, ad);
+                const long apix = ((long)n * T + t) * HW + pix;
+                Vec<ET, VEC>::load(reinterpret_cast<const ET*>(a.add) + apix * a.add_c + c0, ad);
+                unsigned mb = 0xfu;
+                if (a.add_mask) mb = a.add_mask[apix * (a.add_c / 4) + c0 / 4] >> (c0 & 3);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) y[i] += ad[i];
+                for (int i = 0; i < VEC; ++i) y[i] += ((mb >> i) & 1u) ? ad[i] : 0.f;
             }
             Vec<ET, VEC>::store(out + o0 + (long)t * HW * a.out_c, y);
 #pragma unroll
@@ -146,7 +150,7 @@ __global__ void copy_tail_nhwc(const ET* src, ET* dst, long npix, int c, int cs)
 size_t mvf_nhwc_ws_fwd_train(const mvf_desc_t*) { return 256; }
 size_t mvf_nhwc_ws_bwd(const mvf_desc_t*) { return 256; }
 
-struct NhwcFlip { int flip; const void* add; int add_c; };
+struct NhwcFlip { int flip; const void* add; int add_c; const unsigned char* add_mask; };
 int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
                              const float* ww, const float* scale, const float* shift, NhwcFlip fl, hipStream_t st) {
     // In-place hazard: a workgroup re-reads neighbour pixels that another workgroup may already have overwritten.
@@ -161,6 +165,7 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     a.flip = fl.flip;
     a.add = fl.add;
     a.add_c = fl.add_c;
+    a.add_mask = fl.add_mask;
     const int esz = d->dtype == MVF_F32 ? 4 : 2;
     const bool vec = (d->cs % 4 == 0) && (d->c % 4 == 0) && (out_c % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % (4 * esz) == 0) &&
                      (!fl.add || (fl.add_c % 4 == 0 && (uintptr_t)fl.add % (4 * esz) == 0));
@@ -198,7 +203,7 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
 
 int mvf_nhwc_fwd_infer_impl(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
                             const float* ww, const float* scale, const float* shift, hipStream_t st) {
-    NhwcFlip f = {0, nullptr, 0};
+    NhwcFlip f = {0, nullptr, 0, nullptr};
     return mvf_nhwc_fwd_infer_impl2(d, x, out, out_c, wt, wh, ww, scale, shift, f, st);
 }
 
@@ -313,12 +318,13 @@ extern "C" {
 // i.e. the data-gradient of the three views).  x and out must not alias.
 int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
                      const float* w_w, const float* scale, const float* shift, int flip, const void* addend, int addend_c,
-                     void* stream) {
+                     const unsigned char* addend_sign_bits, void* stream) {
     MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs, MVF_EINVAL, "nhwc_stencil: bad argument");
     MVF_REQUIRE(!addend || addend_c >= d->cs, MVF_EINVAL, "nhwc_stencil: addend pitch < cs");
+    MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil: gate bits need an addend with pitch % 4 == 0");
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {flip, addend, addend_c};
+    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits};
     return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, scale, shift, f, (hipStream_t)stream);
 }
 

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(int C, int nblk,
 // Column-tiled: a lane owns VN channels (its scale/shift live in registers) and walks rows; no per-element index math.
 template <typename ET, int VN>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const ET* z, long M, int C, const float* scale, const float* shift, const ET* r,
-                                                            const float* rscale, const float* rshift, int act, ET* out, int cqb, int rows) {
+                                                            const float* rscale, const float* rshift, int act, ET* out,
+                                                            unsigned char* bits, int cqb, int rows) {
     const int rl = kThreads / cqb;
     const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
     if (cq * VN >= C) return;
@@ -259,6 +260,13 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const ET* z, long M,
             v[j] = t;
         }
         stv<ET, VN>(out + row * C + c, v);
+        if (bits) {                                         // sign bits of the result, one byte per 4 channels: [M][C/4]
+            unsigned mb = 0;
+#pragma unroll
+            for (int j = 0; j < VN; ++j) mb |= (v[j] > 0.f ? 1u : 0u) << (j + (j >= 4 ? 4 : 0));
+            if constexpr (VN == 8) *reinterpret_cast<unsigned short*>(bits + row * (C / 4) + c / 4) = (unsigned short)mb;
+            else bits[row * (C / 4) + c / 4] = (unsigned char)mb;
+        }
     };
     long row = r0 + lane_r;
     for (; row + rl < r1; row += 2 * rl) {                  // two rows per trip: 2-4 independent loads in flight per lane
@@ -280,17 +288,27 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const ET* z, long M,
     }
 }
 
-// ---- BN backward reductions: gm = g * mask ; sums of gm and gm*xhat.  mask from y>0 (block output) or from
-// ---- scale*z+shift > 0 (recomputed ReLU of this BN's own output) or none.  Optionally writes gm. ----
+// ---- BN backward reductions: gm = g * mask ; sums of gm and gm*xhat.  mask from y>0 (block output, mode 1), from its sign
+// ---- bits (mode 4, ymask = the [M][C/4] bytes bn_apply wrote), from scale*z+shift > 0 (recomputed ReLU of this BN's own
+// ---- output, mode 2), hard-swish' (mode 3) or none.  Optionally writes gm. ----
+// mb: mask bits of the lane's channels in the [M][C/4]-byte layout (bit j of byte j/4 -> bit j + 4*(j/4) of mb), mask_mode 4
 template <typename ET, int VN>
 __device__ __forceinline__ void bn_mask(float (&gv)[VN], const float (&zv)[VN], const float (&yv)[VN], const float (&sc)[VN],
-                                        const float (&sh)[VN], int mask_mode) {
+                                        const float (&sh)[VN], int mask_mode, unsigned mb = 0u) {
 #pragma unroll
     for (int j = 0; j < VN; ++j) {
-        if (mask_mode == 1) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+        if (mask_mode == 4) gv[j] = ((mb >> (j + (j >= 4 ? 4 : 0))) & 1u) ? gv[j] : 0.f;
+        else if (mask_mode == 1) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
         else if (mask_mode == 2) gv[j] = (zv[j] * sc[j] + sh[j]) > 0.f ? gv[j] : 0.f;
         else if (mask_mode == 3) gv[j] *= hswish_grad_f(zv[j] * sc[j] + sh[j]);   // MVF: o = hswish(bn(y))
     }
+}
+
+template <int VN>
+__device__ __forceinline__ unsigned ld_maskbits(const void* bits, long row, int C, int c) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(bits) + row * (C / 4) + c / 4;
+    if constexpr (VN == 8) return *reinterpret_cast<const unsigned short*>(p);
+    else return *p;
 }
 
 template <typename ET, int VN>
@@ -316,8 +334,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const ET* g, in
     }
     const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
     if (ok) {
-        auto body = [&](long r, float (&gv)[VN], const float (&zv)[VN], const float (&yv)[VN]) {
-            bn_mask<ET, VN>(gv, zv, yv, sc, sh, mask_mode);
+        auto body = [&](long r, float (&gv)[VN], const float (&zv)[VN], const float (&yv)[VN], unsigned mb) {
+            bn_mask<ET, VN>(gv, zv, yv, sc, sh, mask_mode, mb);
             if (gm_out) stv<ET, VN>(gm_out + r * C + c, gv);
 #pragma unroll
             for (int j = 0; j < VN; ++j) {
@@ -330,16 +348,18 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const ET* g, in
             float g0[VN], g1[VN], z0[VN], z1[VN], y0[VN], y1[VN];
             ldv<ET, VN>(g + r * g_pitch + c, g0); ldv<ET, VN>(g + (r + rl) * g_pitch + c, g1);
             ldv<ET, VN>(z + r * C + c, z0); ldv<ET, VN>(z + (r + rl) * C + c, z1);
+            unsigned m0 = 0u, m1 = 0u;
             if (mask_mode == 1) { ldv<ET, VN>(ymask + r * C + c, y0); ldv<ET, VN>(ymask + (r + rl) * C + c, y1); }
-            body(r, g0, z0, y0);
-            body(r + rl, g1, z1, y1);
+            if (mask_mode == 4) { m0 = ld_maskbits<VN>(ymask, r, C, c); m1 = ld_maskbits<VN>(ymask, r + rl, C, c); }
+            body(r, g0, z0, y0, m0);
+            body(r + rl, g1, z1, y1, m1);
         }
         for (; r < r1; r += rl) {
             float g0[VN], z0[VN], y0[VN];
             ldv<ET, VN>(g + r * g_pitch + c, g0);
             ldv<ET, VN>(z + r * C + c, z0);
             if (mask_mode == 1) ldv<ET, VN>(ymask + r * C + c, y0);
-            body(r, g0, z0, y0);
+            body(r, g0, z0, y0, mask_mode == 4 ? ld_maskbits<VN>(ymask, r, C, c) : 0u);
         }
     }
     rowlane_reduce<VN>(s1, s2, cqb, rl, red);
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nblk, c
 // dz = gamma*invstd * (gm - dbeta/M - xhat*dgamma/M); gm = g*mask recomputed as above (mask_mode 0: g is already masked)
 // Column-tiled like bn_apply_kernel: the six per-channel coefficients are folded once per lane into registers.
 template <typename ET, int VN>
-__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const ET* g, int g_pitch, const ET* z, long M, int C, const float* gamma,
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const ET* g, int g_pitch, const ET* z, const ET* ymask, long M, int C, const float* gamma,
                                                                 const float* mean, const float* invstd, const float* scale,
                                                                 const float* shift, const float* dgamma, const float* dbeta,
                                                                 int mask_mode, ET* dz, int cqb, int rows) {
@@ -386,7 +406,13 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const ET* g, int
     }
     const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
     auto one = [&](long row, float (&gv)[VN], const float (&zv)[VN]) {
-        bn_mask<ET, VN>(gv, zv, zv, sc, sh, mask_mode == 1 ? 0 : mask_mode);
+        if (mask_mode == 1) {
+            float yv[VN];
+            ldv<ET, VN>(ymask + row * C + c, yv);
+            bn_mask<ET, VN>(gv, zv, yv, sc, sh, 1);
+        } else {
+            bn_mask<ET, VN>(gv, zv, zv, sc, sh, mask_mode, mask_mode == 4 ? ld_maskbits<VN>(ymask, row, C, c) : 0u);
+        }
 #pragma unroll
         for (int j = 0; j < VN; ++j) gv[j] = a[j] * (gv[j] - d0[j] - (zv[j] - mu[j]) * kx[j]);
         stv<ET, VN>(dz + row * C + c, gv);
@@ -659,22 +685,31 @@ int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const floa
     return MVF_OK;
 }
 
-int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
-                 const float* rscale, const float* rshift, int relu, void* out, int dtype, void* stream) {
+int mvf_bn_apply_bits(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
+                      const float* rscale, const float* rshift, int relu, void* out, unsigned char* sign_bits, int dtype,
+                      void* stream) {
     MVF_REQUIRE(z && scale && shift && out && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_apply: bad argument");
     MVF_REQUIRE((rscale == nullptr) == (rshift == nullptr), MVF_EINVAL, "bn_apply: rscale/rshift must come together");
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = c % 8 == 0 && al16(z) && al16(out) && al16(residual);
-    MVF_BN_DISPATCH(bn_apply_kernel, wide, 4096, (const ET*)z, m, c, scale, shift, (const ET*)residual, rscale, rshift, relu, (ET*)out, p.cqb, p.rows);
+    const bool wide = c % 8 == 0 && al16(z) && al16(out) && al16(residual) && ((uintptr_t)sign_bits & 1) == 0;
+    MVF_BN_DISPATCH(bn_apply_kernel, wide, 4096, (const ET*)z, m, c, scale, shift, (const ET*)residual, rscale, rshift, relu, (ET*)out, sign_bits,
+                    p.cqb, p.rows);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
+}
+
+int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
+                 const float* rscale, const float* rshift, int relu, void* out, int dtype, void* stream) {
+    return mvf_bn_apply_bits(z, m, c, scale, shift, residual, rscale, rshift, relu, out, nullptr, dtype, stream);
 }
 
 int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* mean, const float* invstd,
                       const float* scale, const float* shift, int mask_mode, void* gm_out, float* dgamma, float* dbeta,
                       void* ws, size_t ws_bytes, int dtype, void* stream) {
     MVF_REQUIRE(g && z && mean && invstd && dgamma && dbeta && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_bwd_reduce: bad argument");
-    MVF_REQUIRE(mask_mode >= 0 && mask_mode <= 3 && (mask_mode != 1 || ymask) && (mask_mode < 2 || (scale && shift)) && g_pitch >= c && g_pitch % 4 == 0, MVF_EINVAL, "bn_bwd_reduce: bad mask_mode / pitch");
+    MVF_REQUIRE(mask_mode >= 0 && mask_mode <= 4 && ((mask_mode != 1 && mask_mode != 4) || ymask) &&
+                    ((mask_mode != 2 && mask_mode != 3) || (scale && shift)) && g_pitch >= c && g_pitch % 4 == 0,
+                MVF_EINVAL, "bn_bwd_reduce: bad mask_mode / pitch");
     MVF_REQUIRE(ws && ws_bytes >= mvf_bn_workspace_bytes(m, c), MVF_EWS, "bn_bwd_reduce: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)ws;
@@ -687,16 +722,27 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
     return MVF_OK;
 }
 
+int mvf_bn_bwd_apply_masked(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* gamma,
+                            const float* mean, const float* invstd, const float* scale, const float* shift, const float* dgamma,
+                            const float* dbeta, int mask_mode, void* dz, int dtype, void* stream) {
+    MVF_REQUIRE(g && z && gamma && mean && invstd && dgamma && dbeta && dz && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_bwd_apply: bad argument");
+    MVF_REQUIRE(mask_mode >= 0 && mask_mode <= 4 && ((mask_mode != 1 && mask_mode != 4) || ymask) &&
+                    ((mask_mode != 2 && mask_mode != 3) || (scale && shift)) && g_pitch >= c && g_pitch % 4 == 0,
+                MVF_EINVAL, "bn_bwd_apply: bad mask_mode / pitch");
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = c % 8 == 0 && g_pitch % 8 == 0 && al16(g) && al16(z) && al16(dz) && (mask_mode != 1 || al16(ymask)) &&
+                      (mask_mode != 4 || ((uintptr_t)ymask & 1) == 0);
+    MVF_BN_DISPATCH(bn_bwd_apply_kernel, wide, 4096, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, gamma, mean, invstd, scale, shift,
+                    dgamma, dbeta, mask_mode, (ET*)dz, p.cqb, p.rows);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
 int mvf_bn_bwd_apply(const void* g, int g_pitch, const void* z, long m, int c, const float* gamma, const float* mean, const float* invstd,
                      const float* scale, const float* shift, const float* dgamma, const float* dbeta, int mask_mode, void* dz,
                      int dtype, void* stream) {
-    MVF_REQUIRE(g && z && gamma && mean && invstd && dgamma && dbeta && dz && m > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "bn_bwd_apply: bad argument");
-    MVF_REQUIRE((mask_mode == 0 || ((mask_mode == 2 || mask_mode == 3) && scale && shift)) && g_pitch >= c && g_pitch % 4 == 0, MVF_EINVAL, "bn_bwd_apply: mask_mode must be 0, 2 or 3");
-    hipStream_t st = (hipStream_t)stream;
-    const bool wide = c % 8 == 0 && g_pitch % 8 == 0 && al16(g) && al16(z) && al16(dz);
-    MVF_BN_DISPATCH(bn_bwd_apply_kernel, wide, 4096, (const ET*)g, g_pitch, (const ET*)z, m, c, gamma, mean, invstd, scale, shift, dgamma, dbeta, mask_mode, (ET*)dz, p.cqb, p.rows);
-    MVF_LAUNCH_CHECK();
-    return MVF_OK;
+    MVF_REQUIRE(mask_mode == 0 || mask_mode == 2 || mask_mode == 3, MVF_EINVAL, "bn_bwd_apply: mask_mode must be 0, 2 or 3 (use mvf_bn_bwd_apply_masked)");
+    return mvf_bn_bwd_apply_masked(g, g_pitch, z, nullptr, m, c, gamma, mean, invstd, scale, shift, dgamma, dbeta, mask_mode, dz, dtype, stream);
 }
 
 int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,

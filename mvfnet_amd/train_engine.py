@@ -93,11 +93,13 @@ class _BN(object):
         else:
             pend.append(self.mod.num_batches_tracked)
 
-    def apply(self, z, m, act, residual=None, rbn=None):
+    def apply(self, z, m, act, residual=None, rbn=None, bits=False):
+        """out = act(bn(z) [+ residual]); bits=True also keeps the sign bits of out ([m][c/4] bytes) for the backward masks."""
         out = self.eng.buf((id(self), "apply"), z.shape, z.dtype)
-        check(lib.mvf_bn_apply(_p(z), m, self.c, _p(self.scale), _p(self.shift), _p(residual), _p(rbn.scale if rbn else None),
-                               _p(rbn.shift if rbn else None), act, _p(out), self.eng.dt, _st()), "mvf_bn_apply")
-        return out
+        sb = self.eng.buf((id(self), "bits"), (m, self.c // 4), torch.uint8) if bits else None
+        check(lib.mvf_bn_apply_bits(_p(z), m, self.c, _p(self.scale), _p(self.shift), _p(residual), _p(rbn.scale if rbn else None),
+                                    _p(rbn.shift if rbn else None), act, _p(out), _p(sb), self.eng.dt, _st()), "mvf_bn_apply")
+        return (out, sb) if bits else out
 
     def backward(self, g, g_pitch, z, m, eng, mask_mode, ymask=None, gm_out=None):
         """dgamma/dbeta into the flat grad buffer; returns dz."""
@@ -105,10 +107,11 @@ class _BN(object):
         check(lib.mvf_bn_bwd_reduce(_p(g), g_pitch, _p(z), _p(ymask), m, self.c, _p(self.mean), _p(self.invstd), _p(self.scale),
                                     _p(self.shift), mask_mode, _p(gm_out), _p(self.dgamma), _p(self.dbeta), _p(ws), ws.numel(), eng.dt, _st()),
               "mvf_bn_bwd_reduce")
-        src, pitch, mode = (gm_out, self.c, 0) if gm_out is not None else (g, g_pitch, mask_mode if mask_mode != 1 else 0)
+        src, pitch, mode = (gm_out, self.c, 0) if gm_out is not None else (g, g_pitch, mask_mode)
         dz = eng.buf((id(self), "dz"), z.shape, z.dtype)
-        check(lib.mvf_bn_bwd_apply(_p(src), pitch, _p(z), m, self.c, _p(self.gamma), _p(self.mean), _p(self.invstd), _p(self.scale),
-                                   _p(self.shift), _p(self.dgamma), _p(self.dbeta), mode, _p(dz), eng.dt, _st()), "mvf_bn_bwd_apply")
+        check(lib.mvf_bn_bwd_apply_masked(_p(src), pitch, _p(z), _p(ymask) if mode in (1, 4) else None, m, self.c, _p(self.gamma), _p(self.mean),
+                                          _p(self.invstd), _p(self.scale), _p(self.shift), _p(self.dgamma), _p(self.dbeta), mode, _p(dz), eng.dt,
+                                          _st()), "mvf_bn_bwd_apply")
         return dz
 
 
@@ -198,14 +201,15 @@ class _TConv(object):
             check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
         # dz / x / x2 are persistent engine buffers (eng.buf) or tensors the caller keeps alive until join_side()
 
-    def dgrad(self, dz, n, ho, wo, h, w, residual=None, res_c0=0):
+    def dgrad(self, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
         """dx (n*h*w, cin) from dz (n*ho*wo, cout): a conv of dz with the flipped/transposed weights (+ residual, on output
-        channels >= res_c0)."""
+        channels >= res_c0, gated per element by the sign bits res_bits when given)."""
         d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, self.eng.dt, 0, 0, 0,
                      self.stride if self.stride > 1 else 0, res_c0)
         dx = self.eng.buf((id(self), "dx"), (n * h * w, self.cin))
         ws = _conv_ws(dz.device)
-        check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(dx), _p(ws), ws.numel(), _st()), "conv dgrad")
+        check(lib.mvf_conv2d_nhwc_fwd_resmask(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(res_bits), _p(dx), _p(ws), ws.numel(),
+                                              _st()), "conv dgrad")
         return dx
 
 
@@ -234,13 +238,13 @@ class _TMvf(object):
         m = nt * h * w
         d = self.desc(nt, h, w, c)
         y = self.eng.buf((id(self), "y"), (m, self.cs))
-        check(lib.mvf_nhwc_stencil(C.byref(d), _p(x), c, _p(y), self.cs, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 0, None, 0, _st()), "mvf stencil")
+        check(lib.mvf_nhwc_stencil(C.byref(d), _p(x), c, _p(y), self.cs, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 0, None, 0, None, _st()), "mvf stencil")
         if not self.use_hs:
             return y, y
         self.bn.stats(y, m, eng)
         return y, self.bn.apply(y, m, 2)
 
-    def backward(self, dxp, x, y, nt, h, w, c, eng, addend=None):
+    def backward(self, dxp, x, y, nt, h, w, c, eng, addend=None, addend_bits=None):
         """dxp (m, c): grad w.r.t. the conv input [o | x_rest]; on return its first cs channels hold the grad w.r.t. x's slice
         (+ addend[:, :cs], the skip-connection gradient, when given: the conv epilogue added it to channels >= cs only)."""
         m = nt * h * w
@@ -266,7 +270,7 @@ class _TMvf(object):
             with _on_stream(side):
                 check(lib.mvf_nhwc_tapgrad(C.byref(d), _p(x), c, _p(dy), self.cs, _p(self.dwt), _p(dwh), _p(dww), _p(ws), ws.numel(), _st()), "mvf tapgrad")
         check(lib.mvf_nhwc_stencil(C.byref(d), _p(dy), self.cs, _p(dxp), c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 1,
-                                   _p(addend), c if addend is not None else 0, _st()), "mvf stencil^T")
+                                   _p(addend), c if addend is not None else 0, _p(addend_bits), _st()), "mvf stencil^T")
 
 
 class _TBlock(object):
@@ -311,11 +315,11 @@ class _TBlock(object):
         z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3)
         if self.cd is not None:
             zd, _, _ = self.cd.forward(x, nt, h, w, bn=self.bd)
-            out = self.b3.apply(z3, m2, 1, residual=zd, rbn=self.bd)
+            out, bits = self.b3.apply(z3, m2, 1, residual=zd, rbn=self.bd, bits=True)
             s["zd"] = zd
         else:
-            out = self.b3.apply(z3, m2, 1, residual=x)
-        s.update(z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, out=out, ho=ho, wo=wo)
+            out, bits = self.b3.apply(z3, m2, 1, residual=x, bits=True)
+        s.update(z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, out=out, bits=bits, ho=ho, wo=wo)
         self.saved = s
         return out, ho, wo, self.c3.cout
 
@@ -323,12 +327,12 @@ class _TBlock(object):
         s = self.saved
         h, w, c, ho, wo = s["h"], s["w"], s["c"], s["ho"], s["wo"]
         m, m2 = nt * h * w, nt * ho * wo
-        gm = eng.buf((id(self), "gm"), g.shape, g.dtype)
+        bits = s["bits"]       # sign bits of the block output: the ReLU mask of g, applied wherever g is consumed (never materialised)
         # Order matters for the two-stream overlap: each weight-gradient GEMM is queued on the side stream AFTER the
         # data-gradient GEMM that shares its dz has been queued on the main stream, so it starts when the main stream
         # moves on to the (HBM-bound) BatchNorm-backward kernels of the next layer -- MFMA work under memory work --
         # instead of fighting the data-gradient GEMM for the matrix cores.
-        dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 1, ymask=s["out"], gm_out=gm)
+        dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 4, ymask=bits)
         da2 = self.c3.dgrad(dz3, nt, ho, wo, ho, wo)
         self.c3.wgrad(dz3, s["a2"], nt, ho, wo, ho, wo, eng)
         del dz3
@@ -339,26 +343,31 @@ class _TBlock(object):
         del dz2
         dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2)
         del da1
-        resid = gm
+        resid, rbits = g, bits
         if self.cd is not None:
-            dzd = self.bd.backward(gm, self.cd.cout, s["zd"], m2, eng, 0)
-            resid = self.cd.dgrad(dzd, nt, ho, wo, h, w)
+            dzd = self.bd.backward(g, self.cd.cout, s["zd"], m2, eng, 4, ymask=bits)
+            resid, rbits = self.cd.dgrad(dzd, nt, ho, wo, h, w), None
             self.cd.wgrad(dzd, s["x"], nt, h, w, ho, wo, eng, x_pitch=c)
             del dzd
         if self.mvf is None:
-            dx = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid)
+            dx = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid, res_bits=rbits)
             self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c)
         else:
             # skip-connection gradient without a separate add pass: the data-gradient epilogue adds it to the pass-through
             # channels (>= cs); the slice [0, cs) first goes back through the MVF, whose transposed stencil adds its share
             fuse = self.mvf.cs % 4 == 0
-            dxp = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid if fuse else None, res_c0=self.mvf.cs)
+            dxp = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid if fuse else None, res_c0=self.mvf.cs, res_bits=rbits if fuse else None)
             if self.split_ok:
                 self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c, x2=s["o"], split_c=self.mvf.cs)
             else:
                 self.c1.wgrad(dz1, s["xin"], nt, h, w, h, w, eng, x_pitch=c)
-            self.mvf.backward(dxp, s["x"], s["y"], nt, h, w, c, eng, addend=resid if fuse else None)
-            dx = dxp if fuse else eng.add(dxp, resid, key=id(self))
+            self.mvf.backward(dxp, s["x"], s["y"], nt, h, w, c, eng, addend=resid if fuse else None, addend_bits=rbits if fuse else None)
+            if not fuse:
+                if rbits is not None:       # odd slice widths: materialise g * mask once
+                    resid = resid * (s["out"] > 0).to(resid.dtype)
+                dx = eng.add(dxp, resid, key=id(self))
+            else:
+                dx = dxp
         self.saved = None
         return dx
 
