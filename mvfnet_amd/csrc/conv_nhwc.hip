@@ -570,7 +570,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
     conv_tile<ET, WM, WN, TM, TN>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
-// generic fallback (conv_tile GEN): input dilation or images too large for 32-bit tile-relative offsets
+// generic fallback (conv_tile GEN): input dilation, kernels wider than the 32-bit tap masks, or images too large for 32-bit
+// tile-relative offsets
 template <typename ET, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(kThreads) void conv_igemm_gen_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -659,14 +660,17 @@ struct SkHost {
     size_t ws_bytes;
 };
 
-bool g_lowk_enabled = true;      // A/B switch for experiments (MVF_CONV_LOWK=0 disables)
+// Launches with at most this many K chunks use the single-LDS-buffer variant (MVF_CONV_LOWK=n; 0 disables).  Measured on the
+// R50 train step: the 36 KB variant (3-4 workgroups per CU) beats the double-buffered 72 KB one (2 per CU) at EVERY K, bf16 and
+// fp32 -- occupancy hides more latency than the second buffer does (bf16 27.97 -> 26.96 ms, fp32 83.0 -> 79.6 ms per step).
+int g_lowk_max_chunks = 1 << 30;
 int g_pf2_mode = 1;              // two-chunk register prefetch: 0 off, 1 bf16 only, 2 both dtypes (MVF_CONV_PF2)
 
 int sk_slots() {
     static int slots = 0;
     if (!slots) {
         const char* e = getenv("MVF_CONV_LOWK");
-        if (e && e[0] == '0') g_lowk_enabled = false;
+        if (e && e[0] >= '0' && e[0] <= '9') g_lowk_max_chunks = atoi(e);
         e = getenv("MVF_CONV_PF2");
         if (e && e[0] >= '0' && e[0] <= '2') g_pf2_mode = e[0] - '0';
         int dev = 0, cus = 256;
@@ -708,7 +712,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     // the epilogue addresses the output the same way (only a scattered data-gradient class can span whole images)
     MVF_REQUIRE(a.o_s <= 0 || (long)a.o_hfull * a.o_wfull * a.Cout * (long)sizeof(ET) * span_imgs < 0x7ffffff0L, MVF_EUNSUPPORTED,
                 "conv2d: output image too large for tile-relative 32-bit addressing");
-    if (a.dil > 1 || img_bytes * span_imgs >= 0x7ffffff0L || (long)a.Cout * a.wK * (long)sizeof(ET) >= 0x7ffffff0L) {
+    if (a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L || (long)a.Cout * a.wK * (long)sizeof(ET) >= 0x7ffffff0L) {
         auto kern_gen = conv_igemm_gen_kernel<ET, WM, WN, TM, TN>;
         static bool gen_attr = false;
         if (!gen_attr) {
@@ -735,7 +739,16 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
-    if (a.nchunks <= 2 && g_lowk_enabled) {      // HBM-bound small-K conv: half the LDS, 3-4 workgroups per CU
+    // stream-K (double-buffered kernel + a cut last wave) keeps the launches where its cost model says it pays: long-K fp32
+    // convs with a mostly empty last tile wave (+2 % on fp32 inference); everything else takes the single-buffer variant
+    bool sk_wins = false;
+    {
+        const int full0 = tiles / slots * slots, tail0 = tiles - full0;
+        const float wave_us0 = a.nchunks * (sizeof(ET) == 4 ? 3.9f : 1.0f);
+        sk_wins = skh.ws && skh.ws_bytes >= sk_ws_bytes() && tail0 > 0 && (long)tail0 * a.nchunks >= slots &&
+                  (1.0f - (float)tail0 / slots) * wave_us0 > 60.0f;
+    }
+    if (a.nchunks <= g_lowk_max_chunks && !sk_wins) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         hipLaunchKernelGGL(kern_lk, dim3(tiles), dim3(kThreads), lds / 2, st, a);
         MVF_LAUNCH_CHECK();
         return MVF_OK;

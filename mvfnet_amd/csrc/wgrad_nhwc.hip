@@ -469,7 +469,8 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
         else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
         else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
     } else if (d->cin % 8 == 0 && d->cout % 8 == 0 && d->x_pix_stride % 4 == 0 && (d->split_c % 8) == 0 &&
-               ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0) {
+               ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
+               ((long)a.rows_per_split + 6 * 64) * d->cout * 2 < 0x7ffffff0L) {      // 32-bit split-relative dz offsets (incl. look-ahead chunks)
         int rc;
         if (t.bco == 64) rc = launch_wgrad_bf16<1, 2>(a, tiles, nsplit, st);
         else if (t.bk == 64) rc = launch_wgrad_bf16<2, 1>(a, tiles, nsplit, st);
