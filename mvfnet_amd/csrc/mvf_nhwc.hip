@@ -147,9 +147,6 @@ __global__ void copy_tail_nhwc(const ET* src, ET* dst, long npix, int c, int cs)
 
 }  // namespace
 
-size_t mvf_nhwc_ws_fwd_train(const mvf_desc_t*) { return 256; }
-size_t mvf_nhwc_ws_bwd(const mvf_desc_t*) { return 256; }
-
 struct NhwcFlip { int flip; const void* add; int add_c; const unsigned char* add_mask; };
 int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
                              const float* ww, const float* scale, const float* shift, NhwcFlip fl, hipStream_t st) {
@@ -212,17 +209,104 @@ int mvf_nhwc_fwd_infer(const mvf_desc_t* d, const void* x, void* out, const floa
     return mvf_nhwc_fwd_infer_impl(d, x, out, d->c, wt, wh, ww, scale, shift, st);
 }
 
-int mvf_nhwc_fwd_train(const mvf_desc_t*, const void*, void*, const float*, const float*, const float*, const float*,
-                       const float*, float, float, float*, float*, float*, float*, void*, hipStream_t) {
-    mvf_set_error("mvf_fwd_train: NHWC layout not implemented yet (use MVF_NCHW)");
-    return MVF_EUNSUPPORTED;
+// ---- channels-last training entry points: composed from the engine's primitives (same arithmetic as the NCHW kernels) ----
+namespace {
+struct NhwcTrainWs {            // byte offsets into the caller's workspace
+    size_t y, dz, coef, bn, tap, total;
+};
+NhwcTrainWs nhwc_train_ws(const mvf_desc_t* d) {
+    const size_t esz = d->dtype == MVF_F32 ? 4 : 2;
+    const size_t m = (size_t)d->nt * d->h * d->w;
+    NhwcTrainWs w;
+    size_t o = 0;
+    w.y = o;    o += align_up(m * d->cs * esz, 256);
+    w.dz = o;   o += align_up(m * d->cs * esz, 256);
+    w.coef = o; o += align_up((size_t)4 * d->cs * sizeof(float), 256);      // scale, shift, zero dgamma, zero dbeta
+    w.bn = o;   o += align_up(mvf_bn_workspace_bytes((long)m, d->cs), 256);
+    w.tap = o;  o += align_up(mvf_nhwc_tapgrad_workspace_bytes(d), 256);
+    w.total = o;
+    return w;
+}
+__global__ void bn_coef_kernel(const float* gamma, const float* beta, const float* mean, const float* invstd, int c, float* coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float s = gamma[i] * invstd[i];
+    coef[i] = s;                       // scale
+    coef[c + i] = beta[i] - mean[i] * s;   // shift
+    coef[2 * c + i] = 0.f;             // zero dgamma / dbeta for the eval-mode (no batch-statistics term) apply
+    coef[3 * c + i] = 0.f;
+}
+}  // namespace
+
+size_t mvf_nhwc_ws_fwd_train(const mvf_desc_t* d) { return d->cs % 4 ? 256 : nhwc_train_ws(d).total; }
+size_t mvf_nhwc_ws_bwd(const mvf_desc_t* d) { return d->cs % 4 ? 256 : nhwc_train_ws(d).total; }
+
+int mvf_nhwc_fwd_train(const mvf_desc_t* d, const void* x, void* out, const float* wt, const float* wh, const float* ww,
+                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                       float* save_mean, float* save_invstd, void* ws, hipStream_t st) {
+    MVF_REQUIRE(d->cs % 4 == 0 && d->c % 4 == 0, MVF_EUNSUPPORTED, "mvf_fwd_train(NHWC): needs cs %% 4 == 0 and c %% 4 == 0 (use MVF_NCHW)");
+    const NhwcTrainWs w = nhwc_train_ws(d);
+    char* base = (char*)ws;
+    const long m = (long)d->nt * d->h * d->w;
+    float* scale = (float*)(base + w.coef);
+    float* shift = scale + d->cs;
+    // pass 1: y = stencil(x) (compact slice) -> batch statistics (and the folded scale / shift); pass 2: the stencil again with
+    // BN + hard-swish fused, written into `out` (the pass-through channels are copied there): 2 slice reads + 2 slice writes
+    int rc = mvf_nhwc_stencil(d, x, d->c, base + w.y, d->cs, wt, wh, ww, nullptr, nullptr, 0, nullptr, 0, nullptr, st);
+    if (rc) return rc;
+    rc = mvf_bn_train_stats(base + w.y, m, d->cs, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                            base + w.bn, mvf_bn_workspace_bytes(m, d->cs), d->dtype, st);
+    if (rc) return rc;
+    return mvf_nhwc_fwd_infer_impl(d, x, out, d->c, wt, wh, ww, scale, shift, st);
 }
 
-int mvf_nhwc_bwd(const mvf_desc_t*, const void*, const void*, const float*, const float*, const float*, const float*,
-                 const float*, const float*, const float*, int, void*, float*, float*, float*, float*, float*, void*,
-                 hipStream_t) {
-    mvf_set_error("mvf_bwd: NHWC layout not implemented yet (use MVF_NCHW)");
-    return MVF_EUNSUPPORTED;
+int mvf_nhwc_bwd(const mvf_desc_t* d, const void* g, const void* x, const float* wt, const float* wh, const float* ww,
+                 const float* gamma, const float* beta, const float* mean, const float* invstd, int training, void* dx, float* dwt,
+                 float* dwh, float* dww, float* dgamma, float* dbeta, void* ws, hipStream_t st) {
+    MVF_REQUIRE(d->cs % 4 == 0 && d->c % 4 == 0, MVF_EUNSUPPORTED, "mvf_bwd(NHWC): needs cs %% 4 == 0 and c %% 4 == 0 (use MVF_NCHW)");
+    MVF_REQUIRE(gamma == nullptr || (dgamma && dbeta), MVF_EINVAL, "mvf_bwd(NHWC): dgamma / dbeta are NULL");
+    const NhwcTrainWs w = nhwc_train_ws(d);
+    char* base = (char*)ws;
+    const long m = (long)d->nt * d->h * d->w;
+    const void* dy = g;                 // gradient w.r.t. the stencil output, pitch dy_c
+    int dy_c = d->c;
+    int rc;
+    if (gamma) {
+        float* coef = (float*)(base + w.coef);
+        hipLaunchKernelGGL(bn_coef_kernel, dim3((d->cs + 255) / 256), dim3(256), 0, st, gamma, beta, mean, invstd, d->cs, coef);
+        MVF_LAUNCH_CHECK();
+        rc = mvf_nhwc_stencil(d, x, d->c, base + w.y, d->cs, wt, wh, ww, nullptr, nullptr, 0, nullptr, 0, nullptr, st);   // recompute y
+        if (rc) return rc;
+        rc = mvf_bn_bwd_reduce(g, d->c, base + w.y, nullptr, m, d->cs, mean, invstd, coef, coef + d->cs, 3, nullptr, dgamma, dbeta,
+                               base + w.bn, mvf_bn_workspace_bytes(m, d->cs), d->dtype, st);
+        if (rc) return rc;
+        // eval-mode BN has no batch-statistics term: the apply sees zero sums
+        const float* ag = training ? dgamma : coef + 2 * d->cs;
+        const float* ab = training ? dbeta : coef + 3 * d->cs;
+        rc = mvf_bn_bwd_apply_masked(g, d->c, base + w.y, nullptr, m, d->cs, gamma, mean, invstd, coef, coef + d->cs, ag, ab, 3, base + w.dz,
+                                     d->dtype, st);
+        if (rc) return rc;
+        dy = base + w.dz;
+        dy_c = d->cs;
+    }
+    rc = mvf_nhwc_tapgrad(d, x, d->c, dy, dy_c, dwt, dwh, dww, base + w.tap, mvf_nhwc_tapgrad_workspace_bytes(d), st);
+    if (rc) return rc;
+    if (dx != g && d->cs < d->c) {      // pass-through channels
+        const long npix = m;
+        const int blocks = (int)std::min<long>((npix * (d->c - d->cs) + 255) / 256, 256L * 16);
+        if (d->dtype == MVF_F32)
+            hipLaunchKernelGGL(copy_tail_nhwc<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, (float*)dx, npix, d->c, d->cs);
+        else
+            hipLaunchKernelGGL(copy_tail_nhwc<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, (bf16_t*)dx, npix, d->c, d->cs);
+        MVF_LAUNCH_CHECK();
+    }
+    if (dy == g && dx == g) {           // use_hs == False and in place: the transposed stencil must not read what it overwrites
+        MVF_HIP_OK(hipMemcpy2DAsync(base + w.dz, (size_t)d->cs * (d->dtype == MVF_F32 ? 4 : 2), g, (size_t)d->c * (d->dtype == MVF_F32 ? 4 : 2),
+                                    (size_t)d->cs * (d->dtype == MVF_F32 ? 4 : 2), (size_t)m, hipMemcpyDeviceToDevice, st));
+        dy = base + w.dz;
+        dy_c = d->cs;
+    }
+    return mvf_nhwc_stencil(d, dy, dy_c, dx, d->c, wt, wh, ww, nullptr, nullptr, 1, nullptr, 0, nullptr, st);
 }
 
 namespace {

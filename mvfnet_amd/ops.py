@@ -63,9 +63,11 @@ class _MVFProper(torch.autograd.Function):
         _require_gpu(x, "MVF")
         layout = _layout_of(x)
         use_hs_ = gamma is not None
-        if layout is None or (layout == _lib.MVF_NHWC and ((use_hs_ and training) or any(ctx.needs_input_grad[:6]))):
-            # the public channels-last entry points cover inference; training / backward of a channels-last tensor goes
-            # through the NCHW kernels on a contiguous copy (the fused TrainEngine has its own NHWC training primitives)
+        nhwc_train_ok = cs % 4 == 0 and x.shape[1] % 4 == 0        # mvf_fwd_train / mvf_bwd in MVF_NHWC need 4-channel groups
+        if layout is None or (layout == _lib.MVF_NHWC and not nhwc_train_ok and
+                              ((use_hs_ and training) or any(ctx.needs_input_grad[:6]))):
+            # odd channel counts: training / backward of a channels-last tensor goes through the NCHW kernels on a
+            # contiguous copy
             x = x.contiguous()
             layout = _lib.MVF_NCHW
         d = _desc(x, layout, n_segment, cs, mode_bits)

@@ -175,14 +175,49 @@ def test_mvf_abi_rejects_bad_arguments():
         m.cpu()(torch.randn(8, 16, 4, 4))
 
 
-def test_mvf_channels_last_training_goes_through_nchw_kernels():
-    """A channels_last input in training mode (no public NHWC train entry yet) must still give reference numbers."""
-    case = MVF_CASES[0]
+@pytest.mark.parametrize("case", [c for c in MVF_CASES if int(c[3] * c[6])], ids=lambda c: c[0])
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+def test_mvf_channels_last_training_matches_reference_golden(case, train):
+    """A channels_last input with gradients goes through the MVF_NHWC mvf_fwd_train / mvf_bwd entry points (cs % 4 == 0 in
+    every golden case): outputs, input gradient, parameter gradients and running statistics vs the reference's own run."""
     name, N, T, C, H, W, alpha, mode, share, use_hs, planes = case
     g = golden("mvf_cases.npz")
-    m = _build(case, "id", True)
+    tag = "%s/id/%s" % (name, "train" if train else "eval")
+    m = _build(case, "id", train)
     x = torch.from_numpy(synth.synth_tensor("mvf_x/" + name, (N * T, C, H, W))).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     y = m(x)
-    assert rel_err(y.detach().cpu().numpy(), g["%s/id/train/y" % name]) < TOL_F32
-    y.backward(torch.from_numpy(synth.synth_tensor("mvf_dy/%s/id" % name, tuple(y.shape))).cuda())
-    assert rel_err(x.grad.cpu().numpy(), g["%s/id/train/dx" % name]) < TOL_GRAD
+    assert rel_err(y.detach().cpu().numpy(), g[tag + "/y"]) < TOL_F32
+    y.backward(torch.from_numpy(synth.synth_tensor("mvf_dy/%s/id" % name, tuple(y.shape))).cuda().contiguous(memory_format=torch.channels_last))
+    if name in DEGENERATE_BWD:
+        return
+    assert rel_err(x.grad.cpu().numpy(), g[tag + "/dx"]) < TOL_GRAD
+    for pn, p in m.named_parameters():
+        key = tag + "/grad/" + pn
+        if key in g.files:
+            assert p.grad is not None, pn
+            assert rel_err(p.grad.cpu().numpy(), g[key]) < TOL_GRAD, pn
+    if train:
+        for bn_, b in m.named_buffers():
+            ref = g[tag + "/buf/" + bn_]
+            if ref.dtype.kind == "i":
+                assert int(b) == int(ref), bn_
+            else:
+                assert rel_err(b.cpu().numpy(), ref) < TOL_F32, bn_
+
+
+def test_mvf_channels_last_odd_channels_fall_back_to_nchw_kernels():
+    """cs % 4 != 0: the channels_last training path runs the NCHW kernels on a contiguous copy -- same numbers either way."""
+    from mvfnet_amd.modules import MVF
+    torch.manual_seed(0)
+    m = MVF(nn.Identity(), 4, 6, 0.5).cuda().train()          # cs = 3
+    x0 = torch.randn(8, 6, 5, 4, device="cuda")
+    outs = []
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        m.zero_grad()
+        m.bn.running_mean.zero_(); m.bn.running_var.fill_(1.0)
+        x = x0.clone().contiguous(memory_format=fmt).requires_grad_(True)
+        y = m(x)
+        y.backward(torch.ones_like(y))
+        outs.append((y.detach().clone(), x.grad.clone(), m.shift_conv.weight.grad.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
