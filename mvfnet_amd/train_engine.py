@@ -195,10 +195,11 @@ class _TConv(object):
             ws = eng.workspace(nbytes)
             check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
             return
-        side.wait_stream(eng.main_stream())
         ws = eng.workspace(nbytes, side=True)
-        with _on_stream(side):
+
+        def launch():
             check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
+        eng.on_side(launch)
         # dz / x / x2 are persistent engine buffers (eng.buf) or tensors the caller keeps alive until join_side()
 
     def dgrad(self, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
@@ -265,10 +266,11 @@ class _TMvf(object):
         else:
             # the tap gradients only feed the optimizer: off the critical path, on the weight-gradient stream (x and dy are
             # persistent engine buffers, untouched until join_side())
-            side.wait_stream(eng.main_stream())
             ws = eng.workspace(nbytes, side=True)
-            with _on_stream(side):
+
+            def launch():
                 check(lib.mvf_nhwc_tapgrad(C.byref(d), _p(x), c, _p(dy), self.cs, _p(self.dwt), _p(dwh), _p(dww), _p(ws), ws.numel(), _st()), "mvf tapgrad")
+            eng.on_side(launch)
         check(lib.mvf_nhwc_stencil(C.byref(d), _p(dy), self.cs, _p(dxp), c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 1,
                                    _p(addend), c if addend is not None else 0, _p(addend_bits), _st()), "mvf stencil^T")
 
@@ -369,6 +371,7 @@ class _TBlock(object):
             else:
                 dx = dxp
         self.saved = None
+        eng.flush_side()
         return dx
 
 
@@ -384,6 +387,7 @@ class _ParamStore(object):
         if dev.type != "cuda":
             raise RuntimeError("the HIP training engine needs the model on an MI355X device; no CPU fallback")
         self.model, self.device = model, dev
+        self._side_pending = []
         params = [p for p in model.parameters()]
         n = sum(p.numel() for p in params)
         pad = lambda k: (k + 3) // 4 * 4
@@ -446,7 +450,31 @@ class _ParamStore(object):
         ms = getattr(self, "_main", None)
         return ms if ms is not None else torch.cuda.current_stream()
 
+    defer_side = False         # True: side-stream launches of a block are queued behind ONE cross-stream wait (flush_side)
+
+    def on_side(self, launch):
+        """Run `launch` (which enqueues kernels through _st()) on the side stream, ordered after everything queued on the main
+        stream so far.  Each cross-stream wait costs an event packet on the main queue; with defer_side the launches are
+        collected and flush_side() issues them behind one wait."""
+        if self.defer_side:
+            self._side_pending.append(launch)
+            return
+        side = self._side
+        side.wait_stream(self.main_stream())
+        with _on_stream(side):
+            launch()
+
+    def flush_side(self):
+        pend = getattr(self, "_side_pending", None)
+        if pend:
+            self._side.wait_stream(self.main_stream())
+            with _on_stream(self._side):
+                for launch in pend:
+                    launch()
+            del pend[:]
+
     def join_side(self):
+        self.flush_side()
         if getattr(self, "_side", None) is not None:
             self.main_stream().wait_stream(self._side)
 
