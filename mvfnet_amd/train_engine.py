@@ -86,12 +86,12 @@ class _BN(object):
         self._count()
 
     def _count(self):
-        """num_batches_tracked += 1 -- batched by the engine into one launch per step when it collects them (TrainEngine)."""
-        pend = getattr(self.eng, "_nbt_pending", None)
-        if pend is None:
+        """num_batches_tracked += 1 -- TrainEngine keeps every BatchNorm's counter as a view of ONE int64 buffer and bumps them
+        all with a single launch per step (62 tiny kernels, or worse 62 tiny copies under torch._foreach_add_, otherwise)."""
+        if getattr(self.eng, "_nbt_flat", None) is None:
             self.mod.num_batches_tracked += 1
         else:
-            pend.append(self.mod.num_batches_tracked)
+            self.eng._nbt_touched = True
 
     def apply(self, z, m, act, residual=None, rbn=None, bits=False):
         """out = act(bn(z) [+ residual]); bits=True also keeps the sign bits of out ([m][c/4] bytes) for the backward masks."""
@@ -538,7 +538,13 @@ class TrainEngine(_ParamStore):
         self.dfc_w, self.dfc_b = self.grad_of(head.new_fc.weight), self.grad_of(head.new_fc.bias)
         self.dropout = head.dropout_ratio if head.dropout is not None else 0.0
         self.num_classes = head.num_classes
-        self._nbt_pending = []                     # BatchNorm step counters touched in this forward (see _BN._count)
+        # every BatchNorm's num_batches_tracked becomes a 0-dim view of one int64 buffer (see _BN._count)
+        bns = [m_ for m_ in model.modules() if isinstance(m_, torch.nn.modules.batchnorm._BatchNorm) and m_.num_batches_tracked is not None]
+        self._nbt_flat = torch.zeros(max(len(bns), 1), dtype=torch.int64, device=self.device)
+        for i, m_ in enumerate(bns):
+            self._nbt_flat[i] = m_.num_batches_tracked.to(self.device)
+            m_.num_batches_tracked = self._nbt_flat[i]
+        self._nbt_touched = False
 
     # ---- one step -----------------------------------------------------------------------------------------------
     def forward(self, imgs, labels, stages=None):
@@ -603,9 +609,9 @@ class TrainEngine(_ParamStore):
         check(lib.mvf_head_train_fwd(_p(xcur), b, t, hc * wc, cc, _p(self.fc_w), _p(self.fc_b), self.num_classes, _p(lab), _p(mask), _p(pooled),
                                      _p(scores), _p(dscores), _p(loss_part), _p(loss), self.dt, _st()), "head fwd")
         self.saved.update(pooled=pooled, dscores=dscores, mask=mask, hw=hc * wc, c=cc, feat_shape=xcur.shape, scores=scores)
-        if self._nbt_pending:                     # one launch for every BatchNorm's step counter
-            torch._foreach_add_(self._nbt_pending, 1)
-            del self._nbt_pending[:]
+        if self._nbt_touched:                     # one launch for every BatchNorm's step counter
+            self._nbt_flat += 1
+            self._nbt_touched = False
         return loss.clone()                      # `loss` itself is a persistent buffer that the next step overwrites
 
     def backward(self):
