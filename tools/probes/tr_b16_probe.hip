@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O2 -o tools/probes/tr_b16_probe tools/probes/tr_b16_probe.hip
 // Probe of gfx950's ds_read_b64_tr_b16 lane/element mapping (run on the GPU box; prints the table the wgrad kernel relies on).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
