@@ -16,6 +16,7 @@ Kept per conv for the backward: its raw output z (pre-BN) and, for mid-block con
 Nothing is recomputed except ReLU / hard-swish masks (from z and the folded scale/shift).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -538,6 +539,17 @@ class TrainEngine(_ParamStore):
         self.dfc_w, self.dfc_b = self.grad_of(head.new_fc.weight), self.grad_of(head.new_fc.bias)
         self.dropout = head.dropout_ratio if head.dropout is not None else 0.0
         self.num_classes = head.num_classes
+        # Gradient exchange in two buckets (see _launch_tail_allreduce): the flat buffer follows model.parameters() order (stem,
+        # layer1..4, head), backward produces it back to front, so the slice from the first parameter of the third residual
+        # stage to the end (layer3 + layer4 + fc = 94 % of ResNet-50) is complete when backward enters layer2.
+        self._tail_off, self._tail_block = None, None
+        stages_ = [getattr(bb, name) for name in bb.res_layers]
+        if len(stages_) >= 3:
+            first = next(stages_[2].parameters())
+            self._tail_off = self._grad_view[id(first)].storage_offset()
+            self._tail_block = sum(len(st_) for st_ in stages_[:2])        # index of the first block of that stage
+        self._works = []
+        self._tail_launched = False
         # every BatchNorm's num_batches_tracked becomes a 0-dim view of one int64 buffer (see _BN._count)
         bns = [m_ for m_ in model.modules() if isinstance(m_, torch.nn.modules.batchnorm._BatchNorm) and m_.num_batches_tracked is not None]
         self._nbt_flat = torch.zeros(max(len(bns), 1), dtype=torch.int64, device=self.device)
@@ -614,8 +626,11 @@ class TrainEngine(_ParamStore):
             self._nbt_touched = False
         return loss.clone()                      # `loss` itself is a persistent buffer that the next step overwrites
 
-    def backward(self):
+    def backward(self, exchange=False):
+        """exchange=True (train_step): this engine also owns the data-parallel gradient exchange and may start it during
+        backward; False (autograd API / external optimizer hooks): gradients are only produced."""
         self._main = torch.cuda.current_stream()
+        self._exchange = bool(exchange)
         with _on_stream(self._main):
             self._backward()
 
@@ -628,8 +643,10 @@ class TrainEngine(_ParamStore):
         g = self.buf("gfeat", tuple(s["feat_shape"]))
         check(lib.mvf_head_train_bwd(_p(s["dscores"]), _p(s["pooled"]), _p(self.fc_w), _p(s["mask"]), b, t, s["hw"], s["c"], self.num_classes,
                                      _p(self.dfc_w), _p(self.dfc_b), _p(dpool), _p(g), self.dt, _st()), "head bwd")
-        for blk in reversed(self.blocks):
-            g = blk.backward(g, nt, self)
+        for i in range(len(self.blocks) - 1, -1, -1):
+            g = self.blocks[i].backward(g, nt, self)
+            if i == self._tail_block:
+                self._launch_tail_allreduce()
         ho, wo = s["ho"], s["wo"]
         ga = self.buf("ga0", (nt * ho * wo, 64))
         check(lib.mvf_maxpool_bn_relu_bwd(_p(s["amax"]), _p(g), nt, ho, wo, 64, _p(ga), self.dt, _st()), "maxpool bwd")
@@ -638,14 +655,45 @@ class TrainEngine(_ParamStore):
         self.join_side()
         self.saved = None
 
-    def allreduce_grads(self):
-        """reference dist_utils.py:38-49: ONE flat all-reduce (sum); the division by world size is folded into the
-        optimizer kernel's grad_scale."""
+    def _ddp_active(self):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_allreduce):
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_allreduce)
+
+    overlap_allreduce = os.environ.get("MVF_DDP_OVERLAP", "1") != "0"
+
+    def _launch_tail_allreduce(self):
+        """Called from backward when layer3's first block is done: all-reduce flat_grads[tail_off:] (layer3, layer4, head: 94 % of
+        the bytes) asynchronously while layer2 / layer1 / stem run their backward (about half of its time).  The collective is
+        issued from the side stream after that stream has been ordered behind the main stream: at this point everything that
+        writes the slice -- weight-gradient GEMMs and MVF tap gradients (side stream), BatchNorm / head gradients (main stream)
+        -- is queued ahead of it, and nothing later writes it.  Every rank issues the same two collectives in the same order
+        (tail here, head slice in allreduce_grads), which is all RCCL needs."""
+        self._tail_launched = False
+        if not (getattr(self, "_exchange", False) and self.overlap_allreduce and self._tail_off and self._ddp_active() and self.overlap_wgrad):
+            return
+        import torch.distributed as dist
+        side = self.side_stream()
+        self.flush_side()
+        side.wait_stream(self.main_stream())
+        with torch.cuda.stream(side):          # torch's current stream: ProcessGroupNCCL orders its stream behind it
+            self._works.append(dist.all_reduce(self.flat_grads[self._tail_off:], async_op=True))
+        self._tail_launched = True
+
+    def allreduce_grads(self):
+        """reference dist_utils.py:38-49: the flat gradient is all-reduced (sum); the division by world size is folded into the
+        optimizer kernel's grad_scale.  One collective, or two when the tail bucket was launched during backward."""
+        import torch.distributed as dist
+        if not self._ddp_active():
+            return 1
+        if self._tail_launched:
+            dist.all_reduce(self.flat_grads[:self._tail_off])
+            for w in self._works:
+                w.wait()                        # stream-level: the current stream waits for the collective's stream
+            del self._works[:]
+            self._tail_launched = False
+        else:
             dist.all_reduce(self.flat_grads)
-            return dist.get_world_size()
-        return 1
+        return dist.get_world_size()
 
     force_allreduce = False
 
@@ -668,6 +716,6 @@ class TrainEngine(_ParamStore):
 
     def train_step(self, imgs, labels, lr=None):
         loss = self.forward(imgs, labels)
-        self.backward()
+        self.backward(exchange=True)
         self.step(lr)
         return loss

@@ -45,6 +45,18 @@ def _worker(rank, world, port, q):
     a = D.allreduce_flat(flat.clone())
     b = D.allreduce_flat(flat.clone(), bucket_size_mb=1e-5)
     assert torch.allclose(a, torch.arange(10, dtype=torch.float32) * 1.5) and torch.equal(a, b)
+    # the TrainEngine's two-bucket exchange: tail slice asynchronously first (while backward still runs), head slice later --
+    # the same two collectives in the same order on every rank must equal the single flat all-reduce
+    fl = (torch.arange(16, dtype=torch.float32) + 1.0) * (rank + 1)
+    one = fl.clone()
+    dist.all_reduce(one)
+    two = fl.clone()
+    tail_off = 5
+    work = dist.all_reduce(two[tail_off:], async_op=True)
+    two[:tail_off] *= 1.0                                   # "backward" keeps writing the head slice meanwhile
+    dist.all_reduce(two[:tail_off])
+    work.wait()
+    assert torch.equal(one, two)
     # bucketed coalesced path gives the same average
     for p in net.parameters():
         p.grad = torch.full_like(p, float(rank + 1))

@@ -518,3 +518,37 @@ def test_c1_train_bf16_loss_and_gradients_track_reference():
     norm = eng.step()
     assert abs(float(norm[0]) - float(g["c1/train/total_norm/0"])) < 5e-2 * float(g["c1/train/total_norm/0"])
     assert float(eng.forward(imgs, labels)) < float(loss)              # the step reduces the loss
+
+
+def test_two_bucket_gradient_exchange_matches_flat_allreduce_single_rank():
+    """One rank, RCCL process group, exchange forced: the engine launches the tail bucket (layer3 + layer4 + head) from the
+    side stream while backward is still running and the head bucket after it -- parameters after two steps must be bit-identical
+    to the un-overlapped single flat all-reduce (world size 1: the collective is the identity, the test is the stream choreography)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 96, 96)).cuda()
+        labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+        outs = []
+        for overlap in (False, True):
+            m = _model(50, 4)
+            eng = m.train_engine(dtype=torch.bfloat16)
+            eng.force_allreduce = True
+            eng.overlap_allreduce = overlap
+            losses = [float(eng.train_step(imgs, labels)) for _ in range(2)]
+            assert eng._tail_off and 0 < eng._tail_off < eng.flat_grads.numel() // 4      # the tail bucket is most of the buffer
+            torch.cuda.synchronize()
+            outs.append((losses, eng.flat_params.clone(), eng.flat_grads.clone()))
+        assert outs[0][0] == outs[1][0]
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    finally:
+        dist.destroy_process_group()
