@@ -743,22 +743,6 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
-    static const bool sk_all = getenv("MVF_CONV_SKALL") != nullptr;     // experiment: persistent launch of every tile
-    if (sk_all && skh.ws && skh.ws_bytes >= sk_ws_bytes() && tiles > slots) {
-        SkArgs sk;
-        const long units = (long)tiles * a.nchunks;
-        sk.G = slots;
-        sk.units_base = (int)(units / sk.G);
-        sk.units_rem = (int)(units % sk.G);
-        sk.tile0 = 0;
-        sk.ws = (float*)skh.ws;
-        sk.flags = (unsigned*)((char*)skh.ws + (size_t)slots * (128 * 128 * sizeof(float)));
-        sk.err = sk.flags + slots;
-        MVF_HIP_OK(hipMemsetAsync(sk.flags, 0, (size_t)(slots + 1) * sizeof(unsigned), st));
-        hipLaunchKernelGGL(kern_sk, dim3(sk.G), dim3(kThreads), lds, st, a, sk);
-        MVF_LAUNCH_CHECK();
-        return MVF_OK;
-    }
     // stream-K (double-buffered kernel + a cut last wave) keeps the launches where its cost model says it pays: long-K fp32
     // convs with a mostly empty last tile wave (+2 % on fp32 inference); everything else takes the single-buffer variant
     bool sk_wins = false;
