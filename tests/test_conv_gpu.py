@@ -21,6 +21,10 @@ CONV_CASES = [
     (1, 7, 7, 512, 2048, 1, 1, 0),      # many n tiles
     (2, 8, 8, 48, 96, 3, 1, 1),         # cin not a multiple of the chunk, cout not a multiple of the tile
     (4, 7, 7, 2048, 512, 1, 1, 0),      # long K
+    (150, 1, 1, 64, 64, 1, 1, 0),       # 1x1 maps: a 128-row tile spans 128 images (row -> image division by 1)
+    (3, 2, 33, 32, 96, 3, 1, 1),        # two-row maps, Wo not a power of two, every tap masked somewhere
+    (2, 5, 5, 64, 128, 5, 1, 2),        # 5x5 kernel (25 taps in the kh / kw bit masks)
+    (1, 40, 3, 64, 64, 3, 2, 1),        # tall thin map, stride 2
 ]
 
 
