@@ -135,7 +135,8 @@ def test_bn_sign_bits_equal_the_tensor_mask(mc, dtype):
 
 # (n, h, w, cin, cout, k, stride, pad)
 GRAD_CASES = [(2, 8, 8, 64, 32, 1, 1, 0), (2, 9, 9, 32, 64, 3, 1, 1), (2, 10, 10, 32, 32, 3, 2, 1), (3, 8, 8, 64, 128, 1, 2, 0),
-              (1, 14, 14, 256, 256, 3, 1, 1), (2, 7, 7, 132, 36, 3, 1, 1)]
+              (1, 14, 14, 256, 256, 3, 1, 1), (2, 7, 7, 132, 36, 3, 1, 1),
+              (150, 1, 1, 64, 64, 1, 1, 0), (3, 2, 33, 64, 96, 3, 1, 1), (5, 13, 11, 128, 64, 3, 2, 1), (2, 20, 20, 64, 256, 1, 1, 0)]
 
 
 @pytest.mark.parametrize("case", GRAD_CASES, ids=lambda c: "n%d_%dx%d_c%d_o%d_k%d_s%d" % c[:7])
