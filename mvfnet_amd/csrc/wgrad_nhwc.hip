@@ -165,11 +165,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
 
 // ---- bf16 operands on the bf16 matrix cores --------------------------------------------------------------------------
 // v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE contraction indices (= pixels) per lane, but both operands are pixel-major in
-// memory.  The tiles are staged in their natural layout ([pixel][channel], 16-B coalesced global loads, 16-B LDS stores)
-// and the transposition happens in the operand fetch: a lane gathers its 8 pixels with eight 2-byte LDS reads
-// (32 lanes read 32 consecutive channels of one pixel row -> 64 contiguous bytes, conflict-free; the two half-waves are 8
-// rows apart).  That is 8x the LDS instructions of a k-major tile, but this GEMM is L2/HBM-bound long before that (64 x
-// (128+128) x 2 B of operands per 16 MFMAs), and it is 4x fewer HBM bytes and 16x the matrix rate of widening to fp32.
+// memory.  The tiles are staged in their natural layout ([pixel][channel], 16-B coalesced global loads, 16-B LDS stores, rows
+// XOR-swizzled) and the transposition happens in the operand fetch with the gfx950 transpose read ds_read_b64_tr_b16 (two per
+// fragment; see wgrad_bf16_kernel).  Compared with widening to fp32 this is 4x fewer HBM bytes and 16x the matrix rate.
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 // XOR swizzle of the 16-byte units of an LDS row with U units (U = 16: 256-B rows, U = 8: 128-B rows), see wgrad_bf16_kernel
 template <int U>
