@@ -35,6 +35,9 @@ def main():
                       "SQ_INST_CYCLES_VMEM", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC", "SQ_ACTIVE_INST_SCA"):
                 if c in d:
                     d[c + "/wave_cycles"] = d[c] / wc
+        if d.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and d.get("GRBM_GUI_ACTIVE"):
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs (4 per CU)
+            d["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         if d.get("SQ_LDS_BANK_CONFLICT") is not None and d.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_conflict_frac"] = d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"]
     json.dump(agg, open(out, "w"), indent=1, sort_keys=True)
