@@ -521,6 +521,27 @@ def test_c1_train_bf16_loss_and_gradients_track_reference():
     assert float(eng.forward(imgs, labels)) < float(loss)              # the step reduces the loss
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_side_stream_overlap_is_bit_identical_to_single_stream(dtype):
+    """Race detector.  Nothing in the step uses atomics, so training with the weight gradients / MVF tap gradients / weight
+    packs on the side stream must reproduce the single-stream run BIT for bit (losses, parameters, BatchNorm buffers) over
+    several optimizer steps -- and the loss on the fixed batch must go down."""
+    imgs = torch.from_numpy(synth.synth_clip_batch(4, 4, 128, 128)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(4)).cuda()
+    res = []
+    for overlap in (True, False):
+        torch.manual_seed(0)                                     # same dropout masks
+        m = _model(50, 4, dropout=0.5)
+        eng = m.train_engine(dtype=dtype)
+        eng.overlap_wgrad = overlap
+        losses = [float(eng.train_step(imgs, labels)) for _ in range(6)]
+        torch.cuda.synchronize()
+        res.append((losses, eng.flat_params.clone(), torch.cat([b.flatten().float() for b in m.buffers()])))
+    assert all(np.isfinite(res[0][0])) and res[0][0][-1] < res[0][0][0]
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 def test_two_bucket_gradient_exchange_matches_flat_allreduce_single_rank():
     """One rank, RCCL process group, exchange forced: the engine launches the tail bucket (layer3 + layer4 + head) from the
     side stream while backward is still running and the head bucket after it -- parameters after two steps must be bit-identical
