@@ -111,7 +111,10 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
 
 // LOWK = single-buffered A/B tiles and a two-pass (half-tile) epilogue: 36 KB of LDS instead of 72 KB -> 3-4 workgroups per CU.
 // Used for the small-K pointwise convs (1-2 K chunks), which are HBM-bound and need memory-level parallelism, not MFMA overlap.
-template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false>
+// EPI specialises the epilogue at compile time for the three shapes the training step launches all the time (the generic code
+// keeps a uniform branch per feature per row): 0 generic, 1 forward + BatchNorm statistics (no bias / residual / ReLU),
+// 2 plain (data gradient), 3 data gradient + [gated] residual.  1-3 imply contiguous output rows (no scatter).
+template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -439,6 +442,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // The block tile is staged through LDS (the A/B buffers are dead after the last barrier) with 16-byte writes and read
     // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
     // residual loads.
+    const bool e_bias = EPI == 0 && a.bias != nullptr;
+    const bool e_res = EPI == 0 ? a.res != nullptr : EPI == 3;
+    const bool e_relu = EPI == 0 && a.relu;
+    const bool e_stats = EPI == 0 ? a.stats_part != nullptr : EPI == 1;
+    const bool e_scatter = EPI == 0 && a.o_s > 0;
     constexpr int CP = BN * 4 + 16;                      // C-tile pitch in bytes
     constexpr int NH = LOWK ? 2 : 1;                     // epilogue passes (row halves of the block tile)
     constexpr int HR = BM / NH;                          // rows per pass
@@ -450,22 +458,22 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     ET* y = reinterpret_cast<ET*>(a.y);
     const ET* res = reinterpret_cast<const ET*>(a.res);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias && col < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + col);
+    if (e_bias && col < a.Cout) bv = *reinterpret_cast<const float4*>(a.bias + col);
     // fused BatchNorm statistics of the tensor being written (training): this thread's rows of its 4 columns
     float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = st1, kk = st1;
-    if (a.stats_part && a.stats_shift && col < a.Cout) kk = *reinterpret_cast<const float4*>(a.stats_shift + col);
+    if (e_stats && a.stats_shift && col < a.Cout) kk = *reinterpret_cast<const float4*>(a.stats_shift + col);
     // output / residual descriptors: tile-relative 32-bit offsets (contiguous rows from m0, or the full-resolution images
     // from the tile's first image for a scattered data-gradient class)
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const int eimg0 = fd_div(m0, a.fd_hw_mul, a.fd_hw_shr);
     __amdgpu_buffer_rsrc_t rs_y, rs_res;
     {
-        const long total = (a.o_s > 0 ? (long)a.N * a.o_hfull * a.o_wfull : (long)a.M) * a.Cout * ESZ;
-        const long base = (a.o_s > 0 ? (long)eimg0 * a.o_hfull * a.o_wfull : (long)m0) * a.Cout * ESZ;
+        const long total = (e_scatter ? (long)a.N * a.o_hfull * a.o_wfull : (long)a.M) * a.Cout * ESZ;
+        const long base = (e_scatter ? (long)eimg0 * a.o_hfull * a.o_wfull : (long)m0) * a.Cout * ESZ;
         const long left = total - base;
         const unsigned nrec = (unsigned)(left < 0x7ffffff0L ? left : 0x7ffffff0L);
         rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + base), 0, nrec, 0x00020000);
-        rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + base : a.y + base), 0, nrec, 0x00020000);
+        rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(e_res ? a.res + base : a.y + base), 0, nrec, 0x00020000);
     }
     // residual gate bits (contiguous outputs only): one byte per 4 channels, addressed like the output / (4 * ESZ)
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(
@@ -478,7 +486,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     constexpr int kMaskOff = HR * CP;
     constexpr int MSEG = BN / 64;                        // 16-byte segments per mask row
     static_assert(kMaskOff + BM * (BN / 4) <= (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch), "mask tile must fit behind the C tile");
-    const bool mask_lds = a.res_mask && (a.Cout % 64 == 0) && a.mask_lds;
+    const bool mask_lds = e_res && a.res_mask && (a.Cout % 64 == 0) && a.mask_lds;
     if (mask_lds && tid < BM * MSEG) {
         const int row = tid / MSEG, seg = tid - row * MSEG;
         const u32x4 mv = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (unsigned)(row * (a.Cout / 4) + n0 / 4 + seg * 16), 0, 0);
@@ -511,7 +519,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 const bool ok = cok2 && m < a.M;
                 float4 v = *reinterpret_cast<const float4*>(smem + (r0 + ps * RPP) * CP + cq * 16);
                 unsigned off;
-                if (a.o_s > 0) {                         // strided data-gradient class: scatter into the full-resolution map
+                if (e_scatter) {                         // strided data-gradient class: scatter into the full-resolution map
                     const int img = fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * (a.Ho * a.Wo);
                     const int oh = fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
                     off = (unsigned)((((img - eimg0) * a.o_hfull + oh * a.o_s + a.o_ph) * a.o_wfull + ow * a.o_s + a.o_pw) * a.Cout + col) * ESZ;
@@ -519,8 +527,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     off = (unsigned)((m - m0) * a.Cout + col) * ESZ;
                 }
                 off = ok ? off : kOOB;
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (a.res) {
+                if (e_bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+                if (e_res) {
                     float4 rv;
                     const unsigned roff = col >= a.res_c0 ? off : kOOB;       // skipped columns read zeros
                     if constexpr (sizeof(ET) == 2) {
@@ -539,7 +547,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     }
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                 }
-                if (a.relu) {
+                if (e_relu) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
                 if constexpr (sizeof(ET) == 2) {
@@ -555,7 +563,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     pk.x = __float_as_uint(v.x); pk.y = __float_as_uint(v.y); pk.z = __float_as_uint(v.z); pk.w = __float_as_uint(v.w);
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, off, 0, 0);
                 }
-                if (a.stats_part) {
+                if (e_stats) {
                     if (!ok) v = kk;                     // rows past M contribute nothing
                     v.x -= kk.x; v.y -= kk.y; v.z -= kk.z; v.w -= kk.w;
                     st1.x += v.x; st1.y += v.y; st1.z += v.z; st1.w += v.w;
@@ -564,7 +572,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             }
         }
     }
-    if (a.stats_part) {                                  // column sums over the RPP row-threads, fixed order, one writer per column
+    if (e_stats) {                                  // column sums over the RPP row-threads, fixed order, one writer per column
         __syncthreads();
         float4* red = reinterpret_cast<float4*>(smem);
         red[(r0 * 2 + 0) * TPR + cq] = st1;
@@ -607,11 +615,11 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_pf2_kernel(ConvArgs a) {
     conv_tile<ET, WM, WN, TM, TN, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
-template <typename ET, int WM, int WN, int TM, int TN>
+template <typename ET, int WM, int WN, int TM, int TN, int EPI = 0>
 __global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
-    conv_tile<ET, WM, WN, TM, TN, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+    conv_tile<ET, WM, WN, TM, TN, true, false, false, EPI>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
 // Stream-K tail: the last, partial wave of tiles is NOT run one tile per workgroup (which leaves e.g. 47 % of the CUs idle
@@ -754,7 +762,20 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     }
     if (a.nchunks <= g_lowk_max_chunks && !sk_wins) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();
-        hipLaunchKernelGGL(kern_lk, dim3(tiles), dim3(kThreads), lds_lk, st, a);
+        static const bool epi_spec = !(getenv("MVF_CONV_EPI") && getenv("MVF_CONV_EPI")[0] == '0');     // A/B switch
+        const bool simple = epi_spec && !a.bias && !a.relu && a.o_s <= 0;
+        if (simple && a.stats_part && !a.res) {
+            auto k1 = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, 1>;
+            hipLaunchKernelGGL(k1, dim3(tiles), dim3(kThreads), lds_lk, st, a);
+        } else if (simple && !a.stats_part && !a.res) {
+            auto k2 = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, 2>;
+            hipLaunchKernelGGL(k2, dim3(tiles), dim3(kThreads), lds_lk, st, a);
+        } else if (simple && !a.stats_part && a.res) {
+            auto k3 = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, 3>;
+            hipLaunchKernelGGL(k3, dim3(tiles), dim3(kThreads), lds_lk, st, a);
+        } else {
+            hipLaunchKernelGGL(kern_lk, dim3(tiles), dim3(kThreads), lds_lk, st, a);
+        }
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
