@@ -113,8 +113,11 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
 // Used for the small-K pointwise convs (1-2 K chunks), which are HBM-bound and need memory-level parallelism, not MFMA overlap.
 // EPI specialises the epilogue at compile time for the three shapes the training step launches all the time (the generic code
 // keeps a uniform branch per feature per row): 0 generic, 1 forward + BatchNorm statistics (no bias / residual / ReLU),
-// 2 plain (data gradient), 3 data gradient + [gated] residual.  1-3 imply contiguous output rows (no scatter).
-template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0>
+// 2 plain (data gradient), 3 data gradient + [gated] residual, 4 bias + ReLU, 5 bias + residual + ReLU (inference).
+// 1-5 imply contiguous output rows (no scatter).
+// PW specialises the loader for pointwise launches (1x1 taps, no padding, no split operand): a row is either valid for every
+// chunk or never, so the tap masks and the second operand's offsets disappear.
+template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0, bool PW = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -205,6 +208,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             const int oh = fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
             const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad_w;
             const int pix = ((img - img0) * a.H + ih0) * a.W + iw0;    // may be negative for a padded corner; valid taps land >= 0
+            if constexpr (PW) {
+                a_off[i] = m < a.M ? (unsigned)(pix * a.xps + q * UE) * ESZ : kOOB;     // valid for every chunk, or never
+                a_off2[i] = 0u; hmask[i] = 0u; wmask[i] = 0u;
+                continue;
+            }
             a_off[i] = (unsigned)(pix * a.xps + q * UE) * ESZ;
             a_off2[i] = (unsigned)(pix * a.x2ps + q * UE) * ESZ;
             // bit k of hmask: 0 <= ih0 + k < H  (k in [lo, hi)); all zero for rows past M
@@ -267,9 +275,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             const __amdgpu_buffer_rsrc_t rs = from2 ? rs_x2 : rs_x;
 #pragma unroll
             for (int i = 0; i < A_ROWS_PT; ++i) {
-                const bool ok = ((hmask[i] >> kh) & (wmask[i] >> kw) & 1u) != 0u;
-                const unsigned off = ((from2 ? a_off2[i] : a_off[i]) + toff) | cbad;
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : kOOB, 0, 0);
+                unsigned voff;
+                if constexpr (PW) {
+                    voff = (a_off[i] + (unsigned)(cc * CE) * ESZ) | cbad;              // kOOB + small stays out of range
+                } else {
+                    const bool ok = ((hmask[i] >> kh) & (wmask[i] >> kw) & 1u) != 0u;
+                    voff = ok ? (((from2 ? a_off2[i] : a_off[i]) + toff) | cbad) : kOOB;
+                }
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(PW ? rs_x : rs, voff, 0, 0);
                 st.a[i] = make_uint4(v.x, v.y, v.z, v.w);
             }
             const unsigned koff = (unsigned)(((a.w_kh0 + kh * a.w_ts) * a.w_kwfull + (a.w_kw0 + kw * a.w_ts)) * a.Cin + cc * CE) * ESZ;
@@ -442,9 +455,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // The block tile is staged through LDS (the A/B buffers are dead after the last barrier) with 16-byte writes and read
     // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
     // residual loads.
-    const bool e_bias = EPI == 0 && a.bias != nullptr;
-    const bool e_res = EPI == 0 ? a.res != nullptr : EPI == 3;
-    const bool e_relu = EPI == 0 && a.relu;
+    const bool e_bias = EPI == 0 ? a.bias != nullptr : EPI >= 4;
+    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5);
+    const bool e_relu = EPI == 0 ? a.relu != 0 : EPI >= 4;
     const bool e_stats = EPI == 0 ? a.stats_part != nullptr : EPI == 1;
     const bool e_scatter = EPI == 0 && a.o_s > 0;
     constexpr int CP = BN * 4 + 16;                      // C-tile pitch in bytes
@@ -615,11 +628,22 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_pf2_kernel(ConvArgs a) {
     conv_tile<ET, WM, WN, TM, TN, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
-template <typename ET, int WM, int WN, int TM, int TN, int EPI = 0>
+template <typename ET, int WM, int WN, int TM, int TN, int EPI = 0, bool PW = false>
 __global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
-    conv_tile<ET, WM, WN, TM, TN, true, false, false, EPI>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+    conv_tile<ET, WM, WN, TM, TN, true, false, false, EPI, PW>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+template <typename ET, int WM, int WN, int TM, int TN, int EPI>
+void launch_lowk(bool pw, int tiles, size_t lds, hipStream_t st, const ConvArgs& a) {
+    if (pw) {
+        auto k = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, EPI, true>;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds, st, a);
+    } else {
+        auto k = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, EPI, false>;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds, st, a);
+    }
 }
 
 // Stream-K tail: the last, partial wave of tiles is NOT run one tile per workgroup (which leaves e.g. 47 % of the CUs idle
@@ -724,7 +748,6 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     const size_t lds = (size_t)2 * (BM + BN) * kPitch;
     auto kern = conv_igemm_kernel<ET, WM, WN, TM, TN>;
     auto kern_sk = conv_streamk_kernel<ET, WM, WN, TM, TN>;
-    auto kern_lk = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN>;
     auto kern_pf = conv_igemm_pf2_kernel<ET, WM, WN, TM, TN>;
     static bool attr_done = false;   // per instantiation; idempotent, so a benign race at worst
     if (!attr_done) {
@@ -762,20 +785,17 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     }
     if (a.nchunks <= g_lowk_max_chunks && !sk_wins) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();
-        static const bool epi_spec = !(getenv("MVF_CONV_EPI") && getenv("MVF_CONV_EPI")[0] == '0');     // A/B switch
-        const bool simple = epi_spec && !a.bias && !a.relu && a.o_s <= 0;
-        if (simple && a.stats_part && !a.res) {
-            auto k1 = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, 1>;
-            hipLaunchKernelGGL(k1, dim3(tiles), dim3(kThreads), lds_lk, st, a);
-        } else if (simple && !a.stats_part && !a.res) {
-            auto k2 = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, 2>;
-            hipLaunchKernelGGL(k2, dim3(tiles), dim3(kThreads), lds_lk, st, a);
-        } else if (simple && !a.stats_part && a.res) {
-            auto k3 = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, 3>;
-            hipLaunchKernelGGL(k3, dim3(tiles), dim3(kThreads), lds_lk, st, a);
-        } else {
-            hipLaunchKernelGGL(kern_lk, dim3(tiles), dim3(kThreads), lds_lk, st, a);
-        }
+        static const int epi_spec = getenv("MVF_CONV_EPI") ? atoi(getenv("MVF_CONV_EPI")) : 3;     // A/B switch: bit 0 epilogues, bit 1 pointwise loader
+        const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
+        const bool contiguous = (epi_spec & 1) && a.o_s <= 0;
+        const bool train_like = contiguous && !a.bias && !a.relu;
+        const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
+        if (train_like && a.stats_part && !a.res) launch_lowk<ET, WM, WN, TM, TN, 1>(pw, tiles, lds_lk, st, a);
+        else if (train_like && !a.stats_part && !a.res) launch_lowk<ET, WM, WN, TM, TN, 2>(pw, tiles, lds_lk, st, a);
+        else if (train_like && !a.stats_part && a.res) launch_lowk<ET, WM, WN, TM, TN, 3>(pw, tiles, lds_lk, st, a);
+        else if (infer_like && !a.res) launch_lowk<ET, WM, WN, TM, TN, 4>(pw, tiles, lds_lk, st, a);
+        else if (infer_like && a.res) launch_lowk<ET, WM, WN, TM, TN, 5>(pw, tiles, lds_lk, st, a);
+        else launch_lowk<ET, WM, WN, TM, TN, 0>(pw, tiles, lds_lk, st, a);
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
