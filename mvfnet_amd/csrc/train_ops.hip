@@ -311,11 +311,13 @@ __device__ __forceinline__ unsigned ld_maskbits(const void* bits, long row, int 
     else return *p;
 }
 
-template <typename ET, int VN>
+// MM >= 0 fixes the mask mode at compile time (the per-element mask code is then a single case instead of a select chain)
+template <typename ET, int VN, int MM = -1>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const ET* g, int g_pitch, const ET* z, const ET* ymask, long M, int C,
                                                                  const float* mean, const float* invstd, const float* scale,
-                                                                 const float* shift, int mask_mode, ET* gm_out, int cqb, int rows,
+                                                                 const float* shift, int mask_mode_rt, ET* gm_out, int cqb, int rows,
                                                                  float* part) {
+    const int mask_mode = MM >= 0 ? MM : mask_mode_rt;
     __shared__ float red[2 * VN * kThreads];
     const int rl = kThreads / cqb;
     const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
@@ -380,11 +382,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nblk, c
 
 // dz = gamma*invstd * (gm - dbeta/M - xhat*dgamma/M); gm = g*mask recomputed as above (mask_mode 0: g is already masked)
 // Column-tiled like bn_apply_kernel: the six per-channel coefficients are folded once per lane into registers.
-template <typename ET, int VN>
+template <typename ET, int VN, int MM = -1>
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const ET* g, int g_pitch, const ET* z, const ET* ymask, long M, int C, const float* gamma,
                                                                 const float* mean, const float* invstd, const float* scale,
                                                                 const float* shift, const float* dgamma, const float* dbeta,
-                                                                int mask_mode, ET* dz, int cqb, int rows) {
+                                                                int mask_mode_rt, ET* dz, int cqb, int rows) {
+    const int mask_mode = MM >= 0 ? MM : mask_mode_rt;
     const int rl = kThreads / cqb;
     const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
     if (cq * VN >= C) return;
@@ -655,6 +658,34 @@ size_t mvf_bn_workspace_bytes(long m, int c) {
         }                                                                                                                    \
     } while (0)
 
+// the same with the mask mode (0-4) as a third template argument
+#define MVF_BN_DISPATCH_MM1(KERNEL, MMV, WIDE_OK, BLOCKS, ...)                                                               \
+    do {                                                                                                                     \
+        if (dtype == MVF_F32) {                                                                                              \
+            using ET = float;                                                                                                \
+            const ColPlan p = col_plan(m, c, 4, BLOCKS);                                                                     \
+            hipLaunchKernelGGL((KERNEL<float, 4, MMV>), dim3(p.gx, p.gy), dim3(kThreads), 0, st, __VA_ARGS__);               \
+        } else if (WIDE_OK) {                                                                                                \
+            using ET = bf16_t;                                                                                               \
+            const ColPlan p = col_plan(m, c, 8, BLOCKS);                                                                     \
+            hipLaunchKernelGGL((KERNEL<bf16_t, 8, MMV>), dim3(p.gx, p.gy), dim3(kThreads), 0, st, __VA_ARGS__);              \
+        } else {                                                                                                             \
+            using ET = bf16_t;                                                                                               \
+            const ColPlan p = col_plan(m, c, 4, BLOCKS);                                                                     \
+            hipLaunchKernelGGL((KERNEL<bf16_t, 4, MMV>), dim3(p.gx, p.gy), dim3(kThreads), 0, st, __VA_ARGS__);              \
+        }                                                                                                                    \
+    } while (0)
+#define MVF_BN_DISPATCH_MM(KERNEL, MODE, WIDE_OK, BLOCKS, ...)                                \
+    do {                                                                                      \
+        switch (MODE) {                                                                       \
+            case 0: MVF_BN_DISPATCH_MM1(KERNEL, 0, WIDE_OK, BLOCKS, __VA_ARGS__); break;      \
+            case 1: MVF_BN_DISPATCH_MM1(KERNEL, 1, WIDE_OK, BLOCKS, __VA_ARGS__); break;      \
+            case 2: MVF_BN_DISPATCH_MM1(KERNEL, 2, WIDE_OK, BLOCKS, __VA_ARGS__); break;      \
+            case 3: MVF_BN_DISPATCH_MM1(KERNEL, 3, WIDE_OK, BLOCKS, __VA_ARGS__); break;      \
+            default: MVF_BN_DISPATCH_MM1(KERNEL, 4, WIDE_OK, BLOCKS, __VA_ARGS__); break;     \
+        }                                                                                     \
+    } while (0)
+
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const float* beta, float eps, float momentum,
@@ -715,7 +746,11 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
     float* part = (float*)ws;
     const bool wide = false;                 // measured: the 8-byte-lane variant is ~7% faster for this kernel (more rows in flight per wave)
     const int gy = col_plan(m, c, (dtype != MVF_F32 && wide) ? 8 : 4).gy;
-    MVF_BN_DISPATCH(bn_bwd_reduce_kernel, wide, 2048, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (ET*)gm_out, p.cqb, p.rows, part);
+    static const bool bn_spec = !(getenv("MVF_BN_SPEC") && getenv("MVF_BN_SPEC")[0] == '0');      // A/B switch
+    if (bn_spec)
+        MVF_BN_DISPATCH_MM(bn_bwd_reduce_kernel, mask_mode, wide, 2048, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (ET*)gm_out, p.cqb, p.rows, part);
+    else
+        MVF_BN_DISPATCH(bn_bwd_reduce_kernel, wide, 2048, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (ET*)gm_out, p.cqb, p.rows, part);
     MVF_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, st, c, gy, part, dgamma, dbeta);
     MVF_LAUNCH_CHECK();
@@ -732,7 +767,12 @@ int mvf_bn_bwd_apply_masked(const void* g, int g_pitch, const void* z, const voi
     hipStream_t st = (hipStream_t)stream;
     const bool wide = c % 8 == 0 && g_pitch % 8 == 0 && al16(g) && al16(z) && al16(dz) && (mask_mode != 1 || al16(ymask)) &&
                       (mask_mode != 4 || ((uintptr_t)ymask & 1) == 0);
-    MVF_BN_DISPATCH(bn_bwd_apply_kernel, wide, 4096, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, gamma, mean, invstd, scale, shift,
+    static const bool bn_spec = !(getenv("MVF_BN_SPEC") && getenv("MVF_BN_SPEC")[0] == '0');      // A/B switch
+    if (bn_spec)
+        MVF_BN_DISPATCH_MM(bn_bwd_apply_kernel, mask_mode, wide, 4096, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, gamma, mean, invstd, scale, shift,
+                    dgamma, dbeta, mask_mode, (ET*)dz, p.cqb, p.rows);
+    else
+        MVF_BN_DISPATCH(bn_bwd_apply_kernel, wide, 4096, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, gamma, mean, invstd, scale, shift,
                     dgamma, dbeta, mask_mode, (ET*)dz, p.cqb, p.rows);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
