@@ -185,12 +185,19 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * (2 if residual is not None else 1) + self.w.numel())
         return (fl, "dgrad M%d N%d K%d s%d" % (n * h * w, self.cin, self.kh * self.kw * self.cout, self.stride), nbytes)
 
+    def ddgb(self, out, d, dz, dx, z, bn, part, ws):          # stride-1 data gradient + BN-backward sums (reads z as well)
+        n, ho, wo, h, w = d.n, d.h, d.w, d.ho, d.wo
+        fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin
+        nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * 2 + self.w.numel())
+        return (fl, "dgrad M%d N%d K%d s%d +bn" % (n * h * w, self.cin, self.kh * self.kw * self.cout, self.stride), nbytes)
+
     def dwgr(self, out, dz, x, n, h, w, ho, wo, eng_, x_pitch=None, x2=None, split_c=0):
         k_alg = 147 if self.stem else self.kh * self.kw * self.cin
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * (4 if self.stem else self.cin)) + 4 * self.w.numel()
         return (2.0 * n * ho * wo * self.cout * k_alg, "wgrad M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)
 
-    undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "dgrad", ddgr), tw.wrap(TE._TConv, "wgrad", dwgr)]
+    undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb),
+            tw.wrap(TE._TConv, "wgrad", dwgr)]
     overlap = eng.overlap_wgrad
     eng.overlap_wgrad = False          # time every kernel alone on the launch stream (the timed steps overlap wgrad on a side stream)
     try:

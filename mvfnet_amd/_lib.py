@@ -61,6 +61,10 @@ def _load():
     lib.mvf_conv2d_workspace_bytes.argtypes = [cp]
     lib.mvf_conv2d_nhwc_fwd_ws.restype = i32
     lib.mvf_conv2d_nhwc_fwd_ws.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, sz, vp]
+    lib.mvf_conv2d_nhwc_dgrad_bnsums.restype = i32
+    lib.mvf_conv2d_nhwc_dgrad_bnsums.argtypes = [cp, vp, vp, vp, vp, fp, fp, fp, fp, fp, vp, sz, vp]
+    lib.mvf_bn_bwd_finalize.restype = i32
+    lib.mvf_bn_bwd_finalize.argtypes = [fp, i32, i32, fp, fp, vp]
     lib.mvf_conv2d_nhwc_fwd_resmask.restype = i32
     lib.mvf_conv2d_nhwc_fwd_resmask.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, vp, sz, vp]
     lib.mvf_conv2d_stats_rows.restype = i32

@@ -57,6 +57,10 @@ struct ConvArgs {
     int o_s, o_ph, o_pw, o_hfull, o_wfull;   // o_s > 0: output pixel (oh,ow) lands at (oh*o_s+o_ph, ow*o_s+o_pw) of an o_hfull x o_wfull map
     float* stats_part;         // optional [tiles_m][Cout][2]: per-tile column sums of (y - K), (y - K)^2 (BatchNorm batch statistics)
     const float* stats_shift;  // K per output channel (the BN's old running mean; any K is exact, a close one avoids cancellation)
+    // EPI 6 (data gradient whose output feeds a ReLU(BN(z)) backward): per-tile column sums of gm and gm * xhat into stats_part,
+    // gm = y * [bn_scale*z + bn_shift > 0], xhat = (z - bn_mean) * bn_invstd; z has the output's shape
+    const char* bn_z;
+    const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
     int M;
     int cpt;       // chunks per tap = ceil(Cin*esz / 128)
     int nchunks;   // KH*KW*cpt
@@ -113,8 +117,8 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
 // Used for the small-K pointwise convs (1-2 K chunks), which are HBM-bound and need memory-level parallelism, not MFMA overlap.
 // EPI specialises the epilogue at compile time for the three shapes the training step launches all the time (the generic code
 // keeps a uniform branch per feature per row): 0 generic, 1 forward + BatchNorm statistics (no bias / residual / ReLU),
-// 2 plain (data gradient), 3 data gradient + [gated] residual, 4 bias + ReLU, 5 bias + residual + ReLU (inference).
-// 1-5 imply contiguous output rows (no scatter).
+// 2 plain (data gradient), 3 data gradient + [gated] residual, 4 bias + ReLU, 5 bias + residual + ReLU (inference),
+// 6 plain data gradient + the BatchNorm-backward sums of the BN it feeds.  1-6 imply contiguous output rows (no scatter).
 // PW specialises the loader for pointwise launches (1x1 taps, no padding, no split operand): a row is either valid for every
 // chunk or never, so the tap masks and the second operand's offsets disappear.
 template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0, bool PW = false>
@@ -455,10 +459,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // The block tile is staged through LDS (the A/B buffers are dead after the last barrier) with 16-byte writes and read
     // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
     // residual loads.
-    const bool e_bias = EPI == 0 ? a.bias != nullptr : EPI >= 4;
+    const bool e_bias = EPI == 0 ? a.bias != nullptr : (EPI == 4 || EPI == 5);
     const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5);
-    const bool e_relu = EPI == 0 ? a.relu != 0 : EPI >= 4;
+    const bool e_relu = EPI == 0 ? a.relu != 0 : (EPI == 4 || EPI == 5);
     const bool e_stats = EPI == 0 ? a.stats_part != nullptr : EPI == 1;
+    constexpr bool e_bnb = EPI == 6;                     // BatchNorm-backward sums instead of forward statistics
     const bool e_scatter = EPI == 0 && a.o_s > 0;
     constexpr int CP = BN * 4 + 16;                      // C-tile pitch in bytes
     constexpr int NH = LOWK ? 2 : 1;                     // epilogue passes (row halves of the block tile)
@@ -475,6 +480,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // fused BatchNorm statistics of the tensor being written (training): this thread's rows of its 4 columns
     float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = st1, kk = st1;
     if (e_stats && a.stats_shift && col < a.Cout) kk = *reinterpret_cast<const float4*>(a.stats_shift + col);
+    float4 b_mu = st1, b_rs = st1, b_sc = st1, b_sh = st1;
+    if (e_bnb && col < a.Cout) {
+        b_mu = *reinterpret_cast<const float4*>(a.bn_mean + col); b_rs = *reinterpret_cast<const float4*>(a.bn_invstd + col);
+        b_sc = *reinterpret_cast<const float4*>(a.bn_scale + col); b_sh = *reinterpret_cast<const float4*>(a.bn_shift + col);
+    }
     // output / residual descriptors: tile-relative 32-bit offsets (contiguous rows from m0, or the full-resolution images
     // from the tile's first image for a scattered data-gradient class)
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -486,7 +496,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         const long left = total - base;
         const unsigned nrec = (unsigned)(left < 0x7ffffff0L ? left : 0x7ffffff0L);
         rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + base), 0, nrec, 0x00020000);
-        rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(e_res ? a.res + base : a.y + base), 0, nrec, 0x00020000);
+        rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(e_res ? a.res + base : (e_bnb ? a.bn_z + base : a.y + base)), 0, nrec, 0x00020000);
     }
     // residual gate bits (contiguous outputs only): one byte per 4 channels, addressed like the output / (4 * ESZ)
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(
@@ -576,6 +586,23 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     pk.x = __float_as_uint(v.x); pk.y = __float_as_uint(v.y); pk.z = __float_as_uint(v.z); pk.w = __float_as_uint(v.w);
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, off, 0, 0);
                 }
+                if constexpr (e_bnb) {               // v = the stored (rounded) gradient; z through the residual descriptor
+                    float4 zv;
+                    if constexpr (sizeof(ET) == 2) {
+                        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0);
+                        zv = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+                                         __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+                    } else {
+                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
+                        zv = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+                    }
+                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    v.x = (zv.x * b_sc.x + b_sh.x) > 0.f ? v.x : 0.f; v.y = (zv.y * b_sc.y + b_sh.y) > 0.f ? v.y : 0.f;
+                    v.z = (zv.z * b_sc.z + b_sh.z) > 0.f ? v.z : 0.f; v.w = (zv.w * b_sc.w + b_sh.w) > 0.f ? v.w : 0.f;
+                    st1.x += v.x; st1.y += v.y; st1.z += v.z; st1.w += v.w;
+                    st2.x += v.x * ((zv.x - b_mu.x) * b_rs.x); st2.y += v.y * ((zv.y - b_mu.y) * b_rs.y);
+                    st2.z += v.z * ((zv.z - b_mu.z) * b_rs.z); st2.w += v.w * ((zv.w - b_mu.w) * b_rs.w);
+                }
                 if (e_stats) {
                     if (!ok) v = kk;                     // rows past M contribute nothing
                     v.x -= kk.x; v.y -= kk.y; v.z -= kk.z; v.w -= kk.w;
@@ -585,7 +612,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             }
         }
     }
-    if (e_stats) {                                  // column sums over the RPP row-threads, fixed order, one writer per column
+    if (e_stats || e_bnb) {                         // column sums over the RPP row-threads, fixed order, one writer per column
         __syncthreads();
         float4* red = reinterpret_cast<float4*>(smem);
         red[(r0 * 2 + 0) * TPR + cq] = st1;
@@ -763,6 +790,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     // the epilogue addresses the output the same way (only a scattered data-gradient class can span whole images)
     MVF_REQUIRE(a.o_s <= 0 || (long)a.o_hfull * a.o_wfull * a.Cout * (long)sizeof(ET) * span_imgs < 0x7ffffff0L, MVF_EUNSUPPORTED,
                 "conv2d: output image too large for tile-relative 32-bit addressing");
+    MVF_REQUIRE(!a.bn_z || !(a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L), MVF_EUNSUPPORTED,
+                "conv2d_dgrad_bnsums: shape needs the generic kernel, which has no BatchNorm-backward epilogue");
     if (a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L || (long)a.Cout * a.wK * (long)sizeof(ET) >= 0x7ffffff0L) {
         auto kern_gen = conv_igemm_gen_kernel<ET, WM, WN, TM, TN>;
         static bool gen_attr = false;
@@ -783,14 +812,16 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         sk_wins = skh.ws && skh.ws_bytes >= sk_ws_bytes() && tail0 > 0 && (long)tail0 * a.nchunks >= slots &&
                   (1.0f - (float)tail0 / slots) * wave_us0 > 60.0f;
     }
-    if (a.nchunks <= g_lowk_max_chunks && !sk_wins) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
+    if (a.bn_z) sk_wins = false;                 // the BatchNorm-backward epilogue lives in the single-buffer kernel only
+    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();
         static const int epi_spec = getenv("MVF_CONV_EPI") ? atoi(getenv("MVF_CONV_EPI")) : 3;     // A/B switch: bit 0 epilogues, bit 1 pointwise loader
         const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
         const bool contiguous = (epi_spec & 1) && a.o_s <= 0;
         const bool train_like = contiguous && !a.bias && !a.relu;
         const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
-        if (train_like && a.stats_part && !a.res) launch_lowk<ET, WM, WN, TM, TN, 1>(pw, tiles, lds_lk, st, a);
+        if (train_like && a.stats_part && !a.res && !a.bn_z) launch_lowk<ET, WM, WN, TM, TN, 1>(pw, tiles, lds_lk, st, a);
+        else if (contiguous && a.bn_z && !a.bias && !a.relu && !a.res) launch_lowk<ET, WM, WN, TM, TN, 6>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && !a.res) launch_lowk<ET, WM, WN, TM, TN, 2>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && a.res) launch_lowk<ET, WM, WN, TM, TN, 3>(pw, tiles, lds_lk, st, a);
         else if (infer_like && !a.res) launch_lowk<ET, WM, WN, TM, TN, 4>(pw, tiles, lds_lk, st, a);
@@ -842,9 +873,22 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
     return mvf_conv2d_nhwc_fwd_ws(d, x, x2, w_packed, bias, residual, y, nullptr, 0, stream);
 }
 
+struct BnBwdSums {            // optional: the data gradient also accumulates the BatchNorm-backward sums of the BN it feeds
+    const void* z;
+    const float *mean, *invstd, *scale, *shift;
+};
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream, const unsigned char* res_mask = nullptr);
+                         void* stream, const unsigned char* res_mask = nullptr, const BnBwdSums* bnb = nullptr);
+
+int mvf_conv2d_nhwc_dgrad_bnsums(const mvf_conv_desc_t* d, const void* dz, const void* w_packed_dgrad, void* y, const void* bn_z,
+                                 const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
+                                 float* sums_part, void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && bn_z && bn_mean && bn_invstd && bn_scale && bn_shift && sums_part, MVF_EINVAL, "conv2d_dgrad_bnsums: NULL argument");
+    MVF_REQUIRE(d->in_dil <= 1, MVF_EUNSUPPORTED, "conv2d_dgrad_bnsums: stride-1 data gradients only (strided ones scatter parity classes)");
+    const BnBwdSums b = {bn_z, bn_mean, bn_invstd, bn_scale, bn_shift};
+    return conv_fwd_impl(d, dz, nullptr, w_packed_dgrad, nullptr, nullptr, y, sums_part, nullptr, ws, ws_bytes, stream, nullptr, &b);
+}
 
 int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                                 const void* residual, const unsigned char* res_sign_bits, void* y, void* ws, size_t ws_bytes,
@@ -872,7 +916,7 @@ int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const voi
 
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream, const unsigned char* res_mask) {
+                         void* stream, const unsigned char* res_mask, const BnBwdSums* bnb) {
     MVF_REQUIRE(d && x && w_packed && y, MVF_EINVAL, "conv2d: NULL argument");
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -915,6 +959,9 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     (void)esz;
     a.pad_w = d->pad; a.w_kh0 = 0; a.w_kw0 = 0; a.w_ts = 1; a.w_kwfull = d->kw;
     a.stats_part = stats_part; a.stats_shift = stats_shift;
+    if (bnb) {
+        a.bn_z = (const char*)bnb->z; a.bn_mean = bnb->mean; a.bn_invstd = bnb->invstd; a.bn_scale = bnb->scale; a.bn_shift = bnb->shift;
+    }
     hipStream_t st = (hipStream_t)stream;
     SkHost skh = {ws, ws_bytes};
     auto launch = [&](const ConvArgs& aa) -> int {

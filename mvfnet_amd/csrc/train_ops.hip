@@ -757,6 +757,13 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
     return MVF_OK;
 }
 
+int mvf_bn_bwd_finalize(const float* sums_part, int nblk, int c, float* dgamma, float* dbeta, void* stream) {
+    MVF_REQUIRE(sums_part && dgamma && dbeta && nblk > 0 && c > 0, MVF_EINVAL, "bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, (hipStream_t)stream, c, nblk, sums_part, dgamma, dbeta);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
 int mvf_bn_bwd_apply_masked(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* gamma,
                             const float* mean, const float* invstd, const float* scale, const float* shift, const float* dgamma,
                             const float* dbeta, int mask_mode, void* dz, int dtype, void* stream) {

@@ -102,12 +102,20 @@ class _BN(object):
                                     _p(rbn.shift if rbn else None), act, _p(out), _p(sb), self.eng.dt, _st()), "mvf_bn_apply")
         return (out, sb) if bits else out
 
-    def backward(self, g, g_pitch, z, m, eng, mask_mode, ymask=None, gm_out=None):
-        """dgamma/dbeta into the flat grad buffer; returns dz."""
+    def backward(self, g, g_pitch, z, m, eng, mask_mode, ymask=None, gm_out=None, sums_done=False):
+        """dgamma/dbeta into the flat grad buffer; returns dz.  sums_done: dgamma / dbeta were already produced by the data
+        gradient that wrote g (_TConv.dgrad_bnsums)."""
+        if not sums_done:
+            self._reduce(g, g_pitch, z, m, eng, mask_mode, ymask, gm_out)
+        return self._apply_bwd(g, g_pitch, z, m, eng, mask_mode, ymask, gm_out)
+
+    def _reduce(self, g, g_pitch, z, m, eng, mask_mode, ymask, gm_out):
         ws = eng.workspace(lib.mvf_bn_workspace_bytes(m, self.c))
         check(lib.mvf_bn_bwd_reduce(_p(g), g_pitch, _p(z), _p(ymask), m, self.c, _p(self.mean), _p(self.invstd), _p(self.scale),
                                     _p(self.shift), mask_mode, _p(gm_out), _p(self.dgamma), _p(self.dbeta), _p(ws), ws.numel(), eng.dt, _st()),
               "mvf_bn_bwd_reduce")
+
+    def _apply_bwd(self, g, g_pitch, z, m, eng, mask_mode, ymask, gm_out):
         src, pitch, mode = (gm_out, self.c, 0) if gm_out is not None else (g, g_pitch, mask_mode)
         dz = eng.buf((id(self), "dz"), z.shape, z.dtype)
         check(lib.mvf_bn_bwd_apply_masked(_p(src), pitch, _p(z), _p(ymask) if mode in (1, 4) else None, m, self.c, _p(self.gamma), _p(self.mean),
@@ -202,6 +210,23 @@ class _TConv(object):
             check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
         eng.on_side(launch)
         # dz / x / x2 are persistent engine buffers (eng.buf) or tensors the caller keeps alive until join_side()
+
+    def dgrad_bnsums(self, dz, n, ho, wo, h, w, bn, z):
+        """Stride-1 data gradient that also accumulates the backward sums of `bn` (the ReLU(BN(z)) its output feeds) in its
+        epilogue and finalises dgamma / dbeta: bn.backward(..., sums_done=True) then only needs the apply pass."""
+        d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, self.eng.dt, 0, 0, 0, 0, 0)
+        dx = self.eng.buf((id(self), "dx"), (n * h * w, self.cin))
+        ws = _conv_ws(dz.device)
+        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        part = self.eng.buf((id(self), "bnsums"), (rows, self.cin, 2), torch.float32)
+        self.launch_dgrad_bnsums(d, dz, dx, z, bn, part, ws)
+        check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cin, _p(bn.dgamma), _p(bn.dbeta), _st()), "bn bwd finalize")
+        return dx
+
+    def launch_dgrad_bnsums(self, d, dz, dx, z, bn, part, ws):
+        """Exactly one implicit-GEMM launch (bench.py brackets this call with HIP events)."""
+        check(lib.mvf_conv2d_nhwc_dgrad_bnsums(C.byref(d), _p(dz), _p(self.wd), _p(dx), _p(z), _p(bn.mean), _p(bn.invstd), _p(bn.scale), _p(bn.shift),
+                                               _p(part), _p(ws), ws.numel(), _st()), "conv dgrad+bn sums")
 
     def dgrad(self, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
         """dx (n*h*w, cin) from dz (n*ho*wo, cout): a conv of dz with the flipped/transposed weights (+ residual, on output
@@ -336,15 +361,23 @@ class _TBlock(object):
         # moves on to the (HBM-bound) BatchNorm-backward kernels of the next layer -- MFMA work under memory work --
         # instead of fighting the data-gradient GEMM for the matrix cores.
         dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 4, ymask=bits)
-        da2 = self.c3.dgrad(dz3, nt, ho, wo, ho, wo)
+        fuse = eng.fuse_bn_bwd_sums
+        if fuse:       # the data gradient's epilogue also produces the BatchNorm-backward sums of the BN its output feeds
+            da2 = self.c3.dgrad_bnsums(dz3, nt, ho, wo, ho, wo, self.b2, s["z2"])
+        else:
+            da2 = self.c3.dgrad(dz3, nt, ho, wo, ho, wo)
         self.c3.wgrad(dz3, s["a2"], nt, ho, wo, ho, wo, eng)
         del dz3
-        dz2 = self.b2.backward(da2, self.c2.cout, s["z2"], m2, eng, 2)
+        dz2 = self.b2.backward(da2, self.c2.cout, s["z2"], m2, eng, 2, sums_done=fuse)
         del da2
-        da1 = self.c2.dgrad(dz2, nt, ho, wo, h, w)
+        fuse1 = fuse and self.c2.stride == 1
+        if fuse1:
+            da1 = self.c2.dgrad_bnsums(dz2, nt, ho, wo, h, w, self.b1, s["z1"])
+        else:
+            da1 = self.c2.dgrad(dz2, nt, ho, wo, h, w)
         self.c2.wgrad(dz2, s["a1"], nt, h, w, ho, wo, eng)
         del dz2
-        dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2)
+        dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2, sums_done=fuse1)
         del da1
         resid, rbits = g, bits
         if self.cd is not None:
@@ -439,6 +472,7 @@ class _ParamStore(object):
 
     overlap_wgrad = True
     fuse_stats = True          # BatchNorm batch statistics accumulated in the producing conv's epilogue
+    fuse_bn_bwd_sums = os.environ.get("MVF_FUSE_BN_BWD", "1") != "0"    # ... and the backward sums in the data gradient's
 
     def side_stream(self):
         if not self.overlap_wgrad:
