@@ -133,6 +133,42 @@ def test_bn_sign_bits_equal_the_tensor_mask(mc, dtype):
         assert torch.equal(o1[:, :cs], o2[:, :cs])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 9, 7, 256, 64, 1), (3, 10, 10, 64, 64, 3), (1, 20, 20, 128, 128, 3)], ids=str)
+def test_dgrad_bnsums_equals_separate_reduce(shape, dtype):
+    """mvf_conv2d_nhwc_dgrad_bnsums: same data gradient bit for bit, and the epilogue's BatchNorm-backward sums equal
+    mvf_bn_bwd_reduce (mask mode 2) on that output."""
+    from mvfnet_amd import _lib
+    from mvfnet_amd._lib import ConvDesc
+    lib, check = _lib.lib, _lib.check
+    n, h, w, cout, cin, k = shape
+    dt = 0 if dtype == torch.float32 else 1
+    g = torch.Generator().manual_seed(1)
+    pad, m = k // 2, n * h * w
+    dz = (torch.randn(m, cout, generator=g) * 0.5).to(dtype).cuda()
+    wgt = (torch.randn(cout, cin, k, k, generator=g) * 0.05).cuda()
+    wd = torch.empty(cin, k, k, cout, dtype=dtype, device="cuda")
+    check(lib.mvf_pack_conv_weight_dgrad(P(wgt), cout, cin, k, k, P(wd), dt, None))
+    z = torch.randn(m, cin, generator=g).to(dtype).cuda()
+    mean, invstd = torch.randn(cin, generator=g).cuda() * 0.1, (torch.rand(cin, generator=g) + 0.5).cuda()
+    scale, shift = (torch.rand(cin, generator=g) + 0.5).cuda(), torch.randn(cin, generator=g).cuda() * 0.3
+    d = ConvDesc(n, h, w, cout, cin, k, k, 1, k - 1 - pad, h, w, cout, dt, 0, 0, 0, 0, 0)
+    ws = torch.zeros(max(lib.mvf_conv2d_workspace_bytes(C.byref(d)), 1), dtype=torch.uint8, device="cuda")
+    y1, y2 = torch.empty(m, cin, dtype=dtype, device="cuda"), torch.empty(m, cin, dtype=dtype, device="cuda")
+    rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+    part = torch.zeros(rows, cin, 2, device="cuda")
+    check(lib.mvf_conv2d_nhwc_dgrad_bnsums(C.byref(d), P(dz), P(wd), P(y1), P(z), P(mean), P(invstd), P(scale), P(shift), P(part), P(ws), ws.numel(), None))
+    dg, db = torch.empty(cin, device="cuda"), torch.empty(cin, device="cuda")
+    check(lib.mvf_bn_bwd_finalize(P(part), rows, cin, P(dg), P(db), None))
+    check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(dz), None, P(wd), None, None, P(y2), P(ws), ws.numel(), None))
+    ws2 = torch.empty(lib.mvf_bn_workspace_bytes(m, cin), dtype=torch.uint8, device="cuda")
+    dg2, db2 = torch.empty(cin, device="cuda"), torch.empty(cin, device="cuda")
+    check(lib.mvf_bn_bwd_reduce(P(y2), cin, P(z), None, m, cin, P(mean), P(invstd), P(scale), P(shift), 2, None, P(dg2), P(db2), P(ws2), ws2.numel(), dt, None))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    assert rel_err(dg.cpu().numpy(), dg2.cpu().numpy()) < 2e-6 and rel_err(db.cpu().numpy(), db2.cpu().numpy()) < 2e-6
+
+
 # (n, h, w, cin, cout, k, stride, pad)
 GRAD_CASES = [(2, 8, 8, 64, 32, 1, 1, 0), (2, 9, 9, 32, 64, 3, 1, 1), (2, 10, 10, 32, 32, 3, 2, 1), (3, 8, 8, 64, 128, 1, 2, 0),
               (1, 14, 14, 256, 256, 3, 1, 1), (2, 7, 7, 132, 36, 3, 1, 1),
