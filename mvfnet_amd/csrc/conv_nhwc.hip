@@ -208,6 +208,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
 #pragma unroll
         for (int i = 0; i < A_ROWS_PT; ++i) {
             const int m = m0 + lrow + 32 * i;
+            if constexpr (PW) {
+                if (a.stride == 1) {             // pointwise stride 1: input pixel == output pixel, no division at all
+                    a_off[i] = m < a.M ? (unsigned)((m - img0 * hw_o) * a.xps + q * UE) * ESZ : kOOB;
+                    a_off2[i] = 0u; hmask[i] = 0u; wmask[i] = 0u;
+                    continue;
+                }
+            }
             const int img = fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * hw_o;
             const int oh = fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
             const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad_w;
