@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tests/golden")
+import os; R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R, os.path.join(R, "tests"), os.path.join(R, "tests", "golden")]
 from helpers import rel_l2
 from mvfnet_amd import synth
 import mvfnet_amd

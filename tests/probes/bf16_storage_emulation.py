@@ -1,7 +1,7 @@
 """CPU: how far does bf16 STORAGE alone move the oracle's stage outputs?  (conv inputs/weights/outputs and BN outputs rounded
 to bf16, fp32 arithmetic otherwise) -- the yardstick for the engine's bf16 deviation on the same synthetic network."""
 import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os; R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R, os.path.join(R, "tests")]
 from helpers import rel_l2
 from mvfnet_amd import synth, arch
 from oracle import net_torch

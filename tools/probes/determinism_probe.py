@@ -1,7 +1,7 @@
 """Race detector: the training step has no atomics, so N steps with the side-stream overlap must be BIT-identical to N steps
 with every kernel on one stream.  python tools/probes/determinism_probe.py [steps] [dtype]"""
 import sys, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os; R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R, os.path.join(R, "tests")]
 from mvfnet_amd import synth
 import mvfnet_amd
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
