@@ -26,6 +26,7 @@
 //  * XCD-aware tile order: the 8 XCDs get contiguous ranges of (m-tile, n-tile) pairs with n fastest, so the
 //    n-tiles that re-read one A row panel run on the same XCD and hit its L2.
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.h"
@@ -537,17 +538,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     *reinterpret_cast<float4*>(cp + g * 32) =
                         make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
             }
-        __syncthreads();
+        // Phase A, before the C-tile barrier: every row's output offset and its residual (or, for the BatchNorm-sum epilogue,
+        // z) load are issued here, all at once -- rows past M / columns past Cout get an out-of-range buffer offset (loads
+        // return 0, stores are dropped), so nothing below branches on them and one memory round trip covers the whole half
+        // tile instead of one per row.
+        constexpr int NPS = HR / RPP;
+        typedef typename std::conditional<sizeof(ET) == 2, u32x2, u32x4>::type raw_t;
+        unsigned offs[NPS];
+        raw_t rraw[NPS];
         {
-            // branch-free rows: out-of-range rows / columns get an out-of-range buffer offset (loads return 0, stores are dropped),
-            // so the residual loads of the unrolled rows can all be issued ahead of their use
             const int mrow0 = m0 + hf * HR + r0;
             const bool cok2 = col < a.Cout;              // Cout % 4 == 0 (checked on the host)
-#pragma unroll 4
-            for (int ps = 0; ps < HR / RPP; ++ps) {
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
                 const int m = mrow0 + ps * RPP;
-                const bool ok = cok2 && m < a.M;
-                float4 v = *reinterpret_cast<const float4*>(smem + (r0 + ps * RPP) * CP + cq * 16);
                 unsigned off;
                 if (e_scatter) {                         // strided data-gradient class: scatter into the full-resolution map
                     const int img = fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * (a.Ho * a.Wo);
@@ -556,22 +560,34 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 } else {
                     off = (unsigned)((m - m0) * a.Cout + col) * ESZ;
                 }
-                off = ok ? off : kOOB;
+                offs[ps] = (cok2 && m < a.M) ? off : kOOB;
+                if (e_res || e_bnb) {
+                    const unsigned roff = (e_bnb || col >= a.res_c0) ? offs[ps] : kOOB;       // skipped columns read zeros
+                    if constexpr (sizeof(ET) == 2) rraw[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, roff, 0, 0);
+                    else rraw[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            auto unpack = [](const raw_t& t) {
+                if constexpr (sizeof(ET) == 2)
+                    return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                                       __uint_as_float(t.y & 0xffff0000u));
+                else
+                    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+            };
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const unsigned off = offs[ps];
+                const bool ok = off != kOOB;
+                float4 v = *reinterpret_cast<const float4*>(smem + (r0 + ps * RPP) * CP + cq * 16);
                 if (e_bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
                 if (e_res) {
-                    float4 rv;
-                    const unsigned roff = col >= a.res_c0 ? off : kOOB;       // skipped columns read zeros
-                    if constexpr (sizeof(ET) == 2) {
-                        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_res, roff, 0, 0);
-                        rv = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
-                                         __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
-                    } else {
-                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0);
-                        rv = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
-                    }
+                    float4 rv = unpack(rraw[ps]);
                     if (a.res_mask) {
                         const unsigned mb = mask_lds ? (unsigned)*reinterpret_cast<const unsigned char*>(smem + kMaskOff + (hf * HR + r0 + ps * RPP) * (BN / 4) + cq)
-                                                     : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, roff == kOOB ? kOOB : roff / (4 * ESZ), 0, 0);
+                                                     : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, ok ? off / (4 * ESZ) : kOOB, 0, 0);
                         rv.x = (mb & 1u) ? rv.x : 0.f; rv.y = (mb & 2u) ? rv.y : 0.f;
                         rv.z = (mb & 4u) ? rv.z : 0.f; rv.w = (mb & 8u) ? rv.w : 0.f;
                     }
@@ -593,16 +609,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     pk.x = __float_as_uint(v.x); pk.y = __float_as_uint(v.y); pk.z = __float_as_uint(v.z); pk.w = __float_as_uint(v.w);
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, off, 0, 0);
                 }
-                if constexpr (e_bnb) {               // v = the stored (rounded) gradient; z through the residual descriptor
-                    float4 zv;
-                    if constexpr (sizeof(ET) == 2) {
-                        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0);
-                        zv = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
-                                         __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
-                    } else {
-                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
-                        zv = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
-                    }
+                if constexpr (e_bnb) {               // v = the stored (rounded) gradient; z was fetched in phase A
+                    const float4 zv = unpack(rraw[ps]);
                     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     v.x = (zv.x * b_sc.x + b_sh.x) > 0.f ? v.x : 0.f; v.y = (zv.y * b_sc.y + b_sh.y) > 0.f ? v.y : 0.f;
                     v.z = (zv.z * b_sc.z + b_sh.z) > 0.f ? v.z : 0.f; v.w = (zv.w * b_sc.w + b_sh.w) > 0.f ? v.w : 0.f;
