@@ -89,19 +89,25 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply(NhwcArgs a) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) prev[i] = 0.f;
         Vec<ET, VEC>::load(x + e0, cur);
+        // neighbour validity is per thread, constant over t: out-of-range neighbours re-read the centre pixel (always valid)
+        // and are zeroed afterwards, so the five loads of a t-step are unconditional and go out back to back (a conditional
+        // load each cost its own memory round trip: the compiler waits at every join)
+        const bool ok_up = vh && hh > 0, ok_dn = vh && hh < H - 1, ok_lf = vw && wv > 0, ok_rt = vw && wv < W - 1;
+        const long d_up = ok_up ? -(long)W * C : 0, d_dn = ok_dn ? (long)W * C : 0, d_lf = ok_lf ? -(long)C : 0, d_rt = ok_rt ? (long)C : 0;
         for (int t = 0; t < T; ++t) {
             const ET* f = x + e0 + (long)t * fstride;
-            if (t + 1 < T) Vec<ET, VEC>::load(f + fstride, next);
-            else {
+            const bool ok_nx = t + 1 < T;
+            Vec<ET, VEC>::load(f + (ok_nx ? fstride : 0), next);
+            Vec<ET, VEC>::load(f + d_up, up);
+            Vec<ET, VEC>::load(f + d_dn, dn);
+            Vec<ET, VEC>::load(f + d_lf, lf);
+            Vec<ET, VEC>::load(f + d_rt, rt);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) next[i] = 0.f;
+            for (int i = 0; i < VEC; ++i) {
+                next[i] = ok_nx ? next[i] : 0.f;
+                up[i] = ok_up ? up[i] : 0.f; dn[i] = ok_dn ? dn[i] : 0.f;
+                lf[i] = ok_lf ? lf[i] : 0.f; rt[i] = ok_rt ? rt[i] : 0.f;
             }
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) up[i] = dn[i] = lf[i] = rt[i] = 0.f;
-            if (vh && hh > 0) Vec<ET, VEC>::load(f - (long)W * C, up);
-            if (vh && hh < H - 1) Vec<ET, VEC>::load(f + (long)W * C, dn);
-            if (vw && wv > 0) Vec<ET, VEC>::load(f - C, lf);
-            if (vw && wv < W - 1) Vec<ET, VEC>::load(f + C, rt);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 float yt = wt[i][0] * prev[i] + wt[i][1] * cur[i] + wt[i][2] * next[i];
