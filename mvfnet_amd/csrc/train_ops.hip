@@ -445,29 +445,43 @@ __global__ void maxpool_bn_fwd_kernel(const ET* z, int n, int h, int w, int c, i
     const int c4 = c >> 2;
     const long total = (long)n * ho * wo * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cq = (int)(i % c4);
-        long t = i / c4;
-        const int ow = (int)(t % wo); t /= wo;
-        const int oh = (int)(t % ho);
-        const int img = (int)(t / ho);
+        int cq, ow, oh, img;
+        if (total <= 0x7fffffffL) {
+            unsigned t = (unsigned)i;
+            cq = (int)(t % (unsigned)c4); t /= (unsigned)c4;
+            ow = (int)(t % (unsigned)wo); t /= (unsigned)wo;
+            oh = (int)(t % (unsigned)ho);
+            img = (int)(t / (unsigned)ho);
+        } else {
+            cq = (int)(i % c4);
+            long t = i / c4;
+            ow = (int)(t % wo); t /= wo;
+            oh = (int)(t % ho);
+            img = (int)(t / ho);
+        }
         const float4 s = *reinterpret_cast<const float4*>(scale + cq * 4), b = *reinterpret_cast<const float4*>(shift + cq * 4);
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         unsigned am[4] = {0, 0, 0, 0};                    // window position (dy*3+dx) of the FIRST max, as ATen picks it
-        for (int dy = 0; dy < 3; ++dy) {
-            const int ih = oh * 2 - 1 + dy;
-            if (ih < 0 || ih >= h) continue;
-            for (int dx = 0; dx < 3; ++dx) {
-                const int iw = ow * 2 - 1 + dx;
-                if (iw < 0 || iw >= w) continue;
-                float4 v = ld4(z + (((long)img * h + ih) * w + iw) * c + cq * 4);
-                v.x = fmaxf(v.x * s.x + b.x, 0.f); v.y = fmaxf(v.y * s.y + b.y, 0.f);
-                v.z = fmaxf(v.z * s.z + b.z, 0.f); v.w = fmaxf(v.w * s.w + b.w, 0.f);
-                const unsigned code = dy * 3 + dx;
-                if (v.x > m.x) { m.x = v.x; am[0] = code; }
-                if (v.y > m.y) { m.y = v.y; am[1] = code; }
-                if (v.z > m.z) { m.z = v.z; am[2] = code; }
-                if (v.w > m.w) { m.w = v.w; am[3] = code; }
-            }
+        // the nine window loads are unconditional (out-of-image taps re-read a clamped pixel and are skipped in the compare):
+        // with a branch per tap the compiler waits for every load before issuing the next (nine serial round trips)
+        float4 win[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int ih = oh * 2 - 1 + k / 3, iw = ow * 2 - 1 + k % 3;
+            const int ihc = min(max(ih, 0), h - 1), iwc = min(max(iw, 0), w - 1);
+            win[k] = ld4(z + (((long)img * h + ihc) * w + iwc) * c + cq * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int ih = oh * 2 - 1 + k / 3, iw = ow * 2 - 1 + k % 3;
+            const bool in = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
+            float4 v = win[k];
+            v.x = fmaxf(v.x * s.x + b.x, 0.f); v.y = fmaxf(v.y * s.y + b.y, 0.f);
+            v.z = fmaxf(v.z * s.z + b.z, 0.f); v.w = fmaxf(v.w * s.w + b.w, 0.f);
+            if (in && v.x > m.x) { m.x = v.x; am[0] = k; }
+            if (in && v.y > m.y) { m.y = v.y; am[1] = k; }
+            if (in && v.z > m.z) { m.z = v.z; am[2] = k; }
+            if (in && v.w > m.w) { m.w = v.w; am[3] = k; }
         }
         const long oidx = (((long)img * ho + oh) * wo + ow) * c + cq * 4;
         st4(y + oidx, m);
@@ -483,26 +497,44 @@ __global__ void maxpool_bn_bwd_kernel(const unsigned char* amax, const ET* g, in
     const int c4 = c >> 2;
     const long total = (long)n * h * w * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cq = (int)(i % c4);
-        long t = i / c4;
-        const int iw = (int)(t % w); t /= w;
-        const int ih = (int)(t % h);
-        const int img = (int)(t / h);
+        int cq, iw, ih, img;
+        if (total <= 0x7fffffffL) {                       // 32-bit index math (64-bit division by a runtime value is ~100 instructions)
+            unsigned t = (unsigned)i;
+            cq = (int)(t % (unsigned)c4); t /= (unsigned)c4;
+            iw = (int)(t % (unsigned)w); t /= (unsigned)w;
+            ih = (int)(t % (unsigned)h);
+            img = (int)(t / (unsigned)h);
+        } else {
+            cq = (int)(i % c4);
+            long t = i / c4;
+            iw = (int)(t % w); t /= w;
+            ih = (int)(t % h);
+            img = (int)(t / h);
+        }
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {                 // windows with oh*2-1 <= ih <= oh*2+1
-            if (oh >= ho) continue;
-            const unsigned dy = ih - (oh * 2 - 1);
-            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
-                if (ow >= wo) continue;
-                const unsigned me = dy * 3 + (iw - (ow * 2 - 1));
-                const long oidx = (((long)img * ho + oh) * wo + ow) * c + cq * 4;
-                const unsigned am = *reinterpret_cast<const unsigned*>(amax + oidx);
-                const float4 gv = ld4(g + oidx);
-                if ((am & 255u) == me) acc[0] += gv.x;
-                if (((am >> 8) & 255u) == me) acc[1] += gv.y;
-                if (((am >> 16) & 255u) == me) acc[2] += gv.z;
-                if ((am >> 24) == me) acc[3] += gv.w;
-            }
+        // the (<= 4) covering windows: oh in {ih/2, (ih+1)/2}, ow likewise (the second differs only for odd coordinates);
+        // all eight loads are issued unconditionally on clamped indices, invalid candidates are masked in the compare
+        unsigned amv[4];
+        float4 gvv[4];
+        bool okv[4];
+        unsigned mev[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oh = (ih + (k >> 1)) >> 1, ow = (iw + (k & 1)) >> 1;
+            okv[k] = oh < ho && ow < wo && ((k >> 1) == 0 || (ih & 1)) && ((k & 1) == 0 || (iw & 1));
+            const int ohc = min(oh, ho - 1), owc = min(ow, wo - 1);
+            mev[k] = (unsigned)(ih - (oh * 2 - 1)) * 3u + (unsigned)(iw - (ow * 2 - 1));
+            const long oidx = (((long)img * ho + ohc) * wo + owc) * c + cq * 4;
+            amv[k] = *reinterpret_cast<const unsigned*>(amax + oidx);
+            gvv[k] = ld4(g + oidx);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned am = amv[k], me = mev[k];
+            if (okv[k] && (am & 255u) == me) acc[0] += gvv[k].x;
+            if (okv[k] && ((am >> 8) & 255u) == me) acc[1] += gvv[k].y;
+            if (okv[k] && ((am >> 16) & 255u) == me) acc[2] += gvv[k].z;
+            if (okv[k] && (am >> 24) == me) acc[3] += gvv[k].w;
         }
         st4(ga + i * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
