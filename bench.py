@@ -127,12 +127,16 @@ def _summ(rec, per_layer, tag):
     if per_layer:
         agg = {}
         for r in rec:
-            a = agg.setdefault(r[3], [0, 0.0, 0.0])
+            a = agg.setdefault(r[3], [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += r[0].elapsed_time(r[1])
             a[2] += r[2]
-        for k, (cnt, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-            print("  %-6s %-44s x%-2d %8.3f ms  %7.1f TF/s" % (tag, k, cnt, t, f / t / 1e9), file=sys.stderr)
+            a[3] += r[4]
+        # "bound" = the larger of bytes / 6.3 TB/s (measured HBM ceiling) and flops / 2.5 PF; "over" = time above it
+        rows = [(k, cnt, t, f, b, max(b / 6.3e9, f / 2.5e12)) for k, (cnt, t, f, b) in agg.items()]
+        for k, cnt, t, f, b, lo in sorted(rows, key=lambda r: -(r[2] - r[5]))[:48]:
+            print("  %-6s %-40s x%-2d %7.3f ms %6.1f TF/s %5.2f TB/s  bound %6.3f  over %6.3f" % (tag, k, cnt, t, f / t / 1e9, b / t / 1e9, lo, t - lo),
+                  file=sys.stderr)
     return ms, fl, by, len(rec)
 
 

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -103,6 +104,31 @@ __host__ __device__ constexpr int kLowkLds() {
     return (BM + BN) * kPitch > (BM / 2) * (BN * 4 + 16) + BM * (BN / 4) ? (BM + BN) * kPitch : (BM / 2) * (BN * 4 + 16) + BM * (BN / 4);
 }
 
+// LDS-DMA issued from inline asm: hipcc counts a builtin LDS-DMA as a pending LDS write and drains it (vmcnt(0)) before the
+// next ds_read -- exactly the overlap this variant exists for -- so the statement is hidden from its bookkeeping and the loop
+// waits for it explicitly (cdna_hip_programming.md, "What hipcc does not do" item 1).  M0 = wave-uniform LDS byte address.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 rsrc_words(const void* base, unsigned nbytes) {
+    const unsigned long p = (unsigned long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)nbytes);
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void glds16(const i32x4 rs, const unsigned lds_dst, const unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
+}
+
+// dynamic LDS of the LDS-DMA variant: NB unpadded A/B tile buffers (128-B rows), or the half C tile + gate bytes
+template <int BM, int BN, int NB>
+__host__ __device__ constexpr int kGldsLds() {
+    return NB * (BM + BN) * 128 > (BM / 2) * (BN * 4 + 16) + BM * (BN / 4) ? NB * (BM + BN) * 128 : (BM / 2) * (BN * 4 + 16) + BM * (BN / 4);
+}
+
 // What a workgroup does with the accumulators of one (tile, chunk range) segment
 enum SegMode { SEG_FULL = 0, SEG_PRODUCE = 1, SEG_FINISH = 2 };
 
@@ -122,25 +148,36 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
 // 6 plain data gradient + the BatchNorm-backward sums of the BN it feeds.  1-6 imply contiguous output rows (no scatter).
 // PW specialises the loader for pointwise launches (1x1 taps, no padding, no split operand): a row is either valid for every
 // chunk or never, so the tap masks and the second operand's offsets disappear.
-template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0, bool PW = false>
+// GLDS = N > 0: the A/B tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds; no staging VGPRs, no ds_write pass, which
+// at ~79 B/clk/CU is what bounds the register-staged loop on the long-K layers) into N unpadded buffers.  The DMA writes
+// lane-linearly (M0 base + 16 * lane), so a wave instruction lands 8 rows x 128 B; the bank-conflict-free image is made on the
+// SOURCE side: position p of row r holds the 16-byte unit p ^ ((r >> 1) & 7), and the operand fetch applies the same XOR.
+// Out-of-range buffer offsets DMA zeros (tools/probes/glds_probe.hip), so padding taps stay branch-free.
+template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0, bool PW = false, int GLDS = 0>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    static_assert(BM == kBM, "BM must be 128");
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(BM == kBM || (BM == 2 * kBM && GLDS == 3), "BM is 128 (256 for the 8-wave LDS-DMA tile)");
+    static_assert(WM * WN == 4 || (WM * WN == 8 && GLDS == 3), "4 waves (8 for the big tile)");
+    constexpr int NT = WM * WN * 64;        // threads per workgroup
+    constexpr int RP = NT / 8;              // rows per loader pass (8 lanes x 16 B per row)
     constexpr int ESZ = TT<ET>::ESZ, UE = TT<ET>::UE, CE = TT<ET>::CE;
-    constexpr int A_ROWS_PT = BM / 32;      // rows per thread in the A loader (256 thr = 32 rows x 8 units)
-    constexpr int B_ROWS_PT = BN / 32;
+    constexpr int A_ROWS_PT = BM / RP;      // rows per thread in the A loader (256 thr = 32 rows x 8 units)
+    constexpr int B_ROWS_PT = BN / RP;
     __syncthreads();                                   // LDS hand-over from a previous segment of this workgroup
-    constexpr int NBUF = LOWK ? 1 : 2;
-    char* As = smem;                                   // [NBUF][BM][kPitch]
-    char* Bs = smem + NBUF * BM * kPitch;              // [NBUF][BN][kPitch]
+    static_assert(!GLDS || (!GEN && !PF2 && !LOWK), "the LDS-DMA loop is its own variant");
+    constexpr int NBUF = GLDS ? GLDS : (LOWK ? 1 : 2);
+    constexpr int PITCH = GLDS ? 128 : kPitch;         // LDS-DMA rows are unpadded (lane-linear destination)
+    constexpr int kSmem = GLDS ? kGldsLds<BM, BN, GLDS ? GLDS : 1>() : (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch);
+    char* As = smem;                                   // [NBUF][BM][PITCH]
+    char* Bs = smem + NBUF * BM * PITCH;               // [NBUF][BN][PITCH]
 
     const int tn_i = tile % a.tiles_n, tm_i = tile / a.tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int lrow = tid >> 3, q = tid & 7;            // loader: row-in-32, 16-B unit within the 128-B chunk
+    const int lrow = tid >> 3;                         // loader: row-in-32, 16-B unit within the 128-B chunk
+    const int q = GLDS ? ((tid & 7) ^ ((lrow >> 1) & 7)) : (tid & 7);     // LDS-DMA: the unit that belongs at position tid & 7
 
     // ---- per-thread loader state (rows are fixed for the whole K loop) ----
     struct Stage {                       // one K chunk of this thread's loader rows, in registers
@@ -172,10 +209,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     constexpr unsigned kOOB = 0x80000000u;
     unsigned a_off[A_ROWS_PT], a_off2[A_ROWS_PT], hmask[A_ROWS_PT], wmask[A_ROWS_PT], b_off[B_ROWS_PT];
     __amdgpu_buffer_rsrc_t rs_x, rs_x2, rs_w;
+    i32x4 gs_x = {0, 0, 0, 0}, gs_x2 = gs_x, gs_w = gs_x;      // the same descriptors as plain SGPR words (LDS-DMA asm operands)
     if constexpr (GEN) {
 #pragma unroll
         for (int i = 0; i < A_ROWS_PT; ++i) {
-            const int m = m0 + lrow + 32 * i;
+            const int m = m0 + lrow + RP * i;
             if (m < a.M) {
                 const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
                 const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
@@ -190,7 +228,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS_PT; ++i) {
-            const int co = n0 + lrow + 32 * i;
+            const int co = n0 + lrow + RP * i;
             b_ok[i] = co < a.Cout;
             b_ptr[i] = a.w + ((long)(b_ok[i] ? co : 0) * a.wK + q * UE) * ESZ;
         }
@@ -206,9 +244,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         rs_x2 = rs_x;
         if (a.split_c > 0) rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 + (long)img0 * img_px * a.x2ps * ESZ), 0, span(a.x2ps), 0x00020000);
         rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)((long)a.Cout * a.wK * ESZ), 0x00020000);
+        if constexpr (GLDS > 0) {
+            gs_x = rsrc_words(a.x + (long)img0 * img_px * a.xps * ESZ, span(a.xps));
+            gs_x2 = gs_x;
+            if (a.split_c > 0) gs_x2 = rsrc_words(a.x2 + (long)img0 * img_px * a.x2ps * ESZ, span(a.x2ps));
+            gs_w = rsrc_words(a.w, (unsigned)((long)a.Cout * a.wK * ESZ));
+        }
 #pragma unroll
         for (int i = 0; i < A_ROWS_PT; ++i) {
-            const int m = m0 + lrow + 32 * i;
+            const int m = m0 + lrow + RP * i;
             if constexpr (PW) {
                 if (a.stride == 1) {             // pointwise stride 1: input pixel == output pixel, no division at all
                     a_off[i] = m < a.M ? (unsigned)((m - img0 * hw_o) * a.xps + q * UE) * ESZ : kOOB;
@@ -239,13 +283,16 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS_PT; ++i) {
-            const int co = n0 + lrow + 32 * i;
+            const int co = n0 + lrow + RP * i;
             b_off[i] = co < a.Cout ? (unsigned)((long)co * a.wK + q * UE) * ESZ : kOOB;
         }
     }
 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    auto load_chunk = [&](Stage& st) {
+    const unsigned lds_a0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)As + wave * 8 * PITCH);
+    const unsigned lds_b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)Bs + wave * 8 * PITCH);
+    auto load_chunk = [&](Stage& st, int buf = 0) {
+        (void)buf;
         const int ci = cc * CE + q * UE;                       // first channel of this thread's unit
         const bool cok = ci < a.Cin;
         const bool from2 = (a.split_c > 0) && (cc * CE < a.split_c);
@@ -294,25 +341,33 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     const bool ok = ((hmask[i] >> kh) & (wmask[i] >> kw) & 1u) != 0u;
                     voff = ok ? (((from2 ? a_off2[i] : a_off[i]) + toff) | cbad) : kOOB;
                 }
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(PW ? rs_x : rs, voff, 0, 0);
-                st.a[i] = make_uint4(v.x, v.y, v.z, v.w);
+                if constexpr (GLDS > 0) {
+                    glds16((PW || !from2) ? gs_x : gs_x2, lds_a0 + (unsigned)((buf * BM + RP * i) * PITCH), voff);
+                } else {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(PW ? rs_x : rs, voff, 0, 0);
+                    st.a[i] = make_uint4(v.x, v.y, v.z, v.w);
+                }
             }
             const unsigned koff = (unsigned)(((a.w_kh0 + kh * a.w_ts) * a.w_kwfull + (a.w_kw0 + kw * a.w_ts)) * a.Cin + cc * CE) * ESZ;
 #pragma unroll
             for (int i = 0; i < B_ROWS_PT; ++i) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (b_off[i] + koff) | cbad, 0, 0);
-                st.b[i] = make_uint4(v.x, v.y, v.z, v.w);
+                if constexpr (GLDS > 0) {
+                    glds16(gs_w, lds_b0 + (unsigned)((buf * BN + RP * i) * PITCH), (b_off[i] + koff) | cbad);
+                } else {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (b_off[i] + koff) | cbad, 0, 0);
+                    st.b[i] = make_uint4(v.x, v.y, v.z, v.w);
+                }
             }
         }
         advance();
     };
     auto store_chunk = [&](int buf, const Stage& st) {
-        char* ad = As + buf * BM * kPitch + lrow * kPitch + q * 16;
+        char* ad = As + buf * BM * PITCH + lrow * PITCH + q * 16;
 #pragma unroll
-        for (int i = 0; i < A_ROWS_PT; ++i) *reinterpret_cast<uint4*>(ad + 32 * i * kPitch) = st.a[i];
-        char* bd = Bs + buf * BN * kPitch + lrow * kPitch + q * 16;
+        for (int i = 0; i < A_ROWS_PT; ++i) *reinterpret_cast<uint4*>(ad + RP * i * PITCH) = st.a[i];
+        char* bd = Bs + buf * BN * PITCH + lrow * PITCH + q * 16;
 #pragma unroll
-        for (int i = 0; i < B_ROWS_PT; ++i) *reinterpret_cast<uint4*>(bd + 32 * i * kPitch) = st.b[i];
+        for (int i = 0; i < B_ROWS_PT; ++i) *reinterpret_cast<uint4*>(bd + RP * i * PITCH) = st.b[i];
     };
 
     f32x16 acc[TM][TN];
@@ -324,17 +379,22 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nseg = c_end - c_begin;
-    const int frag_off = (lane & 31) * kPitch + (lane >> 5) * 16;
+    const int frag_off = (lane & 31) * PITCH + (GLDS ? 0 : (lane >> 5) * 16);
+    const int fsw = (lane >> 1) & 7;                   // LDS-DMA image: XOR of the fragment row (row & 31 == lane & 31)
+    // FPIPE: the operand fragments of k-step ks+2 are fetched from LDS behind the MFMAs of k-step ks (two fragment register
+    // sets), so the ds_read round trip is exposed once per chunk instead of once per k-step
+    constexpr bool FPIPE = GLDS != 0;
     auto compute = [&](int buf) {
-        const char* Ab = As + buf * BM * kPitch + (wm * TM * 32) * kPitch + frag_off;
-        const char* Bb = Bs + buf * BN * kPitch + (wn * TN * 32) * kPitch + frag_off;
+        const char* Ab = As + buf * BM * PITCH + (wm * TM * 32) * PITCH + frag_off;
+        const char* Bb = Bs + buf * BN * PITCH + (wn * TN * 32) * PITCH + frag_off;
+        auto fetch = [&](int ks, uint4 (&fa)[TM], uint4 (&fb)[TN]) {
+            const int ko = GLDS ? (((2 * ks + (lane >> 5)) ^ fsw) * 16) : ks * 32;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            uint4 fa[TM], fb[TN];
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(Ab + i * 32 * PITCH + ko);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(Ab + i * 32 * kPitch + ks * 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bb + j * 32 * kPitch + ks * 32);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bb + j * 32 * PITCH + ko);
+        };
+        auto mma = [&](const uint4 (&fa)[TM], const uint4 (&fb)[TN]) {
             if constexpr (ESZ == 4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -357,9 +417,71 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[i][j], 0, 0, 0);
                     }
             }
+        };
+        if constexpr (FPIPE) {
+            uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+            // (the order is pinned: left alone, the machine scheduler folds the two sets back into one and waits per k-step)
+            fetch(0, fa0, fb0);
+            fetch(1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(2, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(3, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa0, fb0);
+            mma(fa1, fb1);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 fa[TM], fb[TN];
+                fetch(ks, fa, fb);
+                mma(fa, fb);
+            }
         }
     };
-    if constexpr (LOWK) {
+    if constexpr (GLDS == 1) {
+        // one buffer: DMA, wait, compute; the overlap comes from the other workgroups of the CU (32 KB of LDS each)
+        for (int kc = 0; kc < nseg; ++kc) {
+            load_chunk(s0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    } else if constexpr (GLDS == 3) {
+        // three buffers, two chunks in flight: chunk kc+2 is issued as soon as every wave is past chunk kc-1 (whose buffer it
+        // takes), and the wait at the top leaves the DMAs of chunk kc+1 outstanding (a counted vmcnt: the statements are asm,
+        // so the count is this loop's own bookkeeping -- A_ROWS_PT + B_ROWS_PT DMAs per chunk per thread)
+        constexpr int kPerChunk = A_ROWS_PT + B_ROWS_PT;
+        static_assert(kPerChunk == 6, "the counted wait below is written for 6 DMAs per chunk");
+        if (nseg > 0) load_chunk(s0, 0);
+        if (nseg > 1) load_chunk(s0, 1);
+        int bcur = 0, bnext = 2;
+        for (int kc = 0; kc < nseg; ++kc) {
+            if (kc + 1 < nseg) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // (hipcc does not know of the DMAs: this is a bare barrier + lgkmcnt)
+            if (kc + 2 < nseg) load_chunk(s0, bnext);
+            compute(bcur);
+            bcur = bcur == 2 ? 0 : bcur + 1;
+            bnext = bnext == 2 ? 0 : bnext + 1;
+        }
+        __syncthreads();
+    } else if constexpr (GLDS >= 2) {
+        // GLDS buffers: chunk kc+GLDS-1 is in flight while chunk kc is multiplied; one barrier per chunk
+        if (nseg > 0) load_chunk(s0, 0);
+        for (int kc = 0; kc < nseg; ++kc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // chunk kc has landed for every wave; the buffer of chunk kc-1 is free
+            if (kc + 1 < nseg) load_chunk(s0, (kc + 1) & 1);
+            compute(kc & 1);
+        }
+        __syncthreads();
+    } else if constexpr (LOWK) {
         // single LDS buffer, one chunk ahead in registers
         if (nseg > 0) {
             load_chunk(s0);
@@ -427,7 +549,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) slot[((i * TN + j) * 16 + r) * kThreads + tid] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) slot[((i * TN + j) * 16 + r) * NT + tid] = acc[i][j][r];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -457,7 +579,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((i * TN + j) * 16 + r) * kThreads + tid];
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((i * TN + j) * 16 + r) * NT + tid];
         }
     }
 
@@ -474,11 +596,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     constexpr bool e_bnb = EPI == 6;                     // BatchNorm-backward sums instead of forward statistics
     const bool e_scatter = EPI == 0 && a.o_s > 0;
     constexpr int CP = BN * 4 + 16;                      // C-tile pitch in bytes
-    constexpr int NH = LOWK ? 2 : 1;                     // epilogue passes (row halves of the block tile)
+    constexpr int NH = (LOWK || GLDS) ? 2 : 1;           // epilogue passes (row halves of the block tile)
     constexpr int HR = BM / NH;                          // rows per pass
-    static_assert(HR * CP <= NBUF * (BM + BN) * kPitch, "C tile (or half) must fit in the A/B LDS buffers");
-    static_assert(!LOWK || (WM == 2 && TM == 2) || (WM == 4 && TM == 1), "half split follows the wave-row layout");
-    constexpr int TPR = BN / 4, RPP = kThreads / TPR;   // threads per row, rows per pass
+    static_assert(HR * CP <= kSmem, "C tile (or half) must fit in the A/B LDS buffers");
+    static_assert(HR % 32 == 0, "half split follows the MFMA row tiles");
+    constexpr int PPT = BM / kBM;                        // statistics partials per tile: one per 128 rows, whatever the tile height
+    constexpr int HPP = NH / PPT;                        // epilogue passes per partial
+    static_assert(NH % PPT == 0 && HPP >= 1, "a statistics partial covers whole epilogue passes");
+    constexpr int TPR = BN / 4, RPP = NT / TPR;   // threads per row, rows per pass
     const int cq = tid % TPR, r0 = tid / TPR;
     const int col = n0 + cq * 4;
     ET* y = reinterpret_cast<ET*>(a.y);
@@ -516,7 +641,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // C-tile barrier below.  Needs 16-byte aligned rows: Cout % 64 == 0, else the rows read their byte from memory.
     constexpr int kMaskOff = HR * CP;
     constexpr int MSEG = BN / 64;                        // 16-byte segments per mask row
-    static_assert(kMaskOff + BM * (BN / 4) <= (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch), "mask tile must fit behind the C tile");
+    static_assert(kMaskOff + BM * (BN / 4) <= kSmem, "mask tile must fit behind the C tile");
     const bool mask_lds = e_res && a.res_mask && (a.Cout % 64 == 0) && a.mask_lds;
     if (mask_lds && tid < BM * MSEG) {
         const int row = tid / MSEG, seg = tid - row * MSEG;
@@ -626,22 +751,25 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 }
             }
         }
-    }
-    if (e_stats || e_bnb) {                         // column sums over the RPP row-threads, fixed order, one writer per column
-        __syncthreads();
-        float4* red = reinterpret_cast<float4*>(smem);
-        red[(r0 * 2 + 0) * TPR + cq] = st1;
-        red[(r0 * 2 + 1) * TPR + cq] = st2;
-        __syncthreads();
-        if (r0 == 0 && col < a.Cout) {
-            float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-            for (int r = 0; r < RPP; ++r) {
-                const float4 p1 = red[(r * 2 + 0) * TPR + cq], p2 = red[(r * 2 + 1) * TPR + cq];
-                s1.x += p1.x; s1.y += p1.y; s1.z += p1.z; s1.w += p1.w;
-                s2.x += p2.x; s2.y += p2.y; s2.z += p2.z; s2.w += p2.w;
+        if ((e_stats || e_bnb) && (hf + 1) % HPP == 0) {   // column sums over the RPP row-threads, fixed order, one writer per column
+            __syncthreads();
+            float4* red = reinterpret_cast<float4*>(smem);
+            red[(r0 * 2 + 0) * TPR + cq] = st1;
+            red[(r0 * 2 + 1) * TPR + cq] = st2;
+            __syncthreads();
+            const int pidx = tm_i * PPT + hf / HPP;      // one partial per 128 rows
+            if (r0 == 0 && col < a.Cout && pidx * kBM < a.M) {
+                float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+                for (int r = 0; r < RPP; ++r) {
+                    const float4 p1 = red[(r * 2 + 0) * TPR + cq], p2 = red[(r * 2 + 1) * TPR + cq];
+                    s1.x += p1.x; s1.y += p1.y; s1.z += p1.z; s1.w += p1.w;
+                    s2.x += p2.x; s2.y += p2.y; s2.z += p2.z; s2.w += p2.w;
+                }
+                float* p = a.stats_part + ((long)pidx * a.Cout + col) * 2;
+                p[0] = s1.x; p[1] = s2.x; p[2] = s1.y; p[3] = s2.y; p[4] = s1.z; p[5] = s2.z; p[6] = s1.w; p[7] = s2.w;
             }
-            float* p = a.stats_part + ((long)tm_i * a.Cout + col) * 2;
-            p[0] = s1.x; p[1] = s2.x; p[2] = s1.y; p[3] = s2.y; p[4] = s1.z; p[5] = s2.z; p[6] = s1.w; p[7] = s2.w;
+            st1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            st2 = st1;
         }
     }
 }
@@ -675,6 +803,61 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
     conv_tile<ET, WM, WN, TM, TN, true, false, false, EPI, PW>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+// LDS-DMA staged variant for the long-K (matrix-core bound) launches
+template <typename ET, int WM, int WN, int TM, int TN, int EPI, int NB>
+__global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<ET, WM, WN, TM, TN, false, false, false, EPI, false, NB>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+// The long-K tile: 256 x 128 outputs per workgroup of 8 waves (4 x 2, 64 x 64 each), three 48 KB LDS-DMA buffers = one
+// workgroup per CU with two chunks (96 KB) in flight.  A 128 x 128 tile moves 32 KB per 2.1 MFLOP (64 FLOP/B); at the ~1.5 us
+// loaded latency the 64-96 KB a CU can keep in flight caps it near 700 TF/s whatever the staging (measured: register-staged
+// 3 workgroups/CU 650, LDS-DMA 2 x 2 buffers 700-750) -- this tile needs 2/3 of the bytes per flop and keeps 1.5x in flight.
+template <typename ET, int EPI>
+__global__ __launch_bounds__(512) void conv_igemm_big_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<ET, 4, 2, 2, 2, false, false, false, EPI, false, 3>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+template <typename ET, int EPI>
+int launch_big(hipStream_t st, const ConvArgs& a0) {
+    ConvArgs a = a0;
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.Cout + 127) / 128;
+    auto k = conv_igemm_big_kernel<ET, EPI>;
+    constexpr int lds = kGldsLds<256, 128, 3>();
+    static bool attr = false;
+    if (!attr) {
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+    return MVF_OK;
+}
+
+template <typename ET, int WM, int WN, int TM, int TN, int EPI>
+int launch_glds(int nb, int tiles, hipStream_t st, const ConvArgs& a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    if (nb == 1) {
+        auto k = conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 1>;
+        constexpr int lds = kGldsLds<BM, BN, 1>();
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds, st, a);
+    } else {
+        auto k = conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 2>;
+        constexpr int lds = kGldsLds<BM, BN, 2>();
+        static bool attr = false;
+        if (!attr) {
+            MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds, st, a);
+    }
+    return MVF_OK;
 }
 
 template <typename ET, int WM, int WN, int TM, int TN, int EPI>
@@ -759,6 +942,9 @@ struct SkHost {
 // fp32 -- occupancy hides more latency than the second buffer does (bf16 27.97 -> 26.96 ms, fp32 83.0 -> 79.6 ms per step).
 int g_lowk_max_chunks = 1 << 30;
 int g_pf2_mode = 1;              // two-chunk register prefetch: 0 off, 1 bf16 only, 2 both dtypes (MVF_CONV_PF2)
+int g_big_min = 0;               // 256 x 128 LDS-DMA tile from this many K chunks on (MVF_CONV_BIG; 0 = off)
+int g_glds_min = -1, g_glds_nb = 2;  // LDS-DMA variant: -1 = the measured default policy (see launch_conv), 0 = off, n = from n K chunks on;
+                                     // with 1 or 2 LDS buffers (MVF_CONV_GLDS=min[,nb])
 
 int sk_slots() {
     static int slots = 0;
@@ -767,6 +953,14 @@ int sk_slots() {
         if (e && e[0] >= '0' && e[0] <= '9') g_lowk_max_chunks = atoi(e);
         e = getenv("MVF_CONV_PF2");
         if (e && e[0] >= '0' && e[0] <= '2') g_pf2_mode = e[0] - '0';
+        e = getenv("MVF_CONV_BIG");
+        if (e && e[0] >= '0' && e[0] <= '9') g_big_min = atoi(e);
+        e = getenv("MVF_CONV_GLDS");
+        if (e && ((e[0] >= '0' && e[0] <= '9') || e[0] == '-')) {
+            g_glds_min = atoi(e);
+            const char* c = strchr(e, ',');
+            if (c && (c[1] == '1' || c[1] == '2')) g_glds_nb = c[1] - '0';
+        }
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) {
             hipDeviceProp_t p;
@@ -835,6 +1029,38 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         const bool contiguous = (epi_spec & 1) && a.o_s <= 0;
         const bool train_like = contiguous && !a.bias && !a.relu;
         const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
+        // long K, wide output: the 256 x 128 LDS-DMA tile (MVF_CONV_BIG = <min chunks>, 0 = off)
+        if (BN == 128 && g_big_min > 0 && a.nchunks >= g_big_min && a.Cout >= 128 && a.M >= 256) {
+            int rc;
+            if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_big<ET, 1>(st, a);
+            else if (contiguous && a.bn_z && !a.bias && !a.relu && !a.res) rc = launch_big<ET, 6>(st, a);
+            else if (train_like && !a.stats_part && !a.res) rc = launch_big<ET, 2>(st, a);
+            else if (train_like && !a.stats_part && a.res) rc = launch_big<ET, 3>(st, a);
+            else if (infer_like && !a.res) rc = launch_big<ET, 4>(st, a);
+            else if (infer_like && a.res) rc = launch_big<ET, 5>(st, a);
+            else rc = launch_big<ET, 0>(st, a);
+            if (rc != MVF_OK) return rc;
+            MVF_LAUNCH_CHECK();
+            return MVF_OK;
+        }
+        // long K: LDS-DMA staging (MVF_CONV_GLDS = "<min chunks>[,<buffers 1|2>]", 0 = off)
+        // default policy (measured per layer on the R50 train step, bf16): the DMA variant wins 10-15 % from 32 chunks on
+        // (K >= 2048: the 3x3 layers of layer3/4) and, for the 128 x 64 tile, from 9 chunks (layer1's 3x3); it loses 10-20 % on
+        // the 8-18 chunk pointwise layers, where three register-staged workgroups per CU hide more latency than two DMA ones
+        const bool glds_auto = g_glds_min < 0 && sizeof(ET) == 2 && (a.nchunks >= 32 || (BN == 64 && a.nchunks >= 9));
+        if ((g_glds_min > 0 && a.nchunks >= g_glds_min) || glds_auto) {
+            int rc;
+            if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(g_glds_nb, tiles, st, a);
+            else if (contiguous && a.bn_z && !a.bias && !a.relu && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 6>(g_glds_nb, tiles, st, a);
+            else if (train_like && !a.stats_part && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 2>(g_glds_nb, tiles, st, a);
+            else if (train_like && !a.stats_part && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 3>(g_glds_nb, tiles, st, a);
+            else if (infer_like && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 4>(g_glds_nb, tiles, st, a);
+            else if (infer_like && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 5>(g_glds_nb, tiles, st, a);
+            else rc = launch_glds<ET, WM, WN, TM, TN, 0>(g_glds_nb, tiles, st, a);
+            if (rc != MVF_OK) return rc;
+            MVF_LAUNCH_CHECK();
+            return MVF_OK;
+        }
         if (train_like && a.stats_part && !a.res && !a.bn_z) launch_lowk<ET, WM, WN, TM, TN, 1>(pw, tiles, lds_lk, st, a);
         else if (contiguous && a.bn_z && !a.bias && !a.relu && !a.res) launch_lowk<ET, WM, WN, TM, TN, 6>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && !a.res) launch_lowk<ET, WM, WN, TM, TN, 2>(pw, tiles, lds_lk, st, a);
