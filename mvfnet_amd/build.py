@@ -12,7 +12,7 @@ REPO = os.path.dirname(HERE)
 OUT = os.path.join(HERE, "libmvfnet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(HERE, "csrc")]
+         "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(HERE, "csrc")] + os.environ.get("MVF_HIPCC_EXTRA", "").split()
 
 
 def sources():

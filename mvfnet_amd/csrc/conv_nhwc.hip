@@ -53,6 +53,7 @@ struct ConvArgs {
     int res_c0;    // residual only for output channels >= res_c0
     const unsigned char* res_mask;   // optional [M][Cout/4] bytes: bit j of byte k gates residual channel 4k+j (ReLU sign bits)
     int mask_lds;  // stage the gate bytes in LDS (experiment switch MVF_MASK_LDS=0)
+    int prio;      // experiment switch MVF_CONV_PRIO=1: raise the wave priority around the MFMA phase of the LDS-DMA loops
     int dil;       // input dilation (generic fallback; the strided data-gradient is normally decomposed into parity classes)
     int pad_w;     // horizontal padding (pad = vertical)
     int w_kh0, w_kw0, w_ts, w_kwfull;   // weight tap (kh,kw) of this launch = full-pack tap (kh0 + kh*ts, kw0 + kw*ts)
@@ -158,12 +159,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(BM == kBM || (BM == 2 * kBM && GLDS == 3), "BM is 128 (256 for the 8-wave LDS-DMA tile)");
-    static_assert(WM * WN == 4 || (WM * WN == 8 && GLDS == 3), "4 waves (8 for the big tile)");
+    static_assert(WM * WN == 4 || (WM * WN == 8 && GLDS >= 2), "4 waves (8 for the LDS-DMA experiments)");
     constexpr int NT = WM * WN * 64;        // threads per workgroup
     constexpr int RP = NT / 8;              // rows per loader pass (8 lanes x 16 B per row)
     constexpr int ESZ = TT<ET>::ESZ, UE = TT<ET>::UE, CE = TT<ET>::CE;
     constexpr int A_ROWS_PT = BM / RP;      // rows per thread in the A loader (256 thr = 32 rows x 8 units)
     constexpr int B_ROWS_PT = BN / RP;
+#ifdef MVF_CONV_ABLATE
+    if (a.prio & 8) return;                            // ablation: launch + dispatch floor
+#endif
     __syncthreads();                                   // LDS hand-over from a previous segment of this workgroup
     static_assert(!GLDS || (!GEN && !PF2 && !LOWK), "the LDS-DMA loop is its own variant");
     constexpr int NBUF = GLDS ? GLDS : (LOWK ? 1 : 2);
@@ -419,6 +423,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             }
         };
         if constexpr (FPIPE) {
+            if (a.prio & 1) __builtin_amdgcn_s_setprio(1);
             uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
             // (the order is pinned: left alone, the machine scheduler folds the two sets back into one and waits per k-step)
             fetch(0, fa0, fb0);
@@ -434,6 +439,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             __builtin_amdgcn_sched_barrier(0);
             mma(fa0, fb0);
             mma(fa1, fb1);
+            if (a.prio & 1) __builtin_amdgcn_s_setprio(0);
         } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -477,8 +483,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         for (int kc = 0; kc < nseg; ++kc) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                           // chunk kc has landed for every wave; the buffer of chunk kc-1 is free
-            if (kc + 1 < nseg) load_chunk(s0, (kc + 1) & 1);
-            compute(kc & 1);
+            if (kc + 1 < nseg && !(a.prio & 4)) load_chunk(s0, (kc + 1) & 1);
+            if (!(a.prio & 2)) compute(kc & 1);
         }
         __syncthreads();
     } else if constexpr (LOWK) {
@@ -540,6 +546,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         }
     }
 
+#ifdef MVF_CONV_ABLATE
+    if (a.prio & 16) return;                           // ablation: no epilogue
+#endif
     // ---- stream-K hand-over of partial accumulators (inter-workgroup, placement independent: agent-scope release on
     // the producer, ONE relaxed poll + agent-scope acquire on the consumer; cdna_hip_programming.md Guideline 16) -----
     if (mode == SEG_PRODUCE) {
@@ -725,6 +734,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     u32x2 pk;
                     pk.x = pack_bf16x2(v.x, v.y);
                     pk.y = pack_bf16x2(v.z, v.w);
+#ifdef MVF_CONV_ABLATE
+                    if (!(a.prio & 32))
+#endif
                     __builtin_amdgcn_raw_buffer_store_b64(pk, rs_y, off, 0, 0);
                     // statistics of what is STORED (bf16-rounded), as the consumers will read it
                     v = make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
@@ -807,7 +819,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
 
 // LDS-DMA staged variant for the long-K (matrix-core bound) launches
 template <typename ET, int WM, int WN, int TM, int TN, int EPI, int NB>
-__global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(ConvArgs a) {
+__global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
     conv_tile<ET, WM, WN, TM, TN, false, false, false, EPI, false, NB>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
@@ -822,6 +834,14 @@ __global__ __launch_bounds__(512) void conv_igemm_big_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
     conv_tile<ET, 4, 2, 2, 2, false, false, false, EPI, false, 3>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+// experiment: the 128 x 128 two-buffer DMA tile computed by 8 waves (4 x 2, 32 x 64 each) -> 4 waves per SIMD at 2 workgroups/CU
+template <typename ET, int EPI>
+__global__ __launch_bounds__(512) void conv_igemm_glds8_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<ET, 4, 2, 1, 2, false, false, false, EPI, false, 2>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
 template <typename ET, int EPI>
@@ -843,6 +863,19 @@ int launch_big(hipStream_t st, const ConvArgs& a0) {
 template <typename ET, int WM, int WN, int TM, int TN, int EPI>
 int launch_glds(int nb, int tiles, hipStream_t st, const ConvArgs& a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    if constexpr (BM == 128 && BN == 128) {
+        if (nb == 3) {
+            auto k = conv_igemm_glds8_kernel<ET, EPI>;
+            constexpr int lds = kGldsLds<128, 128, 2>();
+            static bool attr8 = false;
+            if (!attr8) {
+                MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                attr8 = true;
+            }
+            hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, st, a);
+            return MVF_OK;
+        }
+    }
     if (nb == 1) {
         auto k = conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 1>;
         constexpr int lds = kGldsLds<BM, BN, 1>();
@@ -942,6 +975,8 @@ struct SkHost {
 // fp32 -- occupancy hides more latency than the second buffer does (bf16 27.97 -> 26.96 ms, fp32 83.0 -> 79.6 ms per step).
 int g_lowk_max_chunks = 1 << 30;
 int g_pf2_mode = 1;              // two-chunk register prefetch: 0 off, 1 bf16 only, 2 both dtypes (MVF_CONV_PF2)
+int g_glds1_max = -1;            // single-buffer LDS-DMA kernel (4 workgroups per CU) up to this many K chunks: -1 = default policy
+                                 // (bf16: 8), 0 = off (MVF_CONV_GLDS1)
 int g_big_min = 0;               // 256 x 128 LDS-DMA tile from this many K chunks on (MVF_CONV_BIG; 0 = off)
 int g_glds_min = -1, g_glds_nb = 2;  // LDS-DMA variant: -1 = the measured default policy (see launch_conv), 0 = off, n = from n K chunks on;
                                      // with 1 or 2 LDS buffers (MVF_CONV_GLDS=min[,nb])
@@ -953,13 +988,15 @@ int sk_slots() {
         if (e && e[0] >= '0' && e[0] <= '9') g_lowk_max_chunks = atoi(e);
         e = getenv("MVF_CONV_PF2");
         if (e && e[0] >= '0' && e[0] <= '2') g_pf2_mode = e[0] - '0';
+        e = getenv("MVF_CONV_GLDS1");
+        if (e && e[0] >= '0' && e[0] <= '9') g_glds1_max = atoi(e);
         e = getenv("MVF_CONV_BIG");
         if (e && e[0] >= '0' && e[0] <= '9') g_big_min = atoi(e);
         e = getenv("MVF_CONV_GLDS");
         if (e && ((e[0] >= '0' && e[0] <= '9') || e[0] == '-')) {
             g_glds_min = atoi(e);
             const char* c = strchr(e, ',');
-            if (c && (c[1] == '1' || c[1] == '2')) g_glds_nb = c[1] - '0';
+            if (c && (c[1] >= '1' && c[1] <= '3')) g_glds_nb = c[1] - '0';      // 3 = two buffers, 8 waves (128 x 128 tile only)
         }
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) {
@@ -1047,6 +1084,25 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         // default policy (measured per layer on the R50 train step, bf16): the DMA variant wins 10-15 % from 32 chunks on
         // (K >= 2048: the 3x3 layers of layer3/4) and, for the 128 x 64 tile, from 9 chunks (layer1's 3x3); it loses 10-20 % on
         // the 8-18 chunk pointwise layers, where three register-staged workgroups per CU hide more latency than two DMA ones
+        // short K: the single-buffer DMA kernel needs no staging registers -> 4 workgroups per CU instead of 3, which hides more
+        // of the per-tile fixed latency chain (kernel arguments -> offsets -> first chunk -> epilogue -> store drain) that
+        // dominates these launches (ablation: with loads AND MFMAs removed the conv launches still take 58 % of their time).
+        // Not for the BatchNorm-sum data gradient (its epilogue spills at 128 registers) and not for fp32 unless forced.
+        const bool bnsum_epi = contiguous && a.bn_z && !a.bias && !a.relu && !a.res;
+        const int glds1_max = g_glds1_max >= 0 ? g_glds1_max : (sizeof(ET) == 2 ? 8 : 0);
+        if (glds1_max > 0 && a.nchunks <= glds1_max && !(bnsum_epi && g_glds1_max < 0)) {
+            int rc;
+            if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(1, tiles, st, a);
+            else if (bnsum_epi) rc = launch_glds<ET, WM, WN, TM, TN, 6>(1, tiles, st, a);
+            else if (train_like && !a.stats_part && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 2>(1, tiles, st, a);
+            else if (train_like && !a.stats_part && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 3>(1, tiles, st, a);
+            else if (infer_like && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 4>(1, tiles, st, a);
+            else if (infer_like && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 5>(1, tiles, st, a);
+            else rc = launch_glds<ET, WM, WN, TM, TN, 0>(1, tiles, st, a);
+            if (rc != MVF_OK) return rc;
+            MVF_LAUNCH_CHECK();
+            return MVF_OK;
+        }
         const bool glds_auto = g_glds_min < 0 && sizeof(ET) == 2 && (a.nchunks >= 32 || (BN == 64 && a.nchunks >= 9));
         if ((g_glds_min > 0 && a.nchunks >= g_glds_min) || glds_auto) {
             int rc;
@@ -1193,6 +1249,8 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     a.res_mask = res_mask;
     static const int mask_lds_on = getenv("MVF_MASK_LDS") ? atoi(getenv("MVF_MASK_LDS")) : 1;
     a.mask_lds = mask_lds_on;
+    static const int prio_on = getenv("MVF_CONV_PRIO") ? atoi(getenv("MVF_CONV_PRIO")) : 0;
+    a.prio = prio_on;
     a.M = d->n * d->ho * d->wo;
     a.cpt = (d->cin + ce - 1) / ce;
     a.nchunks = d->kh * d->kw * a.cpt;

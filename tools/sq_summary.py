@@ -28,7 +28,21 @@ def main():
         kcol = "kernel_name" if "kernel_name" in cols else "name"
         for name, cname, val in cur.execute("select %s, counter_name, sum(value) from %s group by 1, 2" % (kcol, view)):
             agg.setdefault(short(name), {})[cname] = agg.get(short(name), {}).get(cname, 0.0) + float(val)
+    # kernel durations from the same databases (--kernel-trace): GRBM_GUI_ACTIVE / 8 XCDs / duration = the shader clock it ran at
+    for f in dbs:
+        db = sqlite3.connect(f)
+        cur = db.cursor()
+        tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+        if "kernels" in tabs:
+            cols = [d[1] for d in cur.execute("pragma table_info(kernels)")]
+            if "start" in cols and "end" in cols and "name" in cols:
+                for name, dur, n in cur.execute("select name, sum(end - start), count(*) from kernels group by 1"):
+                    d = agg.setdefault(short(name), {})
+                    d["duration_ns"] = d.get("duration_ns", 0.0) + float(dur)
+                    d["dispatches"] = d.get("dispatches", 0) + int(n)
     for k, d in agg.items():
+        if d.get("GRBM_GUI_ACTIVE") and d.get("duration_ns"):
+            d["shader_clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / d["duration_ns"]
         wc = d.get("SQ_WAVE_CYCLES")
         if wc:
             for c in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VALU",
