@@ -55,6 +55,11 @@ class Runner(object):
         self.warmup_iters, self.warmup_ratio = warmup_iters, warmup_ratio
         self.ckpt_interval, self.log_interval, self.log = ckpt_interval, log_interval, logger
         self.epoch, self.iter = 0, 0
+        self.hooks = []               # objects with after_train_epoch(runner), e.g. evaluation.EvalTopKAccuracyHook
+
+    def register_hook(self, hook):
+        self.hooks.append(hook)
+        return hook
 
     def current_lr(self):
         return step_lr(self.base_lr, self.epoch, self.iter, self.lr_steps, 0.1, "linear", self.warmup_iters, self.warmup_ratio)
@@ -72,6 +77,10 @@ class Runner(object):
         self.epoch += 1
         if rank == 0 and self.work_dir and self.ckpt_interval and self.epoch % self.ckpt_interval == 0:
             self.save_checkpoint()
+        for h in self.hooks:
+            out = h.after_train_epoch(self)
+            if out and rank == 0 and self.log:
+                self.log("Epoch(val) [%d] %s" % (self.epoch, "  ".join("%s: %.4f" % kv for kv in out.items() if kv[0] != "epoch")))
 
     def run(self, loader, max_epochs):
         while self.epoch < max_epochs:
