@@ -156,6 +156,18 @@ int mvf_bn_fold(const float* gamma, const float* beta, const float* mean, const 
  * (wp >= w + 2*pad + 2) so that the 7x7/2 stem (resnet.py:424-425,481) becomes 7 K-chunks of 8 px x 4 ch. */
 int mvf_stem_prep(const float* x_nchw, int n, int c, int h, int w, int pad, int wp, void* out, int dtype, void* stream);
 
+/* The device side of the input pipeline, fused: decoded uint8 frames (n, hs, ws, 3) HWC -> the h x w window at
+ * (y0, x0) of each frame [crop: augmentations.py CenterCrop / ThreeCrop :465-540 offsets], mirrored when flip != 0 [Flip :196-228],
+ * channels reversed when to_rgb [Normalize.imnormalize :365-374], value = (float(px) [/ 255 when div_255] - mean[c]) * (1/std[c])
+ * in two rounded fp32 steps as the reference's subtract-then-multiply, stacked channels-first [FormatShape formating.py:146-160].
+ * window = device int32 (n,3) rows (y0, x0, flip) or NULL (= 0,0,0).  mean3 / std3 are HOST pointers (3 floats each).
+ * Outputs (either may be NULL): out_stem = (n, h+2*pad, wp, 4) `dtype`, zero padded, the 7x7 stem's operand exactly as
+ * mvf_stem_prep lays it out; out_nchw = (n,3,h,w) fp32, the tensor the reference's collate would hand to the model.
+ * The host then ships uint8 frames (1/4 of the fp32 bytes, distributed.py:40-62 scatter) instead of normalised floats. */
+int mvf_frames_prep_u8(const unsigned char* frames_hwc, int n, int hs, int ws, const int* window, int h, int w,
+                       const float* mean3, const float* std3, int to_rgb, int div_255, int pad, int wp, void* out_stem,
+                       float* out_nchw, int dtype, void* stream);
+
 /* MaxPool2d(3, stride 2, pad 1) on NHWC (resnet.py:431,484). */
 int mvf_maxpool3x3s2_nhwc(const void* x, int n, int h, int w, int c, void* y, int dtype, void* stream);
 

@@ -77,6 +77,9 @@ def _load():
     lib.mvf_bn_fold.argtypes = [fp, fp, fp, fp, f32, i32, fp, fp, vp]
     lib.mvf_stem_prep.restype = i32
     lib.mvf_stem_prep.argtypes = [fp, i32, i32, i32, i32, i32, i32, vp, i32, vp]
+    lib.mvf_frames_prep_u8.restype = i32
+    lib.mvf_frames_prep_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       i32, i32, i32, i32, vp, vp, i32, vp]
     lib.mvf_maxpool3x3s2_nhwc.restype = i32
     lib.mvf_maxpool3x3s2_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp]
     lib.mvf_head_pool_fc.restype = i32

@@ -151,6 +151,7 @@ class ResNet(nn.Module):
         if self._engine is None:
             from ..engine import BackboneEngine
             self._engine = BackboneEngine(self, self.engine_dtype)
+        self._engine.input_pipeline = getattr(self, "input_pipeline", None)      # uint8 frame input (preprocess.FramePipeline)
         return self._engine
 
     def _bn_all_eval(self):

@@ -25,6 +25,44 @@ __global__ void stem_prep_kernel(const float* x, int n, int c, int h, int w, int
     }
 }
 
+// Decoded uint8 HWC frames -> normalised stem operand (and / or the reference's fp32 NCHW tensor): window (crop), mirror (flip),
+// channel order (to_rgb), (float(px) [/ 255] - mean) * stdinv in two rounded fp32 steps (the reference subtracts, then multiplies
+// by 1/std: no FMA), channels-first stacking.  Thread = one pixel of the padded stem image; 3 byte loads, one 8/16-byte store.
+struct FramePrep {
+    float mean[3], stdinv[3];
+    int to_rgb, div_255;
+};
+template <typename ET>
+__global__ void frames_prep_kernel(const unsigned char* frames, int n, int hs, int ws, const int* win, int h, int w, FramePrep fp,
+                                   int pad, int hp, int wp, ET* out_stem, float* out_nchw) {
+    const long total = (long)n * hp * wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % wp);
+        const long t = i / wp;
+        const int yo = (int)(t % hp);
+        const int img = (int)(t / hp);
+        const int ih = yo - pad, iw = xo - pad;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool inside = ih >= 0 && ih < h && iw >= 0 && iw < w;
+        if (inside) {
+            const int y0 = win ? win[img * 3 + 0] : 0, x0 = win ? win[img * 3 + 1] : 0, flip = win ? win[img * 3 + 2] : 0;
+            const int sy = y0 + ih, sx = x0 + (flip ? w - 1 - iw : iw);
+            const unsigned char* px = frames + (((long)img * hs + sy) * ws + sx) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float f = (float)px[fp.to_rgb ? 2 - k : k];
+                if (fp.div_255) f = __fdiv_rn(f, 255.f);
+                v[k] = __fmul_rn(__fsub_rn(f, fp.mean[k]), fp.stdinv[k]);
+            }
+            if (out_nchw) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) out_nchw[(((long)img * 3 + k) * h + ih) * w + iw] = v[k];
+            }
+        }
+        if (out_stem) st4(out_stem + i * 4, make_float4(v[0], v[1], v[2], v[3]));
+    }
+}
+
 // MaxPool2d(3, 2, 1) NHWC; thread = (output pixel, 4 channels)
 template <typename ET>
 __global__ void maxpool_kernel(const ET* x, int n, int h, int w, int c, int ho, int wo, ET* y) {
@@ -133,6 +171,34 @@ int mvf_stem_prep(const float* x_nchw, int n, int c, int h, int w, int pad, int 
         hipLaunchKernelGGL(stem_prep_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, n, c, h, w, pad, hp, wp, (float*)out);
     else
         hipLaunchKernelGGL(stem_prep_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, n, c, h, w, pad, hp, wp, (bf16_t*)out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_frames_prep_u8(const unsigned char* frames_hwc, int n, int hs, int ws, const int* window, int h, int w,
+                       const float* mean3, const float* std3, int to_rgb, int div_255, int pad, int wp, void* out_stem,
+                       float* out_nchw, int dtype, void* stream) {
+    MVF_REQUIRE(frames_hwc && mean3 && std3 && (out_stem || out_nchw) && n > 0 && hs > 0 && ws > 0 && h > 0 && w > 0 && h <= hs && w <= ws && pad >= 0,
+                MVF_EINVAL, "frames_prep_u8: bad argument");
+    MVF_REQUIRE(!out_stem || wp >= w + 2 * pad, MVF_EINVAL, "frames_prep_u8: wp=%d < w + 2*pad", wp);
+    MVF_REQUIRE(dtype == MVF_F32 || dtype == MVF_BF16, MVF_EINVAL, "frames_prep_u8: bad dtype");
+    FramePrep fp;
+    for (int k = 0; k < 3; ++k) {
+        MVF_REQUIRE(std3[k] != 0.f, MVF_EINVAL, "frames_prep_u8: std[%d] is zero", k);
+        fp.mean[k] = mean3[k];
+        fp.stdinv[k] = (float)(1.0 / (double)std3[k]);      // the reference multiplies by 1 / float64(std)
+    }
+    fp.to_rgb = to_rgb;
+    fp.div_255 = div_255;
+    const int p = out_stem ? pad : 0, wpp = out_stem ? wp : w;
+    const int hp = h + 2 * p;
+    const long total = (long)n * hp * wpp;
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(frames_prep_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames_hwc, n, hs, ws, window, h, w, fp,
+                           p, hp, wpp, (float*)out_stem, out_nchw);
+    else
+        hipLaunchKernelGGL(frames_prep_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames_hwc, n, hs, ws, window, h, w, fp,
+                           p, hp, wpp, (bf16_t*)out_stem, out_nchw);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

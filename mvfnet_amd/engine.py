@@ -172,6 +172,7 @@ class BackboneEngine(object):
         if torch.device(device).type != "cuda":
             raise RuntimeError("BackboneEngine needs the model on an MI355X device (got %s); no CPU fallback" % device)
         self.dtype, self.device = dtype, device
+        self.input_pipeline, self.input_window = None, None     # uint8 frame input (preprocess.FramePipeline), see forward()
         with torch.no_grad():
             self.stem = _Conv(resnet.conv1, resnet.bn1, dtype, True, device, stem=True)
             self.blocks = []
@@ -191,15 +192,17 @@ class BackboneEngine(object):
         run as an independent launch chain on its own HIP stream: clips are independent units in eval mode, and
         two chains in flight let one chain's kernels fill the CUs another chain's last (partial) wave of tiles
         leaves idle."""
-        if not x_nchw.is_cuda or x_nchw.dtype != torch.float32:
+        u8 = x_nchw.dtype == torch.uint8             # decoded (NT, Hs, Ws, 3) frames + self.input_pipeline / self.input_window
+        if not x_nchw.is_cuda or not (x_nchw.dtype == torch.float32 or u8):
             raise RuntimeError("engine input must be a float32 GPU tensor (got %s on %s)" % (x_nchw.dtype, x_nchw.device))
         x_nchw = x_nchw.contiguous()
+        window = getattr(self, "input_window", None) if u8 else None
         ns = getattr(self, "streams", 1)
         T = n_segment or self._n_segment()
         clips = x_nchw.shape[0] // max(T, 1)
         if ns > 1 and stages is None and clips >= 2 * ns and x_nchw.shape[0] % T == 0:
-            return self._forward_multi(x_nchw, ns, T)
-        return self._forward_one(x_nchw, stages)
+            return self._forward_multi(x_nchw, ns, T, window)
+        return self._forward_one(x_nchw, stages, window)
 
     def _n_segment(self):
         for b in self.blocks:
@@ -207,7 +210,7 @@ class BackboneEngine(object):
                 return b.mvf.T
         return 1
 
-    def _forward_multi(self, x, ns, T):
+    def _forward_multi(self, x, ns, T, window=None):
         cur = torch.cuda.current_stream()
         if not hasattr(self, "_pool") or len(self._pool) != ns:
             self._pool = [torch.cuda.Stream() for _ in range(ns)]
@@ -220,7 +223,7 @@ class BackboneEngine(object):
                 continue
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                y = self._forward_one(x[lo:hi], None)
+                y = self._forward_one(x[lo:hi], None, None if window is None else window.reshape(-1, 3)[lo:hi])
                 y.record_stream(cur)
             parts.append((st, y))
         for st, y in parts:
@@ -228,12 +231,20 @@ class BackboneEngine(object):
             outs.append(y)
         return torch.cat(outs, 0)
 
-    def _forward_one(self, x_nchw, stages=None):
-        nt, cin, h, w = x_nchw.shape
+    def _forward_one(self, x_nchw, stages=None, window=None):
         pad = self.stem.stem_pad
-        hp, wp = h + 2 * pad, (w + 2 * pad + 2 + 1) // 2 * 2
-        xp = torch.empty(nt, hp, wp, 4, dtype=self.dtype, device=x_nchw.device)
-        check(lib.mvf_stem_prep(_p(x_nchw), nt, cin, h, w, pad, wp, _p(xp), _DT[self.dtype], _stream()), "mvf_stem_prep")
+        if x_nchw.dtype == torch.uint8:              # decoded (nt, Hs, Ws, 3) frames: crop / flip / normalise fused into the stem prep
+            if self.input_pipeline is None:
+                raise RuntimeError("uint8 frames need engine.input_pipeline = preprocess.FramePipeline(...)")
+            nt = x_nchw.shape[0]
+            h, w = self.input_pipeline.crop_hw
+            hp, wp = h + 2 * pad, (w + 2 * pad + 2 + 1) // 2 * 2
+            xp = self.input_pipeline.to_stem(x_nchw, window, pad, wp, self.dtype)
+        else:
+            nt, cin, h, w = x_nchw.shape
+            hp, wp = h + 2 * pad, (w + 2 * pad + 2 + 1) // 2 * 2
+            xp = torch.empty(nt, hp, wp, 4, dtype=self.dtype, device=x_nchw.device)
+            check(lib.mvf_stem_prep(_p(x_nchw), nt, cin, h, w, pad, wp, _p(xp), _DT[self.dtype], _stream()), "mvf_stem_prep")
         ho, wo = (h + 2 * pad - self.stem.kh) // 2 + 1, (w + 2 * pad - 7) // 2 + 1
         y, _, _ = self.stem.run(xp, nt, hp, wp, 4, ho=ho, wo=wo, stride=2, pad=0)
         h2, w2 = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1

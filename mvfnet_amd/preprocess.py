@@ -1,0 +1,90 @@
+"""Device side of the input pipeline: the host ships DECODED uint8 frames (a quarter of the bytes of the
+normalised fp32 tensor the reference's DataLoader + scatter move, codes/core/parallel/distributed.py:40-62) and one HIP kernel
+does crop window -> flip -> Normalize -> FormatShape -> stem layout (`mvf_frames_prep_u8`, include/mvfnet_hip.h).
+
+Mirrors the reference's pipeline steps in names and argument meaning: `img_norm_cfg = dict(mean, std, to_rgb)` of the configs
+(config_zoo R50 8x8: mean [123.675, 116.28, 103.53], std [58.395, 57.12, 57.375], to_rgb True), `Flip(flip_ratio)`'s boolean,
+`CenterCrop` / `ThreeCrop(crop_size)` offsets (augmentations.py:196-228, 342-396, 465-540).  Decoding, resizing and the random
+scale-jitter crop stay on the host."""
+import ctypes
+
+import torch
+
+from ._lib import check, lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def three_crop_offsets(img_h, img_w, crop_h, crop_w):
+    """(x0, y0) of ThreeCrop's crops in the reference's order: left/top, right/bottom, middle (augmentations.py:487-510)."""
+    if crop_h == img_h:
+        s = (img_w - crop_w) // 2
+        return [(0, 0), (2 * s, 0), (s, 0)]
+    if crop_w == img_w:
+        s = (img_h - crop_h) // 2
+        return [(0, 0), (0, 2 * s), (0, s)]
+    ws, hs = (img_w - crop_w) // 4, (img_h - crop_h) // 4
+    return [(0, 2 * hs), (4 * ws, 2 * hs), (2 * ws, 2 * hs)]
+
+
+class FramePipeline(object):
+    """Normalize(mean, std, to_rgb, div_255) + a crop size; per-frame windows (y0, x0, flip) select crop position and mirroring."""
+
+    def __init__(self, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True, div_255=False, crop_size=224):
+        self.mean = (ctypes.c_float * 3)(*[float(v) for v in mean])
+        self.std = (ctypes.c_float * 3)(*[float(v) for v in std])
+        self.to_rgb, self.div_255 = bool(to_rgb), bool(div_255)
+        self.crop_hw = (crop_size, crop_size) if isinstance(crop_size, int) else (int(crop_size[1]), int(crop_size[0]))   # cfg is (w, h)
+
+    def center_window(self, n, hs, ws, flip=False, device="cuda"):
+        """CenterCrop's window for every frame (augmentations.py:342-396: x0 = (W - w) // 2, y0 = (H - h) // 2)."""
+        h, w = self.crop_hw
+        row = [(hs - h) // 2, (ws - w) // 2, int(bool(flip))]
+        return torch.tensor([row] * n, dtype=torch.int32, device=device)
+
+    def _frames(self, frames):
+        if frames.dtype != torch.uint8 or frames.shape[-1] != 3 or not frames.is_cuda:
+            raise TypeError("FramePipeline expects a CUDA uint8 tensor (..., H, W, 3) of decoded frames, got %s %s" % (frames.dtype, tuple(frames.shape)))
+        f = frames.reshape((-1,) + tuple(frames.shape[-3:])).contiguous()
+        h, w = self.crop_hw
+        if h > f.shape[1] or w > f.shape[2]:
+            raise ValueError("crop %dx%d larger than the frames %dx%d" % (h, w, f.shape[1], f.shape[2]))
+        return f
+
+    def _window(self, window, n, hs, ws):
+        if window is None:
+            return None
+        window = window.to(device="cuda", dtype=torch.int32).reshape(-1, 3).contiguous()
+        if window.shape[0] != n:
+            raise ValueError("window needs one (y0, x0, flip) row per frame: %d rows for %d frames" % (window.shape[0], n))
+        h, w = self.crop_hw
+        lo, hi = window.min(0).values.tolist(), window.max(0).values.tolist()
+        if lo[0] < 0 or lo[1] < 0 or hi[0] + h > hs or hi[1] + w > ws:
+            raise ValueError("crop window leaves the %dx%d frame" % (hs, ws))
+        return window
+
+    def to_nchw(self, frames, window=None):
+        """-> (n, 3, h, w) fp32, what the reference's Normalize + FormatShape + ToTensor produce for these frames."""
+        f = self._frames(frames)
+        n, hs, ws = f.shape[:3]
+        win = self._window(window, n, hs, ws)
+        h, w = self.crop_hw
+        out = torch.empty(n, 3, h, w, dtype=torch.float32, device=f.device)
+        check(lib.mvf_frames_prep_u8(f.data_ptr(), n, hs, ws, win.data_ptr() if win is not None else None, h, w, self.mean, self.std,
+                                     int(self.to_rgb), int(self.div_255), 0, w, None, out.data_ptr(), 0,
+                                     torch.cuda.current_stream().cuda_stream), "mvf_frames_prep_u8")
+        return out
+
+    def to_stem(self, frames, window, pad, wp, dtype, out=None):
+        """-> (n, h + 2 pad, wp, 4) `dtype`: the zero-padded channels-last operand of the 7x7 stem conv (what mvf_stem_prep makes
+        from the fp32 NCHW tensor), straight from the uint8 frames."""
+        f = self._frames(frames)
+        n, hs, ws = f.shape[:3]
+        win = self._window(window, n, hs, ws)
+        h, w = self.crop_hw
+        if out is None:
+            out = torch.empty(n, h + 2 * pad, wp, 4, dtype=dtype, device=f.device)
+        check(lib.mvf_frames_prep_u8(f.data_ptr(), n, hs, ws, win.data_ptr() if win is not None else None, h, w, self.mean, self.std,
+                                     int(self.to_rgb), int(self.div_255), pad, wp, out.data_ptr(), None, _DT[dtype],
+                                     torch.cuda.current_stream().cuda_stream), "mvf_frames_prep_u8")
+        return out

@@ -75,6 +75,14 @@ class Recognizer2D(nn.Module):
             raise KeyError('"average_clips" must defined in test_cfg\'s keys')
         return self.cls_head.engine().average(cls_score, self.test_cfg["average_clips"])
 
+    def set_input_pipeline(self, pipeline):
+        """Feed the model DECODED uint8 frames -- `img_group` (B, frames, Hs, Ws, 3) uint8 plus an optional `window=` (frames, 3)
+        int32 of per-frame (y0, x0, flip) -- instead of the normalised fp32 tensor: `pipeline` is a preprocess.FramePipeline
+        (the config's img_norm_cfg + crop size); crop, flip, Normalize and FormatShape then run inside the stem's input kernel."""
+        self.input_pipeline = pipeline
+        self.backbone.input_pipeline = pipeline
+        return self
+
     def forward(self, img_group, label=None, return_loss=True, return_numpy=True, **kwargs):
         if return_loss:
             return self.forward_train(img_group, label, **kwargs)
@@ -100,6 +108,7 @@ class Recognizer2D(nn.Module):
             raise NotImplementedError("forward_train with eval-mode (frozen) BatchNorm is not built; the shipped MVFNet "
                                       "configs train with norm_eval=False")
         eng = self.train_engine()
+        eng.input_pipeline, eng.input_window = getattr(self, "input_pipeline", None), kwargs.get("window")
         eng.dropout = self.cls_head.dropout_ratio if (self.cls_head.dropout is not None and self.cls_head.training) else 0.0
         params = [p for p in self.parameters()]
         loss = _TrainStepFn.apply(eng, imgs, labels, *params)
@@ -110,7 +119,11 @@ class Recognizer2D(nn.Module):
         if not imgs.is_cuda:
             raise RuntimeError("Recognizer2D: mvfnet_amd runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
         with torch.no_grad():
-            x = imgs.reshape((-1, self.in_channels) + tuple(imgs.shape[3:]))
+            if imgs.dtype == torch.uint8:                                 # decoded frames (B, frames, Hs, Ws, 3), see set_input_pipeline
+                x = imgs.reshape((-1,) + tuple(imgs.shape[-3:]))
+                self.backbone.engine().input_window = kwargs.get("window")
+            else:
+                x = imgs.reshape((-1, self.in_channels) + tuple(imgs.shape[3:]))
             feat = self.extract_feat(x)                                   # (B*frames, 2048, h, w), channels-last
             if self.with_cls_head:
                 num_seg = self.module_cfg["n_segment"] if self.module_cfg else x.shape[0] // imgs.shape[0]

@@ -591,20 +591,32 @@ class TrainEngine(_ParamStore):
             self._nbt_flat[i] = m_.num_batches_tracked.to(self.device)
             m_.num_batches_tracked = self._nbt_flat[i]
         self._nbt_touched = False
+        # uint8 input path (preprocess.FramePipeline): decoded frames in, crop / flip / normalise fused into the stem prep;
+        # input_window = per-frame (y0, x0, flip) rows for the NEXT forward (None = top-left window, no flip)
+        self.input_pipeline, self.input_window = None, None
 
     # ---- one step -----------------------------------------------------------------------------------------------
     def forward(self, imgs, labels, stages=None):
-        """imgs [B, T, 3, H, W] fp32, labels [B, 1] / [B] int64 (GPU) -> loss tensor (1,), keeps activations."""
-        if not imgs.is_cuda or imgs.dtype != torch.float32:
-            raise RuntimeError("TrainEngine.forward: float32 GPU input required")
+        """imgs [B, T, 3, H, W] fp32 -- or decoded frames [B, T, Hs, Ws, 3] uint8 with `input_pipeline` set --, labels [B, 1] /
+        [B] int64 (GPU) -> loss tensor (1,), keeps activations."""
+        if not imgs.is_cuda or imgs.dtype not in (torch.float32, torch.uint8):
+            raise RuntimeError("TrainEngine.forward: float32 (or uint8 frames) GPU input required")
         self._main = torch.cuda.current_stream()
         with _on_stream(self._main):
             return self._forward(imgs, labels, stages)
 
     def _forward(self, imgs, labels, stages=None):
         b, t = imgs.shape[0], imgs.shape[1]
-        x = imgs.reshape((-1, 3) + tuple(imgs.shape[3:])).contiguous()
-        nt, _, h, w = x.shape
+        u8 = imgs.dtype == torch.uint8               # decoded (B, T, Hs, Ws, 3) frames: crop/flip/normalise fused into the stem prep
+        if u8:
+            if self.input_pipeline is None:
+                raise RuntimeError("uint8 frames need engine.input_pipeline = preprocess.FramePipeline(...)")
+            x = None
+            nt = b * t
+            h, w = self.input_pipeline.crop_hw
+        else:
+            x = imgs.reshape((-1, 3) + tuple(imgs.shape[3:])).contiguous()
+            nt, _, h, w = x.shape
         self.stem.pack()
         for blk in self.blocks:
             for cv in blk.convs():
@@ -620,7 +632,10 @@ class TrainEngine(_ParamStore):
         self._packs_on_side = side is not None
         hp, wp = h + 6, (w + 6 + 2 + 1) // 2 * 2
         xp = self.buf("xp", (nt, hp, wp, 4))
-        check(lib.mvf_stem_prep(_p(x), nt, 3, h, w, 3, wp, _p(xp), self.dt, _st()), "stem_prep")
+        if u8:
+            self.input_pipeline.to_stem(imgs, self.input_window, 3, wp, self.tdtype, out=xp)
+        else:
+            check(lib.mvf_stem_prep(_p(x), nt, 3, h, w, 3, wp, _p(xp), self.dt, _st()), "stem_prep")
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
         z0, _, _ = self.stem.forward(xp, nt, hp, wp, ho=ho, wo=wo, bn=self.stem_bn)
         h2, w2 = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
@@ -640,12 +655,12 @@ class TrainEngine(_ParamStore):
             if stages is not None and (i + 1) in ends:
                 stages["layer%d" % (ends.index(i + 1) + 1)] = xcur.view(nt, hc, wc, cc)
         # head + loss
-        lab = labels.reshape(-1).to(device=x.device, dtype=torch.int64).contiguous()
+        lab = labels.reshape(-1).to(device=imgs.device, dtype=torch.int64).contiguous()
         mask = None
         if self.dropout > 0.0:
             keep = 1.0 - self.dropout
-            mask = (torch.rand(nt, cc, device=x.device) < keep).float().div_(keep)
-        dev = x.device
+            mask = (torch.rand(nt, cc, device=imgs.device) < keep).float().div_(keep)
+        dev = imgs.device
         f32 = torch.float32
         pooled = self.buf("pooled", (nt, cc), f32)
         scores = self.buf("scores", (b, self.num_classes), f32)
