@@ -12,6 +12,8 @@
 // the NCHW implementation in mvf_nchw.hip is complete).
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -372,6 +374,98 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_tapgrad_kernel(const ET* x,
     }
 }
 
+// Row-parallel form of the same sums: the rows (n, t, h, w) of the slice are cut into `nblk` contiguous ranges, a thread owns 4
+// channels of one row lane and walks its range with stride `nplanes`; the six neighbours (t-1, t+1, up, down, left, right) are
+// loaded UNCONDITIONALLY from a clamped row (the row itself when the neighbour is outside) and zeroed by a select afterwards, so the
+// eight loads of an iteration share one memory round trip (the (clip, band) kernel above waits for five of its seven loads one by
+// one and launches only clips x bands = 128 workgroups on the 14x14 layers: 116 us for 26 MB of reads).  Same partial layout
+// [block][c][7], same fixed-order finalize.
+template <typename ET>
+__global__ __launch_bounds__(kThreads) void mvf_nhwc_tapgrad_rows_kernel(const ET* x, int x_c, const ET* dy, int dy_c, int rows, int h, int w, int T,
+                                                                         int cs, int cgp, int rows_per_blk, float* part) {
+    __shared__ float4 red[kThreads];
+    const int HW = h * w;
+    const int cgi = blockIdx.y * cgp + (threadIdx.x % cgp);
+    const int plane = threadIdx.x / cgp, nplanes = kThreads / cgp;
+    const bool ok = cgi * 4 < cs;
+    const int c0 = cgi * 4;
+    float4 s[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r_begin = blockIdx.x * rows_per_blk, r_end = min(rows, r_begin + rows_per_blk);
+    if (ok) {
+        for (int r = r_begin + plane; r < r_end; r += nplanes) {
+            const int f = r / HW, pix = r - f * HW;          // frame (n*T + t), pixel
+            const int t = f % T, hh = pix / w, wv = pix - hh * w;
+            const bool vp = t > 0, vn = t + 1 < T, vu = hh > 0, vd = hh + 1 < h, vl = wv > 0, vr = wv + 1 < w;
+            const long b = (long)r * x_c + c0;
+            const float4 xc = ld4(x + b);
+            const float4 xp = ld4(x + (vp ? b - (long)HW * x_c : b));
+            const float4 xn = ld4(x + (vn ? b + (long)HW * x_c : b));
+            const float4 xu = ld4(x + (vu ? b - (long)w * x_c : b));
+            const float4 xd = ld4(x + (vd ? b + (long)w * x_c : b));
+            const float4 xl = ld4(x + (vl ? b - x_c : b));
+            const float4 xr = ld4(x + (vr ? b + x_c : b));
+            const float4 d = ld4(dy + (long)r * dy_c + c0);
+#define ACCM(k, v, on) { const float m = (on) ? 1.f : 0.f; s[k].x += d.x * (v.x * m); s[k].y += d.y * (v.y * m); s[k].z += d.z * (v.z * m); s[k].w += d.w * (v.w * m); }
+            ACCM(0, xp, vp) ACCM(1, xn, vn) ACCM(2, xu, vu) ACCM(3, xd, vd) ACCM(4, xl, vl) ACCM(5, xr, vr) ACCM(6, xc, true)
+#undef ACCM
+        }
+    }
+    for (int i = 0; i < 7; ++i) {
+        __syncthreads();
+        red[threadIdx.x] = s[i];
+        __syncthreads();
+        if (plane == 0 && ok) {
+            float4 tsum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < nplanes; ++q) {
+                const float4 v = red[q * cgp + (threadIdx.x % cgp)];
+                tsum.x += v.x; tsum.y += v.y; tsum.z += v.z; tsum.w += v.w;
+            }
+            float* p = part + ((long)blockIdx.x * cs + c0) * 7;
+            p[i] = tsum.x; p[7 + i] = tsum.y; p[14 + i] = tsum.z; p[21 + i] = tsum.w;
+        }
+    }
+}
+
+// 16 (channel, tap sum) outputs x 16 block-lanes per workgroup: lane l sums blocks l, l+16, ... (two accumulators), the 16 lane
+// sums are combined in lane order through LDS -> fixed summation order, 64-byte coalesced reads, cs*7/16 workgroups
+__global__ __launch_bounds__(256) void mvf_tapgrad_finalize_rows_kernel(const float* part, int nblk, int cs, int mode, float* dwt, float* dwh, float* dww) {
+    __shared__ double red[16][16];
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + e;
+    const int n = cs * 7;
+    double a0 = 0, a1 = 0;
+    if (j < n) {
+        int b = sl;
+        for (; b + 16 < nblk; b += 32) {
+            a0 += part[(long)b * n + j];
+            a1 += part[(long)(b + 16) * n + j];
+        }
+        if (b < nblk) a0 += part[(long)b * n + j];
+    }
+    red[sl][e] = a0 + a1;
+    __syncthreads();
+    if (sl != 0 || j >= n) return;
+    double t = 0;
+    for (int q = 0; q < 16; ++q) t += red[q][e];
+    const float v = (float)t;
+    const int c = j / 7, i = j - c * 7;
+    const bool on_h = mode & MVF_VIEW_H, on_w = mode & MVF_VIEW_W;
+    switch (i) {
+        case 0: dwt[c * 3 + 0] = v; break;
+        case 1: dwt[c * 3 + 2] = v; break;
+        case 2: if (dwh) dwh[c * 3 + 0] = on_h ? v : 0.f; break;
+        case 3: if (dwh) dwh[c * 3 + 2] = on_h ? v : 0.f; break;
+        case 4: if (dww) dww[c * 3 + 0] = on_w ? v : 0.f; break;
+        case 5: if (dww) dww[c * 3 + 2] = on_w ? v : 0.f; break;
+        default:
+            dwt[c * 3 + 1] = v;
+            if (dwh) dwh[c * 3 + 1] = on_h ? v : 0.f;
+            if (dww) dww[c * 3 + 1] = on_w ? v : 0.f;
+    }
+}
+
 __global__ void mvf_tapgrad_finalize_kernel(const float* part, int nblk, int cs, int mode, float* dwt, float* dwh, float* dww) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cs) return;
@@ -381,6 +475,31 @@ __global__ void mvf_tapgrad_finalize_kernel(const float* part, int nblk, int cs,
     dwt[c * 3 + 0] = (float)s[0]; dwt[c * 3 + 1] = (float)s[6]; dwt[c * 3 + 2] = (float)s[1];
     if (dwh) { const bool on = mode & MVF_VIEW_H; dwh[c * 3 + 0] = on ? (float)s[2] : 0.f; dwh[c * 3 + 1] = on ? (float)s[6] : 0.f; dwh[c * 3 + 2] = on ? (float)s[3] : 0.f; }
     if (dww) { const bool on = mode & MVF_VIEW_W; dww[c * 3 + 0] = on ? (float)s[4] : 0.f; dww[c * 3 + 1] = on ? (float)s[6] : 0.f; dww[c * 3 + 2] = on ? (float)s[5] : 0.f; }
+}
+
+struct TapRows { int cgp, gy, rows_per_blk, nblk; };
+TapRows tap_rows_plan(long rows, int cs) {
+    TapRows p;
+    const int cg = cs / 4;
+    int cgp = 1;
+    while (cgp < cg && cgp < kThreads) cgp <<= 1;
+    p.cgp = cgp;
+    p.gy = (cg + cgp - 1) / cgp;
+    const int nplanes = kThreads / cgp;
+    // ~512 workgroups (2 per CU) per channel slab, at least 4 rows per row lane
+    long rpb = std::max<long>((rows + 511) / 512, (long)nplanes * 4);
+    rpb = (rpb + nplanes - 1) / nplanes * nplanes;
+    p.rows_per_blk = (int)rpb;
+    p.nblk = (int)((rows + rpb - 1) / rpb);
+    return p;
+}
+int g_tap_rows = -1;      // MVF_TAPGRAD_ROWS=0 keeps the (clip, band) kernel (A/B switch)
+bool tap_rows_on() {
+    if (g_tap_rows < 0) {
+        const char* e = getenv("MVF_TAPGRAD_ROWS");
+        g_tap_rows = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_tap_rows != 0;
 }
 
 struct TapPlan { int cgp, pixw, bands, gy; };
@@ -421,7 +540,9 @@ int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int
 size_t mvf_nhwc_tapgrad_workspace_bytes(const mvf_desc_t* d) {
     if (!d || d->cs <= 0 || d->cs % 4) return 0;
     TapPlan p = tap_plan(d->nt / d->n_segment, d->h * d->w, d->cs);
-    return align_up((size_t)(d->nt / d->n_segment) * p.bands * d->cs * 7 * sizeof(float), 256);
+    TapRows q = tap_rows_plan((long)d->nt * d->h * d->w, d->cs);
+    const size_t a = (size_t)(d->nt / d->n_segment) * p.bands * d->cs * 7 * sizeof(float), b = (size_t)q.nblk * d->cs * 7 * sizeof(float);
+    return align_up(std::max(a, b), 256);
 }
 
 // dw_t/dw_h/dw_w [cs][3] = tap gradients of the three views given dy (pitch dy_c) and the forward input x (pitch x_c)
@@ -430,9 +551,24 @@ int mvf_nhwc_tapgrad(const mvf_desc_t* d, const void* x, int x_c, const void* dy
     MVF_REQUIRE(d && x && dy && dw_t && d->cs % 4 == 0 && x_c % 4 == 0 && dy_c % 4 == 0, MVF_EINVAL, "nhwc_tapgrad: bad argument (cs %% 4?)");
     MVF_REQUIRE(ws && ws_bytes >= mvf_nhwc_tapgrad_workspace_bytes(d), MVF_EWS, "nhwc_tapgrad: workspace too small");
     const int n_clips = d->nt / d->n_segment;
+    hipStream_t st = (hipStream_t)stream;
+    if (tap_rows_on() && (long)d->nt * d->h * d->w < (1L << 31)) {
+        const int rows = d->nt * d->h * d->w;
+        TapRows q = tap_rows_plan(rows, d->cs);
+        dim3 grid(q.nblk, q.gy);
+        if (d->dtype == MVF_F32)
+            hipLaunchKernelGGL(mvf_nhwc_tapgrad_rows_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)x, x_c, (const float*)dy, dy_c, rows, d->h, d->w,
+                               d->n_segment, d->cs, q.cgp, q.rows_per_blk, (float*)ws);
+        else
+            hipLaunchKernelGGL(mvf_nhwc_tapgrad_rows_kernel<bf16_t>, grid, dim3(kThreads), 0, st, (const bf16_t*)x, x_c, (const bf16_t*)dy, dy_c, rows, d->h, d->w,
+                               d->n_segment, d->cs, q.cgp, q.rows_per_blk, (float*)ws);
+        MVF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mvf_tapgrad_finalize_rows_kernel, dim3((d->cs * 7 + 15) / 16), dim3(256), 0, st, (const float*)ws, q.nblk, d->cs, d->mode, dw_t, dw_h, dw_w);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     TapPlan p = tap_plan(n_clips, d->h * d->w, d->cs);
     dim3 grid(n_clips * p.bands, p.gy);
-    hipStream_t st = (hipStream_t)stream;
     if (d->dtype == MVF_F32)
         hipLaunchKernelGGL(mvf_nhwc_tapgrad_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)x, x_c, (const float*)dy, dy_c, d->nt, d->h, d->w, d->n_segment, d->cs, p.cgp, p.pixw, p.bands, (float*)ws);
     else
