@@ -242,6 +242,17 @@ size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d);
 int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real,
                           int cin_real, int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes,
                           void* stream);
+/* Every weight pack of a training step in one launch.  jobs_dev = DEVICE array of njobs records sorted by first_block;
+ * job k owns workgroups [first_block, first_block + ceil(elements / 2048)), total_blocks = their sum.  kind 0 = the forward
+ * pack of mvf_pack_conv_weight (no scale), kind 1 = the data-gradient pack of mvf_pack_conv_weight_dgrad. */
+typedef struct {
+    const float* w;      /* fp32 OIHW parameter */
+    void* out;           /* packed operand in `dtype` */
+    int cout, cin, kh, kw, kw_pad, cin_pad;
+    int kind, first_block;
+} mvf_pack_job_t;
+int mvf_pack_conv_weights_batched(const mvf_pack_job_t* jobs_dev, int njobs, int total_blocks, int dtype, void* stream);
+
 /* data gradient = mvf_conv2d_nhwc_fwd on dz with these weights: packed[ci][kh'][kw'][co] = w[co][ci][KH-1-kh'][KW-1-kw'],
  * pad' = k-1-pad, stride 1, in_dil = forward stride */
 int mvf_pack_conv_weight_dgrad(const float* w_oihw, int cout, int cin, int kh, int kw, void* w_packed, int dtype,

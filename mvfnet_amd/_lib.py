@@ -32,6 +32,11 @@ class ConvDesc(C.Structure):
                 ("res_c0", C.c_int32)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("kw_pad", C.c_int32), ("cin_pad", C.c_int32), ("kind", C.c_int32), ("first_block", C.c_int32)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -73,6 +78,8 @@ def _load():
     lib.mvf_conv2d_nhwc_fwd_stats.argtypes = [cp, vp, vp, vp, vp, fp, fp, vp, sz, vp]
     lib.mvf_pack_conv_weight.restype = i32
     lib.mvf_pack_conv_weight.argtypes = [fp, i32, i32, i32, i32, i32, i32, fp, vp, i32, vp]
+    lib.mvf_pack_conv_weights_batched.restype = i32
+    lib.mvf_pack_conv_weights_batched.argtypes = [vp, i32, i32, i32, vp]
     lib.mvf_bn_fold.restype = i32
     lib.mvf_bn_fold.argtypes = [fp, fp, fp, fp, f32, i32, fp, fp, vp]
     lib.mvf_stem_prep.restype = i32

@@ -408,6 +408,45 @@ __global__ void pack_dgrad_weight_kernel(const float* w, int cout, int cin, int 
     }
 }
 
+// All weight packs of a step in ONE launch (53 forward + 52 data-gradient packs are ~5 us of dispatch each when launched one
+// by one): workgroup b serves the job whose [first_block, next first_block) range holds b, 2048 elements per workgroup.
+// kind 0: out[co][kh][kw_pad][cin_pad] = w[co][ci][kh][kw] (zero padded)      (= pack_weight_kernel, no scale)
+// kind 1: out[ci][kh'][kw'][co] = w[co][ci][KH-1-kh'][KW-1-kw']               (= pack_dgrad_weight_kernel)
+template <typename ET>
+__global__ __launch_bounds__(256) void pack_batched_kernel(const mvf_pack_job_t* jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                          // last job with first_block <= blockIdx.x (wave-uniform binary search)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mvf_pack_job_t j = jobs[lo];
+    const float* w = j.w;
+    ET* out = reinterpret_cast<ET*>(j.out);
+    const long base = (long)((int)blockIdx.x - j.first_block) * 2048;
+    const long total = j.kind == 0 ? (long)j.cout * j.kh * j.kw_pad * j.cin_pad : (long)j.cin * j.kh * j.kw * j.cout;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i >= total) break;
+        long t = i;
+        float v = 0.f;
+        if (j.kind == 0) {
+            const int ci = (int)(t % j.cin_pad); t /= j.cin_pad;
+            const int x = (int)(t % j.kw_pad); t /= j.kw_pad;
+            const int yk = (int)(t % j.kh);
+            const int co = (int)(t / j.kh);
+            if (ci < j.cin && x < j.kw) v = w[(((long)co * j.cin + ci) * j.kh + yk) * j.kw + x];
+        } else {
+            const int co = (int)(t % j.cout); t /= j.cout;
+            const int x = (int)(t % j.kw); t /= j.kw;
+            const int y = (int)(t % j.kh);
+            const int ci = (int)(t / j.kh);
+            v = w[(((long)co * j.cin + ci) * j.kh + (j.kh - 1 - y)) * j.kw + (j.kw - 1 - x)];
+        }
+        stf(out + i, v);
+    }
+}
+
 int plan_split(int M, int tiles) {
     int want = std::max(1, 1024 / std::max(tiles, 1));
     int rows = std::max((M + want - 1) / want, 256);
@@ -484,6 +523,16 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, a.part, nsplit,
                        d->cout, cin_real, kh_p, kw_real, kw_packed, cin_packed, dw_oihw);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_pack_conv_weights_batched(const mvf_pack_job_t* jobs_dev, int njobs, int total_blocks, int dtype, void* stream) {
+    MVF_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && (dtype == MVF_F32 || dtype == MVF_BF16), MVF_EINVAL, "pack_conv_weights_batched: bad argument");
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(pack_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    else
+        hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

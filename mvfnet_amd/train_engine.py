@@ -154,6 +154,14 @@ class _TConv(object):
         if need_dgrad:
             self.pack_dgrad()
 
+    def pack_jobs(self):
+        """(forward job | None, data-gradient job | None) as (w, out, cout, cin, kh, kw, kw_pad, cin_pad, kind) tuples for the
+        batched pack kernel -- the same packs as pack() / pack_dgrad()."""
+        if self.stem:
+            return (self.w, self.wp, self.cout, self.cin, self.kh, self.kw, 8, 4, 0), None
+        fwd = None if self.wp is self.w else (self.w, self.wp, self.cout, self.cin, self.kh, self.kw, self.kw, self.cin, 0)
+        return fwd, (self.w, self.wd, self.cout, self.cin, self.kh, self.kw, self.kw, self.cin, 1)
+
     def pack_dgrad(self):
         if not self.stem:
             check(lib.mvf_pack_conv_weight_dgrad(_p(self.w), self.cout, self.cin, self.kh, self.kw, _p(self.wd), self.eng.dt, _st()), "pack_dgrad")
@@ -594,6 +602,33 @@ class TrainEngine(_ParamStore):
         # uint8 input path (preprocess.FramePipeline): decoded frames in, crop / flip / normalise fused into the stem prep;
         # input_window = per-frame (y0, x0, flip) rows for the NEXT forward (None = top-left window, no flip)
         self.input_pipeline, self.input_window = None, None
+        self._pack_tables = None
+
+    def _pack_all(self, kind):
+        """All forward (kind 0) or data-gradient (kind 1) weight packs in ONE launch (mvf_pack_conv_weights_batched); the job
+        table is built once -- parameters and packed operands are persistent buffers."""
+        if self._pack_tables is None:
+            self._pack_tables = {}
+            convs = [self.stem] + [cv for blk in self.blocks for cv in blk.convs()]
+            for k in (0, 1):
+                jobs, first = [], 0
+                for cv in convs:
+                    j = cv.pack_jobs()[k]
+                    if j is None:
+                        continue
+                    w, out, cout, cin, kh, kw, kwp, cinp, kd = j
+                    total = cout * kh * kwp * cinp if kd == 0 else cin * kh * kw * cout
+                    jobs.append(_lib.PackJob(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, kwp, cinp, kd, first))
+                    first += (total + 2047) // 2048
+                if not jobs:
+                    self._pack_tables[k] = None
+                    continue
+                arr = (_lib.PackJob * len(jobs))(*jobs)
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                self._pack_tables[k] = (host.to(self.device), len(jobs), first)
+        t = self._pack_tables[kind]
+        if t is not None:
+            check(lib.mvf_pack_conv_weights_batched(_p(t[0]), t[1], t[2], self.dt, _st()), "pack_conv_weights_batched")
 
     # ---- one step -----------------------------------------------------------------------------------------------
     def forward(self, imgs, labels, stages=None):
@@ -617,18 +652,13 @@ class TrainEngine(_ParamStore):
         else:
             x = imgs.reshape((-1, 3) + tuple(imgs.shape[3:])).contiguous()
             nt, _, h, w = x.shape
-        self.stem.pack()
-        for blk in self.blocks:
-            for cv in blk.convs():
-                cv.pack(need_dgrad=False)
+        self._pack_all(0)                                  # every forward weight pack, one launch
         # the data-gradient packs are not needed before backward: off the critical path, on the side stream
         side = self.side_stream()
         if side is not None:
             side.wait_stream(self.main_stream())           # after the previous step's parameter update
         with _on_stream(side if side is not None else self.main_stream()):
-            for blk in self.blocks:
-                for cv in blk.convs():
-                    cv.pack_dgrad()
+            self._pack_all(1)
         self._packs_on_side = side is not None
         hp, wp = h + 6, (w + 6 + 2 + 1) // 2 * 2
         xp = self.buf("xp", (nt, hp, wp, 4))

@@ -610,3 +610,30 @@ def test_two_bucket_gradient_exchange_matches_flat_allreduce_single_rank():
         assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_batched_weight_pack_equals_the_per_conv_packs(dtype):
+    """mvf_pack_conv_weights_batched (one launch for every forward / data-gradient pack of the step) writes exactly what the
+    per-conv pack entry points write."""
+    import mvfnet_amd
+    m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(50, 4), None, dict(average_clips=None)).cuda().train()
+    eng = m.train_engine(dtype=dtype) if getattr(m, "_train_engine", None) is None else m.train_engine()
+    convs = [eng.stem] + [cv for blk in eng.blocks for cv in blk.convs()]
+    for cv in convs:
+        cv.pack(need_dgrad=True)
+    torch.cuda.synchronize()
+    want = [(cv.wp.clone(), None if cv.wd is None else cv.wd.clone()) for cv in convs]
+    for cv in convs:
+        if cv.wp is not cv.w:
+            cv.wp.fill_(7.0)
+        if cv.wd is not None:
+            cv.wd.fill_(7.0)
+    eng._pack_all(0)
+    eng._pack_all(1)
+    torch.cuda.synchronize()
+    for cv, (wp, wd) in zip(convs, want):
+        assert torch.equal(cv.wp, wp)
+        if wd is not None:
+            assert torch.equal(cv.wd, wd)
