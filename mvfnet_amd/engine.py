@@ -213,7 +213,10 @@ class BackboneEngine(object):
     def _forward_multi(self, x, ns, T, window=None):
         cur = torch.cuda.current_stream()
         if not hasattr(self, "_pool") or len(self._pool) != ns:
-            self._pool = [torch.cuda.Stream() for _ in range(ns)]
+            from .streams import concurrent_stream
+            self._pool = []
+            for _ in range(ns):                      # chains on streams that share a hardware queue would just run in turn
+                self._pool.append(concurrent_stream(cur, avoid=self._pool))
         clips = x.shape[0] // T
         per = (clips + ns - 1) // ns
         outs, parts = [], []

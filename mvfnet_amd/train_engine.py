@@ -486,7 +486,8 @@ class _ParamStore(object):
         if not self.overlap_wgrad:
             return None
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream()
+            from .streams import concurrent_stream
+            self._side = concurrent_stream(self.main_stream())      # not every new stream gets its own hardware queue (streams.py)
         return self._side
 
     def main_stream(self):

@@ -637,3 +637,17 @@ def test_batched_weight_pack_equals_the_per_conv_packs(dtype):
         assert torch.equal(cv.wp, wp)
         if wd is not None:
             assert torch.equal(cv.wd, wd)
+
+
+@pytest.mark.gpu
+def test_side_stream_really_runs_beside_the_launch_stream():
+    """streams.concurrent_stream: the stream it returns overtakes a spin kernel on the launch stream (a stream that shares the
+    launch stream's hardware queue cannot), also after many other streams were created (what torch.distributed does)."""
+    from mvfnet_amd.streams import concurrent_stream, runs_beside
+    main = torch.cuda.current_stream()
+    junk = [torch.cuda.Stream() for _ in range(7)]          # shift the round-robin stream -> queue assignment
+    s = concurrent_stream(main)
+    assert runs_beside(main, s)
+    s2 = concurrent_stream(main, avoid=[s])
+    assert runs_beside(main, s2) and runs_beside(s, s2)
+    del junk
