@@ -103,10 +103,11 @@ class Recognizer2D(nn.Module):
         gradient buffer), as the reference's DistOptimizerHook expects."""
         if not imgs.is_cuda:
             raise RuntimeError("Recognizer2D: mvfnet_amd runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
-        bn_train = [m.training for m in self.backbone.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
-        if not all(bn_train):
-            raise NotImplementedError("forward_train with eval-mode (frozen) BatchNorm is not built; the shipped MVFNet "
-                                      "configs train with norm_eval=False")
+        # BatchNorms in eval mode (backbone norm_eval=True, reference resnet.py:496-505) normalise with their running statistics
+        # and keep them; what is NOT built is excluding parameters from the update (frozen_stages / norm_frozen / partial_norm)
+        if not all(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("forward_train with parameters excluded from training (frozen_stages >= 0, norm_frozen, "
+                                      "partial_norm) is not built; norm_eval=True alone is")
         eng = self.train_engine()
         eng.input_pipeline, eng.input_window = getattr(self, "input_pipeline", None), kwargs.get("window")
         eng.dropout = self.cls_head.dropout_ratio if (self.cls_head.dropout is not None and self.cls_head.training) else 0.0

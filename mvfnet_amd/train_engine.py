@@ -72,7 +72,24 @@ class _BN(object):
         self.scale = torch.empty(self.c, device=dev)
         self.shift = torch.empty(self.c, device=dev)
 
+    @property
+    def frozen(self):
+        """The module is in eval mode (ResNet(norm_eval=True).train(), reference resnet.py:496-505): normalise with the running
+        statistics, leave them untouched; gamma / beta still get gradients."""
+        return not self.mod.training
+
+    def use_running_stats(self):
+        """Coefficients of a frozen-statistics BN for this step: mean / invstd from the running buffers, folded scale / shift."""
+        check(lib.mvf_bn_fold(_p(self.gamma), _p(self.beta), _p(self.mod.running_mean), _p(self.mod.running_var), C.c_float(self.eps), self.c,
+                              _p(self.scale), _p(self.shift), _st()), "mvf_bn_fold")
+        self.mean.copy_(self.mod.running_mean)
+        torch.rsqrt(self.mod.running_var + self.eps, out=self.invstd)
+        if getattr(self, "_zero", None) is None:
+            self._zero = torch.zeros(self.c, device=self.mean.device)
+
     def stats(self, z, m, eng):
+        if self.frozen:
+            return self.use_running_stats()
         ws = eng.workspace(lib.mvf_bn_workspace_bytes(m, self.c))
         check(lib.mvf_bn_train_stats(_p(z), m, self.c, _p(self.gamma), _p(self.beta), C.c_float(self.eps), C.c_float(self.momentum),
                                      _p(self.mod.running_mean), _p(self.mod.running_var), _p(self.mean), _p(self.invstd), _p(self.scale),
@@ -118,8 +135,11 @@ class _BN(object):
     def _apply_bwd(self, g, g_pitch, z, m, eng, mask_mode, ymask, gm_out):
         src, pitch, mode = (gm_out, self.c, 0) if gm_out is not None else (g, g_pitch, mask_mode)
         dz = eng.buf((id(self), "dz"), z.shape, z.dtype)
+        # frozen statistics: mean and variance do not depend on z, so dz = gamma * invstd * (masked g) -- the batch-statistics
+        # formula with its two correction sums set to zero (dgamma / dbeta themselves are still the real sums)
+        sg, sb = (self._zero, self._zero) if self.frozen else (self.dgamma, self.dbeta)
         check(lib.mvf_bn_bwd_apply_masked(_p(src), pitch, _p(z), _p(ymask) if mode in (1, 4) else None, m, self.c, _p(self.gamma), _p(self.mean),
-                                          _p(self.invstd), _p(self.scale), _p(self.shift), _p(self.dgamma), _p(self.dbeta), mode, _p(dz), eng.dt,
+                                          _p(self.invstd), _p(self.scale), _p(self.shift), _p(sg), _p(sb), mode, _p(dz), eng.dt,
                                           _st()), "mvf_bn_bwd_apply")
         return dz
 
@@ -182,7 +202,7 @@ class _TConv(object):
         d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
         z = self.eng.buf((id(self), "z"), (n * ho * wo, self.cout))
         ws = _conv_ws(x.device)
-        if bn is None or not self.eng.fuse_stats:
+        if bn is None or not self.eng.fuse_stats or bn.frozen:
             self.launch_fwd(d, x, x2, z, ws, None, None)
             if bn is not None:
                 bn.stats(z, n * ho * wo, self.eng)

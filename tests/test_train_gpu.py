@@ -393,6 +393,82 @@ def test_c1_train_two_steps_vs_reference_golden():
                 assert rel_err(a[: g[k].size], g[k]) < 0.1, nme
 
 
+def test_norm_eval_training_vs_reference_golden():
+    """backbone norm_eval=True (reference resnet.py:496-505): every BatchNorm -- the 53 of the ResNet and the 9 inside the MVF
+    modules -- normalises with its running statistics and leaves them alone, gamma / beta still train.  Two clip + SGD-nesterov
+    steps against the reference's own run (tests/golden/normeval_cases.npz).  Without batch statistics the network is
+    well-conditioned, so the tolerances are tight everywhere."""
+    import mvfnet_amd
+    g = golden("normeval_cases.npz")
+    cfg = mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0)
+    cfg["backbone"]["norm_eval"] = True
+    m = mvfnet_amd.build_recognizer(cfg, None, dict(average_clips=None))
+    sd = m.state_dict()
+    vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in sd}, strict=True)
+    m = m.cuda().train()
+    bns = [x for x in m.backbone.modules() if isinstance(x, torch.nn.modules.batchnorm._BatchNorm)]
+    assert len(bns) == 62 and not any(x.training for x in bns)
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    eng = m.train_engine()
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 96, 96, seed=77)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+    loss = eng.forward(imgs, labels)
+    assert abs(float(loss) - float(g["loss/0"])) < 2e-5 * float(g["loss/0"])
+    eng.backward()
+    params = dict(m.named_parameters())
+    for nme, r in zip(list(g["grad_names"]), g["grad_norms"]):
+        got = float(eng.grad_of(params[nme]).double().norm())
+        assert abs(got - r) < 2e-3 * max(r, 1e-6), (nme, got, r)
+    for k in g.files:
+        if k.startswith("grad/"):
+            assert rel_err(eng.grad_of(params[k[5:]]).cpu().numpy(), g[k]) < 2e-3, k
+    norm = eng.step()
+    assert abs(float(norm[0]) - float(g["total_norm/0"])) < 1e-3 * float(g["total_norm/0"])
+    loss1 = eng.forward(imgs, labels)
+    assert abs(float(loss1) - float(g["loss/1"])) < 2e-3 * float(g["loss/1"])
+    eng.backward()
+    norm = eng.step()
+    assert abs(float(norm[0]) - float(g["total_norm/1"])) < 5e-3 * float(g["total_norm/1"])
+    sd = m.state_dict()
+    for k, v in before.items():
+        assert torch.equal(sd[k], v), k                       # frozen statistics (and step counters) did not move
+    for k in g.files:
+        if k.startswith("after2/"):
+            a = sd[k[7:]].detach().float().cpu().numpy().ravel()
+            assert rel_err(a[: g[k].size], g[k]) < 2e-3, k
+
+
+def test_norm_eval_training_bf16_close_to_fp32():
+    import mvfnet_amd
+    g = golden("normeval_cases.npz")
+    cfg = mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0)
+    cfg["backbone"]["norm_eval"] = True
+    m = mvfnet_amd.build_recognizer(cfg, None, dict(average_clips=None))
+    sd = m.state_dict()
+    vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in sd}, strict=True)
+    m = m.cuda().train()
+    eng = m.train_engine(dtype=torch.bfloat16)
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 96, 96, seed=77)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+    loss = eng.forward(imgs, labels)
+    assert abs(float(loss) - float(g["loss/0"])) < 2e-2 * float(g["loss/0"])
+    eng.backward()
+    norm = eng.step()
+    assert abs(float(norm[0]) - float(g["total_norm/0"])) < 5e-2 * float(g["total_norm/0"])
+
+
+def test_parameters_excluded_from_training_are_refused():
+    import mvfnet_amd
+    cfg = mvfnet_amd.mvfnet_config(50, 4)
+    cfg["backbone"]["frozen_stages"] = 1
+    m = mvfnet_amd.build_recognizer(cfg, None, dict(average_clips=None)).cuda().train()
+    imgs = torch.zeros(1, 4, 3, 64, 64, device="cuda")
+    with pytest.raises(NotImplementedError):
+        m(imgs, torch.zeros(1, 1, dtype=torch.int64, device="cuda"))
+
+
 def test_forward_train_autograd_api_and_external_optimizer():
     """The reference's flow: losses = model(img_group, label); loss.backward(); clip; optimizer.step() with torch SGD."""
     m = _model(50, 4)
