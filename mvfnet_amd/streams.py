@@ -31,11 +31,16 @@ def concurrent_stream(main=None, avoid=(), tries=12):
     """A new stream that overlaps with `main` (and with every stream in `avoid`).  Falls back to the last candidate when none of
     `tries` does (a device with a single queue) -- correctness never depends on the overlap, only speed."""
     main = main or torch.cuda.current_stream()
+    if not hasattr(torch.cuda, "_sleep"):          # no spin kernel to measure against: take the stream on faith
+        return torch.cuda.Stream()
     cand = None
     keep = []                                     # rejected candidates stay alive until the search ends: a destroyed stream's
     for _ in range(tries):                        # queue slot would be handed straight to the next candidate
         cand = torch.cuda.Stream()
-        if all(runs_beside(s, cand) for s in (main,) + tuple(avoid)):
+        try:
+            if all(runs_beside(s, cand) for s in (main,) + tuple(avoid)):
+                return cand
+        except RuntimeError:                      # event timing unavailable (e.g. inside a graph capture): keep the candidate
             return cand
         keep.append(cand)
     return cand
