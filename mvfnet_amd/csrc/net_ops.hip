@@ -63,7 +63,9 @@ __global__ void frames_prep_kernel(const unsigned char* frames, int n, int hs, i
     }
 }
 
-// MaxPool2d(3, 2, 1) NHWC; thread = (output pixel, 4 channels)
+// MaxPool2d(3, 2, 1) NHWC; thread = (output pixel, 4 channels).  The nine window loads are UNCONDITIONAL on clamped coordinates (a
+// clamped tap re-reads a pixel that is inside the window anyway, so the maximum is unchanged): a load inside an `if` is waited
+// for on the spot, nine serial round trips per output instead of one.
 template <typename ET>
 __global__ void maxpool_kernel(const ET* x, int n, int h, int w, int c, int ho, int wo, ET* y) {
     const int c4 = c >> 2;
@@ -74,33 +76,60 @@ __global__ void maxpool_kernel(const ET* x, int n, int h, int w, int c, int ho, 
         const int ow = (int)(t % wo); t /= wo;
         const int oh = (int)(t % ho);
         const int img = (int)(t / ho);
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        const ET* base = x + (long)img * h * w * c + cq * 4;
+        float4 v[9];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const int ih = oh * 2 - 1 + dy;
-            if (ih < 0 || ih >= h) continue;
+            const int ih = min(max(oh * 2 - 1 + dy, 0), h - 1);
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int iw = ow * 2 - 1 + dx;
-                if (iw < 0 || iw >= w) continue;
-                float4 v = ld4(x + (((long)img * h + ih) * w + iw) * c + cq * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                const int iw = min(max(ow * 2 - 1 + dx, 0), w - 1);
+                v[dy * 3 + dx] = ld4(base + ((long)ih * w + iw) * c);
             }
+        }
+        float4 m = v[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) {
+            m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w);
         }
         st4(y + (((long)img * ho + oh) * wo + ow) * c + cq * 4, m);
     }
 }
 
 // pooled[clip][ch] = mean over the clip's T*HW feature rows; lanes along channels (coalesced rows)
+// workgroup = 64 channels (16 lanes x 4) x 16 row lanes: 8/16-byte loads, four rows in flight per thread, the 16 row-lane sums
+// combined in lane order through LDS (fixed order).  The one-thread-per-channel form walked the clip's 392 rows serially with
+// 2-byte loads from 128 workgroups: 134 us for 51 MB.
 template <typename ET>
-__global__ void head_pool_kernel(const ET* feat, int rows_per_clip, int c, float* pooled) {
-    const int clip = blockIdx.y;
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    const ET* p = feat + (long)clip * rows_per_clip * c + ch;
-    float s = 0.f;
-    for (int r = 0; r < rows_per_clip; ++r) s += ldf(p + (long)r * c);
-    pooled[(long)clip * c + ch] = s / (float)rows_per_clip;
+__global__ __launch_bounds__(256) void head_pool_kernel(const ET* feat, int rows_per_clip, int c, float* pooled) {
+    __shared__ float4 red[256];
+    const int clip = blockIdx.y, q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = (blockIdx.x * 16 + q) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < c) {
+        const ET* p = feat + (long)clip * rows_per_clip * c + ch;
+        int r = rl;
+        for (; r + 48 < rows_per_clip; r += 64) {
+            const float4 a = ld4(p + (long)r * c), b = ld4(p + (long)(r + 16) * c), d = ld4(p + (long)(r + 32) * c), e = ld4(p + (long)(r + 48) * c);
+            s.x += (a.x + b.x) + (d.x + e.x); s.y += (a.y + b.y) + (d.y + e.y);
+            s.z += (a.z + b.z) + (d.z + e.z); s.w += (a.w + b.w) + (d.w + e.w);
+        }
+        for (; r < rows_per_clip; r += 16) {
+            const float4 a = ld4(p + (long)r * c);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && ch < c) {
+        float4 t = red[q];
+        for (int l = 1; l < 16; ++l) {
+            const float4 v = red[l * 16 + q];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        const float inv = 1.f / (float)rows_per_clip;
+        *reinterpret_cast<float4*>(pooled + (long)clip * c + ch) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
 }
 
 // scores[clip][k] = b[k] + pooled[clip] . W[k]; one wave per (clip, class)
@@ -219,7 +248,8 @@ int mvf_head_pool_fc(const void* feat, int clips, int t, int hw, int c, const fl
                      float* pooled_ws, float* scores, int dtype, void* stream) {
     MVF_REQUIRE(feat && fc_w && pooled_ws && scores && clips > 0 && t > 0 && hw > 0 && c > 0 && classes > 0, MVF_EINVAL, "head_pool_fc: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    dim3 g((c + 255) / 256, clips);
+    MVF_REQUIRE(c % 4 == 0, MVF_ESHAPE, "head_pool_fc: c=%d must be a multiple of 4", c);
+    dim3 g((c + 63) / 64, clips);
     if (dtype == MVF_F32)
         hipLaunchKernelGGL(head_pool_kernel<float>, g, dim3(256), 0, st, (const float*)feat, t * hw, c, pooled_ws);
     else
