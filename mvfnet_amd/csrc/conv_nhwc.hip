@@ -975,6 +975,7 @@ struct SkHost {
 // fp32 -- occupancy hides more latency than the second buffer does (bf16 27.97 -> 26.96 ms, fp32 83.0 -> 79.6 ms per step).
 int g_lowk_max_chunks = 1 << 30;
 int g_pf2_mode = 1;              // two-chunk register prefetch: 0 off, 1 bf16 only, 2 both dtypes (MVF_CONV_PF2)
+int g_glds1_f32_infer = 1;       // fp32: only the inference epilogues (bias + ReLU [+ residual]) take it by default (MVF_CONV_GLDS1_F32=0/1)
 int g_glds1_max = -1;            // single-buffer LDS-DMA kernel (4 workgroups per CU) up to this many K chunks: -1 = default policy
                                  // (bf16: 8), 0 = off (MVF_CONV_GLDS1)
 int g_big_min = 0;               // 256 x 128 LDS-DMA tile from this many K chunks on (MVF_CONV_BIG; 0 = off)
@@ -988,6 +989,8 @@ int sk_slots() {
         if (e && e[0] >= '0' && e[0] <= '9') g_lowk_max_chunks = atoi(e);
         e = getenv("MVF_CONV_PF2");
         if (e && e[0] >= '0' && e[0] <= '2') g_pf2_mode = e[0] - '0';
+        e = getenv("MVF_CONV_GLDS1_F32");
+        if (e && (e[0] == '0' || e[0] == '1')) g_glds1_f32_infer = e[0] - '0';
         e = getenv("MVF_CONV_GLDS1");
         if (e && e[0] >= '0' && e[0] <= '9') g_glds1_max = atoi(e);
         e = getenv("MVF_CONV_BIG");
@@ -1089,7 +1092,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         // dominates these launches (ablation: with loads AND MFMAs removed the conv launches still take 58 % of their time).
         // Not for the BatchNorm-sum data gradient (its epilogue spills at 128 registers) and not for fp32 unless forced.
         const bool bnsum_epi = contiguous && a.bn_z && !a.bias && !a.relu && !a.res;
-        const int glds1_max = g_glds1_max >= 0 ? g_glds1_max : (sizeof(ET) == 2 ? 8 : 0);
+        const int glds1_max = g_glds1_max >= 0 ? g_glds1_max : ((sizeof(ET) == 2 || (infer_like && g_glds1_f32_infer)) ? 8 : 0);
         if (glds1_max > 0 && a.nchunks <= glds1_max && !(bnsum_epi && g_glds1_max < 0)) {
             int rc;
             if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(1, tiles, st, a);
