@@ -103,12 +103,11 @@ class Recognizer2D(nn.Module):
         gradient buffer), as the reference's DistOptimizerHook expects."""
         if not imgs.is_cuda:
             raise RuntimeError("Recognizer2D: mvfnet_amd runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
-        # BatchNorms in eval mode (backbone norm_eval=True, reference resnet.py:496-505) normalise with their running statistics
-        # and keep them; what is NOT built is excluding parameters from the update (frozen_stages / norm_frozen / partial_norm)
-        if not all(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("forward_train with parameters excluded from training (frozen_stages >= 0, norm_frozen, "
-                                      "partial_norm) is not built; norm_eval=True alone is")
+        # BatchNorms in eval mode (backbone norm_eval=True / frozen stages, reference resnet.py:496-527) normalise with their running
+        # statistics and keep them; parameters excluded from training are supported as a prefix of model.parameters()
+        # (frozen_stages), scattered exclusions (norm_frozen, partial_norm) raise NotImplementedError here
         eng = self.train_engine()
+        eng.trainable_offset()
         eng.input_pipeline, eng.input_window = getattr(self, "input_pipeline", None), kwargs.get("window")
         eng.dropout = self.cls_head.dropout_ratio if (self.cls_head.dropout is not None and self.cls_head.training) else 0.0
         params = [p for p in self.parameters()]

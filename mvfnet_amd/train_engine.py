@@ -620,6 +620,7 @@ class TrainEngine(_ParamStore):
             self._nbt_flat[i] = m_.num_batches_tracked.to(self.device)
             m_.num_batches_tracked = self._nbt_flat[i]
         self._nbt_touched = False
+        self._nbt_mods, self._nbt_inc = bns, {}      # increment vectors per pattern of training / eval BatchNorms (frozen ones keep theirs)
         # uint8 input path (preprocess.FramePipeline): decoded frames in, crop / flip / normalise fused into the stem prep;
         # input_window = per-frame (y0, x0, flip) rows for the NEXT forward (None = top-left window, no flip)
         self.input_pipeline, self.input_window = None, None
@@ -722,7 +723,13 @@ class TrainEngine(_ParamStore):
                                      _p(scores), _p(dscores), _p(loss_part), _p(loss), self.dt, _st()), "head fwd")
         self.saved.update(pooled=pooled, dscores=dscores, mask=mask, hw=hc * wc, c=cc, feat_shape=xcur.shape, scores=scores)
         if self._nbt_touched:                     # one launch for every BatchNorm's step counter
-            self._nbt_flat += 1
+            key = tuple(m_.training for m_ in self._nbt_mods)
+            if all(key):
+                self._nbt_flat += 1
+            else:                                 # BatchNorms in eval mode (norm_eval / frozen stages) do not count the step
+                if key not in self._nbt_inc:
+                    self._nbt_inc[key] = torch.tensor([int(k) for k in key] or [0], dtype=torch.int64, device=self.device)
+                self._nbt_flat += self._nbt_inc[key]
             self._nbt_touched = False
         return loss.clone()                      # `loss` itself is a persistent buffer that the next step overwrites
 
@@ -801,11 +808,28 @@ class TrainEngine(_ParamStore):
         with _on_stream(torch.cuda.current_stream()):
             return self._step(lr)
 
+    def trainable_offset(self):
+        """Flat-buffer offset of the first trainable parameter.  Parameters excluded from training (requires_grad False: the
+        reference's frozen_stages, resnet.py:515-527) are supported when they form a PREFIX of model.parameters() -- stem, then
+        layer1..k, which is what frozen_stages produces: the optimizer (norm, clip, weight decay, momentum, update) then simply
+        runs on the rest of the flat buffers, as torch's clip_grad_norm_ / SGD skip parameters without a gradient.  Scattered
+        exclusions (norm_frozen, partial_norm) are refused."""
+        params = list(self.model.parameters())
+        flags = [p.requires_grad for p in params]
+        k = flags.index(True) if True in flags else len(flags)
+        if not all(flags[k:]):
+            raise NotImplementedError("parameters excluded from training must be a prefix of model.parameters() (frozen_stages); "
+                                      "norm_frozen / partial_norm style exclusions are not built")
+        return self._grad_view[id(params[k])].storage_offset() if k < len(params) else self.flat_params.numel()
+
     def _step(self, lr=None):
         world = self.allreduce_grads()
-        n = self.flat_params.numel()
+        off = self.trainable_offset()
+        n = self.flat_params.numel() - off
+        if n <= 0:
+            return self.norm_out
         ws = self.workspace(lib.mvf_sgd_workspace_bytes(n))
-        check(lib.mvf_sgd_nesterov_step(_p(self.flat_params), _p(self.flat_grads), _p(self.flat_mom), n, C.c_float(1.0 / world),
+        check(lib.mvf_sgd_nesterov_step(_p(self.flat_params[off:]), _p(self.flat_grads[off:]), _p(self.flat_mom[off:]), n, C.c_float(1.0 / world),
                                         C.c_float(self.max_norm or 0.0), C.c_float(self.lr if lr is None else lr), C.c_float(self.momentum),
                                         C.c_float(self.weight_decay), int(self.steps == 0), _p(self.norm_out), _p(ws), ws.numel(), _st()), "sgd step")
         self.steps += 1

@@ -459,11 +459,53 @@ def test_norm_eval_training_bf16_close_to_fp32():
     assert abs(float(norm[0]) - float(g["total_norm/0"])) < 5e-2 * float(g["total_norm/0"])
 
 
-def test_parameters_excluded_from_training_are_refused():
+def test_frozen_stages_training_vs_reference_golden():
+    """frozen_stages=1 (reference resnet.py:515-527): stem + layer1 in eval mode and excluded from training -- a prefix of the flat
+    parameter buffer, so norm / clip / weight decay / momentum / update run on the rest only.  Two steps against the reference's own
+    run (clip active: total norm 131 > 40); layers 2-4 keep batch-statistics BN with 2 clips, hence the c1-style tolerances."""
     import mvfnet_amd
-    cfg = mvfnet_amd.mvfnet_config(50, 4)
+    g = golden("frozen_cases.npz")
+    cfg = mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0)
     cfg["backbone"]["frozen_stages"] = 1
-    m = mvfnet_amd.build_recognizer(cfg, None, dict(average_clips=None)).cuda().train()
+    m = mvfnet_amd.build_recognizer(cfg, None, dict(average_clips=None))
+    sd = m.state_dict()
+    vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in sd}, strict=True)
+    m = m.cuda().train()
+    frozen = sorted(n for n, p in m.named_parameters() if not p.requires_grad)
+    assert frozen == sorted(g["frozen_names"])
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    eng = m.train_engine()
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 96, 96, seed=78)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+    loss = eng.forward(imgs, labels)
+    assert abs(float(loss) - float(g["loss/0"])) < 1e-4 * float(g["loss/0"])
+    eng.backward()
+    params = dict(m.named_parameters())
+    for nme, r in zip(list(g["grad_names"]), g["grad_norms"]):
+        got = float(eng.grad_of(params[nme]).double().norm())
+        tol = 3e-3 if (nme.startswith("cls_head") or nme.startswith("backbone.layer4.2")) else 3e-2
+        assert abs(got - r) < tol * max(r, 1e-6), (nme, got, r)
+    norm = eng.step()
+    assert abs(float(norm[0]) - float(g["total_norm/0"])) < 5e-3 * float(g["total_norm/0"])
+    loss1 = eng.forward(imgs, labels)
+    assert abs(float(loss1) - float(g["loss/1"])) < 2e-2 * float(g["loss/1"])
+    eng.backward()
+    eng.step()
+    sd = m.state_dict()
+    for k in frozen + ["backbone.bn1.running_mean", "backbone.layer1.2.bn3.running_var", "backbone.layer1.0.bn1.num_batches_tracked"]:
+        assert torch.equal(sd[k], sd0[k]), k                      # excluded parameters and frozen statistics did not move
+    assert not torch.equal(sd["backbone.layer2.0.bn1.running_mean"], sd0["backbone.layer2.0.bn1.running_mean"])
+    for k in g.files:
+        if k.startswith("after2/"):
+            a = sd[k[7:]].detach().float().cpu().numpy().ravel()
+            assert rel_err(a[: g[k].size], g[k]) < 0.1, k
+
+
+def test_scattered_parameter_exclusion_is_refused():
+    import mvfnet_amd
+    m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(50, 4), None, dict(average_clips=None)).cuda().train()
+    m.backbone.layer3[0].bn2.weight.requires_grad = False          # what norm_frozen / partial_norm produce: not a prefix
     imgs = torch.zeros(1, 4, 3, 64, 64, device="cuda")
     with pytest.raises(NotImplementedError):
         m(imgs, torch.zeros(1, 1, dtype=torch.int64, device="cuda"))
