@@ -53,7 +53,8 @@ struct ConvArgs {
     int res_c0;    // residual only for output channels >= res_c0
     const unsigned char* res_mask;   // optional [M][Cout/4] bytes: bit j of byte k gates residual channel 4k+j (ReLU sign bits)
     int mask_lds;  // stage the gate bytes in LDS (experiment switch MVF_MASK_LDS=0)
-    int prio;      // experiment switch MVF_CONV_PRIO=1: raise the wave priority around the MFMA phase of the LDS-DMA loops
+    int prio;      // experiment switch MVF_CONV_PRIO=1: raise the wave priority around the MFMA phase of the LDS-DMA loops; in
+                   // -DMVF_CONV_ABLATE builds bits 1-5 additionally switch parts of the kernel OFF (timing ablation, wrong results)
     int dil;       // input dilation (generic fallback; the strided data-gradient is normally decomposed into parity classes)
     int pad_w;     // horizontal padding (pad = vertical)
     int w_kh0, w_kw0, w_ts, w_kwfull;   // weight tap (kh,kw) of this launch = full-pack tap (kh0 + kh*ts, kw0 + kw*ts)
@@ -483,8 +484,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         for (int kc = 0; kc < nseg; ++kc) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                           // chunk kc has landed for every wave; the buffer of chunk kc-1 is free
-            if (kc + 1 < nseg && !(a.prio & 4)) load_chunk(s0, (kc + 1) & 1);
+#ifdef MVF_CONV_ABLATE
+            if (kc + 1 < nseg && !(a.prio & 4)) load_chunk(s0, (kc + 1) & 1);      // ablation: bit 2 = no loads, bit 1 = no MFMAs
             if (!(a.prio & 2)) compute(kc & 1);
+#else
+            if (kc + 1 < nseg) load_chunk(s0, (kc + 1) & 1);
+            compute(kc & 1);
+#endif
         }
         __syncthreads();
     } else if constexpr (LOWK) {
@@ -1253,7 +1259,11 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     static const int mask_lds_on = getenv("MVF_MASK_LDS") ? atoi(getenv("MVF_MASK_LDS")) : 1;
     a.mask_lds = mask_lds_on;
     static const int prio_on = getenv("MVF_CONV_PRIO") ? atoi(getenv("MVF_CONV_PRIO")) : 0;
-    a.prio = prio_on;
+#ifdef MVF_CONV_ABLATE
+    a.prio = prio_on;                 // ablation builds: bit 0 priority, bits 1-5 remove loads / MFMAs / epilogue parts (wrong results)
+#else
+    a.prio = prio_on & 1;             // product builds: only the wave-priority experiment
+#endif
     a.M = d->n * d->ho * d->wo;
     a.cpt = (d->cin + ce - 1) / ce;
     a.nchunks = d->kh * d->kw * a.cpt;
