@@ -974,9 +974,8 @@ int mvf_head_train_bwd(const float* dscores, const float* pooled, const float* f
     MVF_REQUIRE(dscores && pooled && fc_w && dfc_w && dfc_b && dpool_ws && dfeat, MVF_EINVAL, "head_train_bwd: NULL argument");
     hipStream_t st = (hipStream_t)stream;
     MVF_REQUIRE(c % 4 == 0, MVF_ESHAPE, "head_train_bwd: c=%d must be a multiple of 4", c);
-    // the clips' mean features go to the head of the dfeat buffer (>= clips*c floats: t*hw*esz >= 4), which the last kernel of this
-    // call overwrites with its real content
-    float* pcm = reinterpret_cast<float*>(dfeat);
+    // the clips' mean features borrow dpool_ws ([clips][c] floats), which the NEXT kernel of this call overwrites with its real content
+    float* pcm = dpool_ws;
     hipLaunchKernelGGL(head_clipmean_kernel, dim3((c + 255) / 256, clips), dim3(256), 0, st, pooled, t, c, pcm);
     MVF_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_fc_bwd_w_kernel, dim3((c + 255) / 256, (classes + kHeadKc - 1) / kHeadKc), dim3(256), 0, st, dscores, pcm, clips, t, c, classes, dfc_w, dfc_b);
