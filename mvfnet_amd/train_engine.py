@@ -404,6 +404,8 @@ class _TBlock(object):
         else:
             da1 = self.c2.dgrad(dz2, nt, ho, wo, h, w)
         self.c2.wgrad(dz2, s["a1"], nt, h, w, ho, wo, eng)
+        if eng.side_batch == 2:
+            eng.flush_side()                       # conv3's and conv2's weight gradients behind ONE cross-stream hand-over
         del dz2
         dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2, sums_done=fuse1)
         del da1
@@ -450,6 +452,7 @@ class _ParamStore(object):
             raise RuntimeError("the HIP training engine needs the model on an MI355X device; no CPU fallback")
         self.model, self.device = model, dev
         self._side_pending = []
+        self._side_keep = []
         params = [p for p in model.parameters()]
         n = sum(p.numel() for p in params)
         pad = lambda k: (k + 3) // 4 * 4
@@ -514,12 +517,22 @@ class _ParamStore(object):
         ms = getattr(self, "_main", None)
         return ms if ms is not None else torch.cuda.current_stream()
 
-    defer_side = False         # True: side-stream launches of a block are queued behind ONE cross-stream wait (flush_side)
+    # cross-stream hand-overs per block (each costs a ~7 us bubble on the launch queue): 0 = one per side launch (4-5 per block),
+    # 1 = one per block (defer_side; default: bf16 step 23.55 -> 23.14 ms), 2 = two per block (after conv2's weight gradient and
+    # at the block's end: 23.26 ms)
+    side_batch = int(os.environ.get("MVF_SIDE_BATCH", "1"))
+    defer_side = side_batch > 0
 
     def on_side(self, launch):
         """Run `launch` (which enqueues kernels through _st()) on the side stream, ordered after everything queued on the main
         stream so far.  Each cross-stream wait costs an event packet on the main queue; with defer_side the launches are
         collected and flush_side() issues them behind one wait."""
+        # the closure (and with it every tensor the side kernels read or write: dz, activations, the side workspace of the moment)
+        # stays referenced until join_side() has ordered the launch stream behind the side stream: tensors are allocated on the
+        # launch stream, so dropping the last reference earlier lets the caching allocator hand their memory to the next
+        # launch-stream allocation while the side kernels are still using it (seen as wrong gradients in the FIRST step of an
+        # engine, when buffers are still being created, once hand-overs were batched per block)
+        self._side_keep.append(launch)
         if self.defer_side:
             self._side_pending.append(launch)
             return
@@ -541,6 +554,7 @@ class _ParamStore(object):
         self.flush_side()
         if getattr(self, "_side", None) is not None:
             self.main_stream().wait_stream(self._side)
+        del self._side_keep[:]                      # from here on the launch stream is ordered behind every side kernel
 
     def add(self, a, b, key=None):
         """a + b (elementwise) through mvf_bn_apply with unit scale / zero shift."""
