@@ -609,7 +609,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     const bool e_relu = EPI == 0 ? a.relu != 0 : (EPI == 4 || EPI == 5);
     const bool e_stats = EPI == 0 ? a.stats_part != nullptr : EPI == 1;
     constexpr bool e_bnb = EPI == 6;                     // BatchNorm-backward sums instead of forward statistics
-    const bool e_scatter = EPI == 0 && a.o_s > 0;
+    const bool e_scatter = (EPI == 0 || EPI == 6) && a.o_s > 0;      // a strided data gradient's parity class (plain or + BN sums)
     constexpr int CP = BN * 4 + 16;                      // C-tile pitch in bytes
     constexpr int NH = (LOWK || GLDS) ? 2 : 1;           // epilogue passes (row halves of the block tile)
     constexpr int HR = BM / NH;                          // rows per pass
@@ -1075,11 +1075,12 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         const bool contiguous = (epi_spec & 1) && a.o_s <= 0;
         const bool train_like = contiguous && !a.bias && !a.relu;
         const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
+        const bool bnsum_epi = (epi_spec & 1) && a.bn_z && !a.bias && !a.relu && !a.res;      // contiguous or a scattered parity class
         // long K, wide output: the 256 x 128 LDS-DMA tile (MVF_CONV_BIG = <min chunks>, 0 = off)
         if (BN == 128 && g_big_min > 0 && a.nchunks >= g_big_min && a.Cout >= 128 && a.M >= 256) {
             int rc;
             if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_big<ET, 1>(st, a);
-            else if (contiguous && a.bn_z && !a.bias && !a.relu && !a.res) rc = launch_big<ET, 6>(st, a);
+            else if (bnsum_epi) rc = launch_big<ET, 6>(st, a);
             else if (train_like && !a.stats_part && !a.res) rc = launch_big<ET, 2>(st, a);
             else if (train_like && !a.stats_part && a.res) rc = launch_big<ET, 3>(st, a);
             else if (infer_like && !a.res) rc = launch_big<ET, 4>(st, a);
@@ -1097,7 +1098,6 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         // of the per-tile fixed latency chain (kernel arguments -> offsets -> first chunk -> epilogue -> store drain) that
         // dominates these launches (ablation: with loads AND MFMAs removed the conv launches still take 58 % of their time).
         // Not for the BatchNorm-sum data gradient (its epilogue spills at 128 registers) and not for fp32 unless forced.
-        const bool bnsum_epi = contiguous && a.bn_z && !a.bias && !a.relu && !a.res;
         const int glds1_max = g_glds1_max >= 0 ? g_glds1_max : ((sizeof(ET) == 2 || (infer_like && g_glds1_f32_infer)) ? 8 : 0);
         if (glds1_max > 0 && a.nchunks <= glds1_max && !(bnsum_epi && g_glds1_max < 0)) {
             int rc;
@@ -1116,7 +1116,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         if ((g_glds_min > 0 && a.nchunks >= g_glds_min) || glds_auto) {
             int rc;
             if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(g_glds_nb, tiles, st, a);
-            else if (contiguous && a.bn_z && !a.bias && !a.relu && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 6>(g_glds_nb, tiles, st, a);
+            else if (bnsum_epi) rc = launch_glds<ET, WM, WN, TM, TN, 6>(g_glds_nb, tiles, st, a);
             else if (train_like && !a.stats_part && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 2>(g_glds_nb, tiles, st, a);
             else if (train_like && !a.stats_part && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 3>(g_glds_nb, tiles, st, a);
             else if (infer_like && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 4>(g_glds_nb, tiles, st, a);
@@ -1127,7 +1127,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
             return MVF_OK;
         }
         if (train_like && a.stats_part && !a.res && !a.bn_z) launch_lowk<ET, WM, WN, TM, TN, 1>(pw, tiles, lds_lk, st, a);
-        else if (contiguous && a.bn_z && !a.bias && !a.relu && !a.res) launch_lowk<ET, WM, WN, TM, TN, 6>(pw, tiles, lds_lk, st, a);
+        else if (bnsum_epi) launch_lowk<ET, WM, WN, TM, TN, 6>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && !a.res) launch_lowk<ET, WM, WN, TM, TN, 2>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && a.res) launch_lowk<ET, WM, WN, TM, TN, 3>(pw, tiles, lds_lk, st, a);
         else if (infer_like && !a.res) launch_lowk<ET, WM, WN, TM, TN, 4>(pw, tiles, lds_lk, st, a);
@@ -1191,7 +1191,6 @@ int mvf_conv2d_nhwc_dgrad_bnsums(const mvf_conv_desc_t* d, const void* dz, const
                                  const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
                                  float* sums_part, void* ws, size_t ws_bytes, void* stream) {
     MVF_REQUIRE(d && bn_z && bn_mean && bn_invstd && bn_scale && bn_shift && sums_part, MVF_EINVAL, "conv2d_dgrad_bnsums: NULL argument");
-    MVF_REQUIRE(d->in_dil <= 1, MVF_EUNSUPPORTED, "conv2d_dgrad_bnsums: stride-1 data gradients only (strided ones scatter parity classes)");
     const BnBwdSums b = {bn_z, bn_mean, bn_invstd, bn_scale, bn_shift};
     return conv_fwd_impl(d, dz, nullptr, w_packed_dgrad, nullptr, nullptr, y, sums_part, nullptr, ws, ws_bytes, stream, nullptr, &b);
 }
@@ -1210,6 +1209,15 @@ int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* 
 
 int mvf_conv2d_stats_rows(const mvf_conv_desc_t* d) {
     if (!d || d->n <= 0 || d->ho <= 0 || d->wo <= 0) return 0;
+    if (d->in_dil > 1) {                 // strided data gradient: one run of 128-row partials per parity class, back to back
+        long rows = 0;
+        for (int ph = 0; ph < d->in_dil; ++ph)
+            for (int pw = 0; pw < d->in_dil; ++pw) {
+                const long ho = (d->ho - ph + d->in_dil - 1) / d->in_dil, wo = (d->wo - pw + d->in_dil - 1) / d->in_dil;
+                if (ho > 0 && wo > 0) rows += ((long)d->n * ho * wo + kBM - 1) / kBM;
+            }
+        return (int)rows;
+    }
     return (int)(((long)d->n * d->ho * d->wo + kBM - 1) / kBM);
 }
 
@@ -1290,6 +1298,7 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     // parity classes (ih % s, iw % s) are independent plain stride-1 convs over the gradient map with ceil(k/s)-tap
     // kernels: s*s launches doing k*k/(s*s) of the zero-upsampled work (9 taps instead of 36 for a 3x3 stride-2 conv).
     const int s_ = dil;
+    long part_rows = 0;                  // statistics partials of the classes already launched (mvf_conv2d_stats_rows order)
     for (int ph = 0; ph < s_; ++ph)
         for (int pw = 0; pw < s_; ++pw) {
             ConvArgs c = a;
@@ -1308,6 +1317,8 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
             c.M = d->n * c.Ho * c.Wo;
             c.nchunks = c.KH * c.KW * c.cpt;
             c.o_s = s_; c.o_ph = ph; c.o_pw = pw; c.o_hfull = d->ho; c.o_wfull = d->wo;
+            if (a.stats_part) c.stats_part = a.stats_part + part_rows * d->cout * 2;
+            part_rows += ((long)c.M + kBM - 1) / kBM;
             int rc = launch(c);
             if (rc) return rc;
         }

@@ -240,9 +240,11 @@ class _TConv(object):
         # dz / x / x2 are persistent engine buffers (eng.buf) or tensors the caller keeps alive until join_side()
 
     def dgrad_bnsums(self, dz, n, ho, wo, h, w, bn, z):
-        """Stride-1 data gradient that also accumulates the backward sums of `bn` (the ReLU(BN(z)) its output feeds) in its
-        epilogue and finalises dgamma / dbeta: bn.backward(..., sums_done=True) then only needs the apply pass."""
-        d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, self.eng.dt, 0, 0, 0, 0, 0)
+        """Data gradient that also accumulates the backward sums of `bn` (the ReLU(BN(z)) its output feeds) in its epilogue and
+        finalises dgamma / dbeta: bn.backward(..., sums_done=True) then only needs the apply pass.  A strided conv's data gradient
+        runs as its parity classes, each adding its own run of partial rows."""
+        d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, self.eng.dt, 0, 0, 0,
+                     self.stride if self.stride > 1 else 0, 0)
         dx = self.eng.buf((id(self), "dx"), (n * h * w, self.cin))
         ws = _conv_ws(dz.device)
         rows = lib.mvf_conv2d_stats_rows(C.byref(d))
@@ -398,7 +400,7 @@ class _TBlock(object):
         del dz3
         dz2 = self.b2.backward(da2, self.c2.cout, s["z2"], m2, eng, 2, sums_done=fuse)
         del da2
-        fuse1 = fuse and self.c2.stride == 1
+        fuse1 = fuse and (self.c2.stride == 1 or eng.fuse_bn_bwd_strided)
         if fuse1:
             da1 = self.c2.dgrad_bnsums(dz2, nt, ho, wo, h, w, self.b1, s["z1"])
         else:
@@ -504,6 +506,7 @@ class _ParamStore(object):
     overlap_wgrad = True
     fuse_stats = True          # BatchNorm batch statistics accumulated in the producing conv's epilogue
     fuse_bn_bwd_sums = os.environ.get("MVF_FUSE_BN_BWD", "1") != "0"    # ... and the backward sums in the data gradient's
+    fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes
 
     def side_stream(self):
         if not self.overlap_wgrad:

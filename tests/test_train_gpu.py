@@ -169,6 +169,47 @@ def test_dgrad_bnsums_equals_separate_reduce(shape, dtype):
     assert rel_err(dg.cpu().numpy(), dg2.cpu().numpy()) < 2e-6 and rel_err(db.cpu().numpy(), db2.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 13, 11, 128, 64, 3, 2), (3, 8, 8, 64, 128, 1, 2), (1, 28, 28, 256, 256, 3, 2), (2, 7, 9, 64, 64, 3, 2)], ids=str)
+def test_strided_dgrad_bnsums_equals_separate_reduce(shape, dtype):
+    """The same for a stride-2 conv's data gradient, which runs as four parity classes scattering into the full-resolution map:
+    identical gradient, and the four runs of partial rows finalise to mvf_bn_bwd_reduce's sums."""
+    from mvfnet_amd import _lib
+    from mvfnet_amd._lib import ConvDesc
+    lib, check = _lib.lib, _lib.check
+    n, h, w, cout, cin, k, st = shape                      # h, w = the conv's INPUT map (= the data gradient's output map)
+    dt = 0 if dtype == torch.float32 else 1
+    g = torch.Generator().manual_seed(3)
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // st + 1, (w + 2 * pad - k) // st + 1
+    m_out, m_in = n * ho * wo, n * h * w
+    dz = (torch.randn(m_out, cout, generator=g) * 0.5).to(dtype).cuda()
+    wgt = (torch.randn(cout, cin, k, k, generator=g) * 0.05).cuda()
+    wd = torch.empty(cin, k, k, cout, dtype=dtype, device="cuda")
+    check(lib.mvf_pack_conv_weight_dgrad(P(wgt), cout, cin, k, k, P(wd), dt, None))
+    z = torch.randn(m_in, cin, generator=g).to(dtype).cuda()
+    mean, invstd = torch.randn(cin, generator=g).cuda() * 0.1, (torch.rand(cin, generator=g) + 0.5).cuda()
+    scale, shift = (torch.rand(cin, generator=g) + 0.5).cuda(), torch.randn(cin, generator=g).cuda() * 0.3
+    d = ConvDesc(n, ho, wo, cout, cin, k, k, 1, k - 1 - pad, h, w, cout, dt, 0, 0, 0, st, 0)
+    ws = torch.zeros(max(lib.mvf_conv2d_workspace_bytes(C.byref(d)), 1), dtype=torch.uint8, device="cuda")
+    y1 = torch.full((m_in, cin), 7.0, dtype=dtype, device="cuda")
+    y2 = torch.full((m_in, cin), 7.0, dtype=dtype, device="cuda")
+    rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+    assert rows >= (m_in + 127) // 128
+    part = torch.full((rows, cin, 2), float("nan"), device="cuda")          # every partial row must be written
+    check(lib.mvf_conv2d_nhwc_dgrad_bnsums(C.byref(d), P(dz), P(wd), P(y1), P(z), P(mean), P(invstd), P(scale), P(shift), P(part), P(ws), ws.numel(), None))
+    dg, db = torch.empty(cin, device="cuda"), torch.empty(cin, device="cuda")
+    check(lib.mvf_bn_bwd_finalize(P(part), rows, cin, P(dg), P(db), None))
+    check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(dz), None, P(wd), None, None, P(y2), P(ws), ws.numel(), None))
+    ws2 = torch.empty(lib.mvf_bn_workspace_bytes(m_in, cin), dtype=torch.uint8, device="cuda")
+    dg2, db2 = torch.empty(cin, device="cuda"), torch.empty(cin, device="cuda")
+    check(lib.mvf_bn_bwd_reduce(P(y2), cin, P(z), None, m_in, cin, P(mean), P(invstd), P(scale), P(shift), 2, None, P(dg2), P(db2), P(ws2), ws2.numel(), dt, None))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    assert torch.isfinite(part).all()
+    assert rel_err(dg.cpu().numpy(), dg2.cpu().numpy()) < 2e-6 and rel_err(db.cpu().numpy(), db2.cpu().numpy()) < 2e-6
+
+
 # (n, h, w, cin, cout, k, stride, pad)
 GRAD_CASES = [(2, 8, 8, 64, 32, 1, 1, 0), (2, 9, 9, 32, 64, 3, 1, 1), (2, 10, 10, 32, 32, 3, 2, 1), (3, 8, 8, 64, 128, 1, 2, 0),
               (1, 14, 14, 256, 256, 3, 1, 1), (2, 7, 7, 132, 36, 3, 1, 1),
