@@ -31,12 +31,11 @@ import os
 import sys
 import time
 
-# more hardware queues than ROCm's default 4: with a process group up, c10d / RCCL create their own streams and the fewer queues
-# there are, the likelier the collective's stream shares one with the launch stream (mvfnet_amd/streams.py picks OUR side streams
-# by measurement; the collective's stream is c10d's choice).  No effect on the single-process numbers (24.22 vs 24.22 ms).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES is deliberately left at ROCm's default of 4: with a torch.distributed process group up, 8 hardware queues
+# made the same step 46 % slower -- 34.4 vs 23.6 ms on one MI355X, BENCH_FORCE_DIST=1 -- although it is neutral without one.
+# Side streams are picked by measurement instead, mvfnet_amd/streams.py.)
 
-import torch  # noqa: E402
+import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
