@@ -810,3 +810,28 @@ def test_side_stream_really_runs_beside_the_launch_stream():
     s2 = concurrent_stream(main, avoid=[s])
     assert runs_beside(main, s2) and runs_beside(s, s2)
     del junk
+
+
+@pytest.mark.gpu
+def test_process_group_does_not_cost_the_stream_overlap():
+    """With a torch.distributed process group up (RCCL, one rank) the train step must run at the single-process speed: the
+    gradient exchange of one rank is free, so any gap means the side stream lost its hardware queue (mvfnet_amd/streams.py) or the
+    queue configuration went wrong (GPU_MAX_HW_QUEUES=8 cost 46 %).  bench.py in two child processes, 15 % tolerance."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra_env, launcher):
+        env = dict(os.environ, **extra_env)
+        cmd = launcher + [os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--clips", "16"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=repo)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
+
+    plain = run({}, [sys.executable])
+    port = str(29600 + os.getpid() % 300)
+    dist_ms = run({"BENCH_FORCE_DIST": "1"}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                                              "--master-addr", "127.0.0.1", "--master-port", port])
+    assert dist_ms < 1.15 * plain, (plain, dist_ms)
