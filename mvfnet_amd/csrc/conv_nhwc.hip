@@ -106,25 +106,6 @@ __host__ __device__ constexpr int kLowkLds() {
     return (BM + BN) * kPitch > (BM / 2) * (BN * 4 + 16) + BM * (BN / 4) ? (BM + BN) * kPitch : (BM / 2) * (BN * 4 + 16) + BM * (BN / 4);
 }
 
-// LDS-DMA issued from inline asm: hipcc counts a builtin LDS-DMA as a pending LDS write and drains it (vmcnt(0)) before the
-// next ds_read -- exactly the overlap this variant exists for -- so the statement is hidden from its bookkeeping and the loop
-// waits for it explicitly (cdna_hip_programming.md, "What hipcc does not do" item 1).  M0 = wave-uniform LDS byte address.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 rsrc_words(const void* base, unsigned nbytes) {
-    const unsigned long p = (unsigned long)base;
-    i32x4 r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
-    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xffffu));
-    r.z = __builtin_amdgcn_readfirstlane((int)nbytes);
-    r.w = 0x00020000;
-    return r;
-}
-__device__ __forceinline__ void glds16(const i32x4 rs, const unsigned lds_dst, const unsigned voff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs) : "memory");
-}
-
 // dynamic LDS of the LDS-DMA variant: NB unpadded A/B tile buffers (128-B rows), or the half C tile + gate bytes
 template <int BM, int BN, int NB>
 __host__ __device__ constexpr int kGldsLds() {

@@ -12,6 +12,8 @@
 // Reference: autograd of nn.Conv2d in Bottleneck.forward (codes/models/backbones/resnet.py:208-244).
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -177,7 +179,12 @@ __device__ __forceinline__ int swz16(int row) {
 }
 constexpr int BMR16 = 64;                            // pixels per chunk = 4 MFMA k-steps
 
-template <int TM, int TN>
+// DMA = true: both operand tiles go global -> LDS by LDS-DMA (see conv_nhwc.hip / common.h glds16): no staging registers, no
+// ds_write pass.  The DMA writes lane-linearly, so the XOR image of the transpose reads is made on the SOURCE side: the lane at
+// position q of row r fetches unit q ^ swz16(r) (constant per thread: every pass advances the row by a multiple of 4).  Padding /
+// out-of-range taps, rows past the split and channel tails are out-of-range buffer offsets = DMA'd zeros.  Not for the MVF
+// split operand (two source tensors inside one wave instruction).
+template <int TM, int TN, bool DMA = false>
 __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
     constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
     // LDS images stay in the natural [pixel][channel] layout (16-byte coalesced staging writes, no padding); the MFMA
@@ -198,7 +205,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
     const int co0 = tile_co * BCO, k0 = tile_k * BK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int qa = tid % UA, ra0 = tid / UA, qb = tid % UB, rb0 = tid / UB;
+    const int ra0 = tid / UA, rb0 = tid / UB;
+    const int qa = DMA ? ((tid % UA) ^ swz16<UA>(ra0)) : tid % UA;       // DMA: the source unit that belongs at LDS position tid % U
+    const int qb = DMA ? ((tid % UB) ^ swz16<UB>(rb0)) : tid % UB;
     const int co = co0 + qa * 8;
     const bool co_ok = co < a.Cout;
     const int kcol = k0 + qb * 8;
@@ -228,6 +237,30 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
     const int hw_o = a.Ho * a.Wo;
     const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(dzp + (long)m_begin * a.Cout), 0, (unsigned)min((long)(m_end - m_begin) * a.Cout * 2, 0x7ffffff0L), 0x00020000);
+    // ---- DMA variant: descriptors as SGPR words, 32-bit byte offsets from the tensor base (host guarantees < 2 GB) ----
+    const i32x4 gs_dz = rsrc_words(dzp + (long)m_begin * a.Cout, (unsigned)min((long)(m_end - m_begin) * a.Cout * 2, 0x7ffffff0L));
+    const i32x4 gs_x = rsrc_words(a.x, (unsigned)min((long)a.N * a.H * a.W * a.xps * 2, 0x7ffffff0L));
+    const unsigned lds_d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)Ds + (wave * 64 / UA) * PA);
+    const unsigned lds_x0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)Xs + (wave * 64 / UB) * PB);
+    auto dma_chunk = [&](int c, int buf) {
+        const int mc = m_begin + c * BMR16;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = c * BMR16 + ra0 + (kThreads / UA) * i;
+            const unsigned off = co_ok ? (unsigned)(r * a.Cout + qa * 8 + co0) * 2u : kOOB;
+            glds16(gs_dz, lds_d0 + (unsigned)((buf * BMR16 + (kThreads / UA) * i) * PA), off);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int m = mc + rb0 + (kThreads / UB) * i;
+            const int img = wg_fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * hw_o;
+            const int oh = wg_fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
+            const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+            const bool ok = m < m_end && k_ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)(((img * a.H + ih) * a.W + iw) * ps + ci) * 2u : kOOB;
+            glds16(gs_x, lds_x0 + (unsigned)((buf * BMR16 + (kThreads / UB) * i) * PB), off);
+        }
+    };
     auto load_chunk = [&](int c, Stage& st) {
         const int mc = m_begin + c * BMR16;
 #pragma unroll
@@ -314,6 +347,30 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
     // round trip per chunk (16 MFMAs = 0.25 us of matrix work against ~2 us of latency), so keep two round trips in flight
     // The prefetch loads are UNCONDITIONAL (also past the last chunk: rows >= m_end read zeros / the tensor base): a conditional
     // load forces the compiler to assume no younger load is in flight at each static s_waitcnt, i.e. vmcnt(0) everywhere.
+    if constexpr (DMA) {
+        // two LDS buffers: chunk c+1 in flight under the MFMAs of chunk c; one barrier per chunk (conv_tile's GLDS >= 2 loop)
+        if (nchunks > 0) dma_chunk(0, 0);
+        for (int cc = 0; cc < nchunks; ++cc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (cc + 1 < nchunks) dma_chunk(cc + 1, (cc + 1) & 1);
+            compute(cc & 1);
+        }
+        float* outp = a.part + (long)wg_split * a.Cout * a.K;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = k0 + (wn * TN + j) * 32 + lc;
+            if (col >= a.K) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
+                    if (row < a.Cout) outp[(long)row * a.K + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     load_chunk(0, s0);
     load_chunk(1, s1);
     if (nchunks > 0) store_chunk(0, s0);
@@ -350,6 +407,23 @@ template <int TM, int TN>
 int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
     constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
     const size_t lds = (size_t)2 * BMR16 * (BCO * 2 + BK * 2);
+    // LDS-DMA loaders by default where they measured faster (R50 bf16 train step, per layer): +6-15 % on the 3x3 and the wide
+    // pointwise layers, -3-7 % on layer1's K = 64 pointwise convs and the stem (kept on the register-staged kernel); the MVF
+    // split operand cannot use them.  MVF_WGRAD_DMA=0 / 2 = never / wherever possible.  Weight gradients alone 5.23 -> 4.78 ms.
+    static const int dma_env = getenv("MVF_WGRAD_DMA") ? atoi(getenv("MVF_WGRAD_DMA")) : 1;
+    const bool dma = dma_env && a.split_c == 0 && (long)a.N * a.H * a.W * a.xps * 2 < 0x7ffffff0L &&
+                     (dma_env == 2 || (a.K >= 128 && a.Cin >= 32));
+    if (dma) {
+        auto kd = wgrad_bf16_kernel<TM, TN, true>;
+        static bool attr_d = false;
+        if (!attr_d) {
+            MVF_HIP_OK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_d = true;
+        }
+        hipLaunchKernelGGL(kd, dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), lds, st, a);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     auto kern = wgrad_bf16_kernel<TM, TN>;
     static bool attr_done = false;
     if (!attr_done) {

@@ -835,3 +835,18 @@ def test_process_group_does_not_cost_the_stream_overlap():
     dist_ms = run({"BENCH_FORCE_DIST": "1"}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                                               "--master-addr", "127.0.0.1", "--master-port", port])
     assert dist_ms < 1.15 * plain, (plain, dist_ms)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2"], ids=["register_staged_wgrad", "lds_dma_wgrad_everywhere"])
+def test_wgrad_loader_variants_forced_by_env(env):
+    """The weight-gradient loader choice is a per-process policy; both forced settings re-run this file's gradient comparisons
+    (conv weight gradients vs the oracle, whole-network goldens) in a child process."""
+    import os
+    import subprocess
+    import sys
+    k, v = env.split("=")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "conv_dgrad_wgrad or c1_train or norm_eval_training or bottleneck_train or stem_wgrad", "-p", "no:cacheprovider"],
+                       env=dict(os.environ, **{k: v}), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
