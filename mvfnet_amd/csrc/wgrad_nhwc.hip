@@ -239,7 +239,10 @@ __global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
         (void*)(dzp + (long)m_begin * a.Cout), 0, (unsigned)min((long)(m_end - m_begin) * a.Cout * 2, 0x7ffffff0L), 0x00020000);
     // ---- DMA variant: descriptors as SGPR words, 32-bit byte offsets from the tensor base (host guarantees < 2 GB) ----
     const i32x4 gs_dz = rsrc_words(dzp + (long)m_begin * a.Cout, (unsigned)min((long)(m_end - m_begin) * a.Cout * 2, 0x7ffffff0L));
-    const i32x4 gs_x = rsrc_words(a.x, (unsigned)min((long)a.N * a.H * a.W * a.xps * 2, 0x7ffffff0L));
+    // MVF split operand: channels < split_c of a tap come from x2 (pitch x2ps).  The host only takes this variant when split_c is
+    // a multiple of the tile's K width, so a whole workgroup reads one of the two tensors (from2 / ps are then uniform)
+    const bool x2u = a.split_c > 0 && (k0 % a.Cin) < a.split_c;
+    const i32x4 gs_x = rsrc_words(x2u ? a.x2 : a.x, (unsigned)min((long)a.N * a.H * a.W * (x2u ? a.x2ps : a.xps) * 2, 0x7ffffff0L));
     const unsigned lds_d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)Ds + (wave * 64 / UA) * PA);
     const unsigned lds_x0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)Xs + (wave * 64 / UB) * PB);
     auto dma_chunk = [&](int c, int buf) {
@@ -411,8 +414,8 @@ int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
     // pointwise layers, -3-7 % on layer1's K = 64 pointwise convs and the stem (kept on the register-staged kernel); the MVF
     // split operand cannot use them.  MVF_WGRAD_DMA=0 / 2 = never / wherever possible.  Weight gradients alone 5.23 -> 4.78 ms.
     static const int dma_env = getenv("MVF_WGRAD_DMA") ? atoi(getenv("MVF_WGRAD_DMA")) : 1;
-    const bool dma = dma_env && a.split_c == 0 && (long)a.N * a.H * a.W * a.xps * 2 < 0x7ffffff0L &&
-                     (dma_env == 2 || (a.K >= 128 && a.Cin >= 32));
+    const bool dma = dma_env && (a.split_c == 0 || (dma_env != 3 && a.split_c % BK == 0 && a.Cin % BK == 0)) &&
+                     (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 2 < 0x7ffffff0L && (dma_env == 2 || (a.K >= 128 && a.Cin >= 32));
     if (dma) {
         auto kd = wgrad_bf16_kernel<TM, TN, true>;
         static bool attr_d = false;
