@@ -838,7 +838,8 @@ def test_process_group_does_not_cost_the_stream_overlap():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2"], ids=["register_staged_wgrad", "lds_dma_wgrad_everywhere"])
+@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2", "MVF_WGRAD_DMA_F32=0"],
+                         ids=["register_staged_wgrad", "lds_dma_wgrad_everywhere", "register_staged_wgrad_f32"])
 def test_wgrad_loader_variants_forced_by_env(env):
     """The weight-gradient loader choice is a per-process policy; both forced settings re-run this file's gradient comparisons
     (conv weight gradients vs the oracle, whole-network goldens) in a child process."""
