@@ -8,20 +8,25 @@ namespace {
 
 // (n,c<=4,h,w) fp32 NCHW -> zero-padded NHWC4: out[n][ih+pad][iw+pad][0..3]; lanes run along w (coalesced reads
 // of each colour plane, 16-B/8-B stores).
+// grid.x = (image, padded row), threads along the padded row: no per-element 64-bit division, and the colour-plane loads are
+// unconditional on a clamped address (zeroed by a select) so the three of a pixel share one round trip
 template <typename ET>
 __global__ void stem_prep_kernel(const float* x, int n, int c, int h, int w, int pad, int hp, int wp, ET* out) {
-    const long total = (long)n * hp * wp;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int xo = (int)(i % wp);
-        const long t = i / wp;
-        const int yo = (int)(t % hp);
-        const int img = (int)(t / hp);
-        const int ih = yo - pad, iw = xo - pad;
+    const int row = blockIdx.x, img = row / hp, yo = row - img * hp;
+    const int ih = yo - pad;
+    const bool rok = ih >= 0 && ih < h;
+    const float* xi = x + ((long)img * c * h + (rok ? ih : 0)) * w;
+    for (int xo = threadIdx.x; xo < wp; xo += blockDim.x) {
+        const int iw = xo - pad;
+        const bool ok = rok && iw >= 0 && iw < w;
+        const int iwc = ok ? iw : 0;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ih >= 0 && ih < h && iw >= 0 && iw < w) {
-            for (int k = 0; k < c; ++k) v[k] = x[(((long)img * c + k) * h + ih) * w + iw];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = x ? xi[(long)(k < c ? k : 0) * h * w + iwc] : 0.f;
+            v[k] = (ok && k < c) ? t : 0.f;
         }
-        st4(out + i * 4, make_float4(v[0], v[1], v[2], v[3]));
+        st4(out + ((long)row * wp + xo) * 4, make_float4(v[0], v[1], v[2], v[3]));
     }
 }
 
@@ -195,11 +200,12 @@ extern "C" {
 int mvf_stem_prep(const float* x_nchw, int n, int c, int h, int w, int pad, int wp, void* out, int dtype, void* stream) {
     MVF_REQUIRE(x_nchw && out && n > 0 && c > 0 && c <= 4 && h > 0 && w > 0 && pad >= 0 && wp >= w + 2 * pad, MVF_EINVAL, "stem_prep: bad argument");
     const int hp = h + 2 * pad;
-    const long total = (long)n * hp * wp;
+    MVF_REQUIRE((long)n * hp < (1L << 31), MVF_ESHAPE, "stem_prep: too many rows");
+    const dim3 grid(n * hp);
     if (dtype == MVF_F32)
-        hipLaunchKernelGGL(stem_prep_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, n, c, h, w, pad, hp, wp, (float*)out);
+        hipLaunchKernelGGL(stem_prep_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x_nchw, n, c, h, w, pad, hp, wp, (float*)out);
     else
-        hipLaunchKernelGGL(stem_prep_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, n, c, h, w, pad, hp, wp, (bf16_t*)out);
+        hipLaunchKernelGGL(stem_prep_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x_nchw, n, c, h, w, pad, hp, wp, (bf16_t*)out);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
