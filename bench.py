@@ -124,7 +124,7 @@ def event_pair_overhead_ms(n=64):
     return v[len(v) // 2]
 
 
-def _summ(rec, per_layer, tag):
+def _summ(rec, per_layer, tag, peak_tf=2500.0):
     ms = sum(r[0].elapsed_time(r[1]) for r in rec)
     fl = sum(r[2] for r in rec)
     by = sum(r[4] for r in rec)
@@ -136,8 +136,8 @@ def _summ(rec, per_layer, tag):
             a[1] += r[0].elapsed_time(r[1])
             a[2] += r[2]
             a[3] += r[4]
-        # "bound" = the larger of bytes / 6.3 TB/s (measured HBM ceiling) and flops / 2.5 PF; "over" = time above it
-        rows = [(k, cnt, t, f, b, max(b / 6.3e9, f / 2.5e12)) for k, (cnt, t, f, b) in agg.items()]
+        # "bound" = the larger of bytes / 6.3 TB/s (measured HBM ceiling) and flops / the dtype's dense MFMA peak; "over" = time above it
+        rows = [(k, cnt, t, f, b, max(b / 6.3e9, f / (peak_tf * 1e9))) for k, (cnt, t, f, b) in agg.items()]
         for k, cnt, t, f, b, lo in sorted(rows, key=lambda r: -(r[2] - r[5]))[:48]:
             print("  %-6s %-40s x%-2d %7.3f ms %6.1f TF/s %5.2f TB/s  bound %6.3f  over %6.3f" % (tag, k, cnt, t, f / t / 1e9, b / t / 1e9, lo, t - lo),
                   file=sys.stderr)
@@ -168,7 +168,7 @@ def roofline_infer(model, imgs, dtype, per_layer):
             del t.rec[:]
             model(imgs, None, return_loss=False, return_numpy=False)
             torch.cuda.synchronize()
-            r = _summ(t.rec, per_layer and i == reps - 1, "conv")
+            r = _summ(t.rec, per_layer and i == reps - 1, "conv", PEAK_TFLOPS[dtype])
             tot = [a + b for a, b in zip(tot, r)]
     finally:
         undo()
@@ -216,8 +216,8 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
             eng.forward(imgs, labels)
             eng.backward()
             torch.cuda.synchronize()
-            totc = [a + b for a, b in zip(totc, _summ(tc.rec, per_layer and i == reps - 1, "igemm"))]
-            totw = [a + b for a, b in zip(totw, _summ(tw.rec, per_layer and i == reps - 1, "wgrad"))]
+            totc = [a + b for a, b in zip(totc, _summ(tc.rec, per_layer and i == reps - 1, "igemm", PEAK_TFLOPS[dtype]))]
+            totw = [a + b for a, b in zip(totw, _summ(tw.rec, per_layer and i == reps - 1, "wgrad", PEAK_TFLOPS[dtype]))]
     finally:
         for u in undo:
             u()
