@@ -149,8 +149,8 @@ def roofline_infer(model, imgs, dtype, per_layer):
     t = _Timer()
     esz = 4 if dtype == "f32" else 2
 
-    def desc(self, out, x, n, h, w, c_total, **kw):
-        y, ho, wo = out
+    def desc(self, ret, x, n, h, w, c_total, **kw):
+        y, ho, wo = ret
         stem = self.kw == 1 and self.cin == 32 and self.kh == 7
         k_alg = 147 if stem else self.kh * self.kw * self.cin
         st = kw.get("stride") or self.stride

@@ -81,12 +81,14 @@ class _Conv(object):
     def out_hw(self, h, w):
         return (h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1
 
-    def run(self, x, n, h, w, c_total, residual=None, x2=None, split_c=0, ho=None, wo=None, stride=None, pad=None):
+    def run(self, x, n, h, w, c_total, residual=None, x2=None, split_c=0, ho=None, wo=None, stride=None, pad=None, out=None):
         stride = self.stride if stride is None else stride
         pad = self.pad if pad is None else pad
         if ho is None:
             ho, wo = self.out_hw(h, w)
-        y = torch.empty(n, ho, wo, self.cout, dtype=self.dt, device=x.device)
+        y = out if out is not None else torch.empty(n, ho, wo, self.cout, dtype=self.dt, device=x.device)
+        if tuple(y.shape) != (n, ho, wo, self.cout) or y.dtype != self.dt or not y.is_contiguous():
+            raise ValueError("conv output buffer %s does not match (%d, %d, %d, %d)" % (tuple(y.shape), n, ho, wo, self.cout))
         d = ConvDesc(n, h, w, self.cin, self.cout, self.kh, self.kw, stride, pad, ho, wo, c_total, _DT[self.dt], self.relu,
                      split_c, split_c)
         ws = _sk_workspace(x.device)
@@ -146,7 +148,7 @@ class _Block(object):
         ce = 32 if dtype == torch.float32 else 64
         self.split_ok = self.mvf is not None and self.mvf.cs % ce == 0
 
-    def run(self, x, nt, h, w, c):
+    def run(self, x, nt, h, w, c, out=None):
         if self.mvf is None:
             o1, _, _ = self.c1.run(x, nt, h, w, c)
         elif self.split_ok:
@@ -158,7 +160,7 @@ class _Block(object):
         idn = x
         if self.down is not None:
             idn, _, _ = self.down.run(x, nt, h, w, c)
-        o3, _, _ = self.c3.run(o2, nt, ho, wo, self.c2.cout, residual=idn)
+        o3, _, _ = self.c3.run(o2, nt, ho, wo, self.c2.cout, residual=idn, out=out)
         return o3, ho, wo, self.c3.cout
 
 
@@ -210,6 +212,15 @@ class BackboneEngine(object):
                 return b.mvf.T
         return 1
 
+    def feature_shape(self, h, w):
+        """(h, w, c) of the features for an h x w input (the shape arithmetic of _forward_one, no kernels)."""
+        pad = self.stem.stem_pad
+        ho, wo = (h + 2 * pad - self.stem.kh) // 2 + 1, (w + 2 * pad - 7) // 2 + 1
+        h, w = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1
+        for blk in self.blocks:
+            h, w = blk.c2.out_hw(h, w)
+        return h, w, self.blocks[-1].c3.cout
+
     def _forward_multi(self, x, ns, T, window=None):
         cur = torch.cuda.current_stream()
         if not hasattr(self, "_pool") or len(self._pool) != ns:
@@ -219,22 +230,28 @@ class BackboneEngine(object):
                 self._pool.append(concurrent_stream(cur, avoid=self._pool))
         clips = x.shape[0] // T
         per = (clips + ns - 1) // ns
-        outs, parts = [], []
+        # every chain's last conv writes its clips straight into one feature tensor (allocated on the caller's stream): no
+        # concatenation copy afterwards
+        if x.dtype == torch.uint8:
+            hin, win = self.input_pipeline.crop_hw
+        else:
+            hin, win = x.shape[2], x.shape[3]
+        hf, wf, cf = self.feature_shape(hin, win)
+        feat = torch.empty(x.shape[0], hf, wf, cf, dtype=self.dtype, device=x.device)
+        used = []
         for i, st in enumerate(self._pool):
             lo, hi = i * per * T, min((i + 1) * per, clips) * T
             if lo >= hi:
                 continue
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                y = self._forward_one(x[lo:hi], None, None if window is None else window.reshape(-1, 3)[lo:hi])
-                y.record_stream(cur)
-            parts.append((st, y))
-        for st, y in parts:
+                self._forward_one(x[lo:hi], None, None if window is None else window.reshape(-1, 3)[lo:hi], out=feat[lo:hi])
+            used.append(st)
+        for st in used:
             cur.wait_stream(st)
-            outs.append(y)
-        return torch.cat(outs, 0)
+        return feat
 
-    def _forward_one(self, x_nchw, stages=None, window=None):
+    def _forward_one(self, x_nchw, stages=None, window=None, out=None):
         pad = self.stem.stem_pad
         if x_nchw.dtype == torch.uint8:              # decoded (nt, Hs, Ws, 3) frames: crop / flip / normalise fused into the stem prep
             if self.input_pipeline is None:
@@ -257,7 +274,7 @@ class BackboneEngine(object):
             stages["maxpool"] = p
         x, h, w, c = p, h2, w2, self.stem.cout
         for i, blk in enumerate(self.blocks):
-            x, h, w, c = blk.run(x, nt, h, w, c)
+            x, h, w, c = blk.run(x, nt, h, w, c, out=out if i == len(self.blocks) - 1 else None)
             if stages is not None and (i + 1) in self.stage_ends:
                 stages["layer%d" % (self.stage_ends.index(i + 1) + 1)] = x
         return x
