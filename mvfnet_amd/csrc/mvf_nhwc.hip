@@ -185,8 +185,13 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     a.cgp = cgp;
     const int HW = d->h * d->w;
     const int nplanes = kThreads / cgp;
-    // enough workgroups to fill 256 CUs several times over, but >= 4 pixels per thread-plane to amortise weights
-    int pixw = std::max(nplanes * 4, 1);
+    // enough workgroups to fill 256 CUs several times over: 4 pixels per thread-plane (amortises the tap registers) only when that
+    // still leaves >= 1024 workgroups -- the 14x14 / 7x7 stages of a 16-32 clip batch got 112-224 workgroups and ran latency-bound
+    static const int pix_env = getenv("MVF_STENCIL_PIX") ? atoi(getenv("MVF_STENCIL_PIX")) : 0;
+    int per = pix_env > 0 ? pix_env : 4;
+    if (pix_env <= 0)
+        while (per > 1 && (long)a.n_clips * ((HW + nplanes * per - 1) / (nplanes * per)) * ((a.cg + cgp - 1) / cgp) < 1024) per >>= 1;
+    int pixw = std::max(nplanes * per, 1);
     while ((long)a.n_clips * ((HW + pixw - 1) / pixw) > 8192 && pixw < HW) pixw *= 2;
     a.pixw = std::min(pixw, HW);
     a.bands = (HW + a.pixw - 1) / a.pixw;
