@@ -248,7 +248,7 @@ def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None):
             traffic = json.load(open(pmc)).get(pmc_key)
         except Exception:
             traffic = None
-    common = {"kernel": "conv_igemm_kernel", "traffic": traffic, "alg_bytes_per_launch": round(by / n),
+    common = {"kernel": "conv_igemm_* (conv_tile instantiations: lowk / glds / streamk, csrc/conv_nhwc.hip)", "traffic": traffic, "alg_bytes_per_launch": round(by / n),
               "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2), "avg_launch_us_raw": round(ms_raw * 1e3 / n, 2),
               "event_pair_overhead_us": round(event_overhead_ms * 1e3, 2), "flop_per_launch": round(fl / n),
               "ms_per_step": round(ms / reps, 3), "tflops": round(achieved, 2), "mfma_frac": round(achieved / peak, 4)}
