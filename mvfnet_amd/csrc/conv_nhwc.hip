@@ -1079,7 +1079,9 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         // of the per-tile fixed latency chain (kernel arguments -> offsets -> first chunk -> epilogue -> store drain) that
         // dominates these launches (ablation: with loads AND MFMAs removed the conv launches still take 58 % of their time).
         // Not for the BatchNorm-sum data gradient (its epilogue spills at 128 registers) and not for fp32 unless forced.
-        const int glds1_max = g_glds1_max >= 0 ? g_glds1_max : ((sizeof(ET) == 2 || (infer_like && g_glds1_f32_infer)) ? 8 : 0);
+        // (bf16 inference epilogues -- bias + ReLU [+ residual], half-batch launch chains -- keep winning up to 16 chunks: +1.9 %)
+        const int glds1_max = g_glds1_max >= 0 ? g_glds1_max
+                              : (sizeof(ET) == 2 ? (infer_like ? 16 : 8) : ((infer_like && g_glds1_f32_infer) ? 8 : 0));
         if (glds1_max > 0 && a.nchunks <= glds1_max && !(bnsum_epi && g_glds1_max < 0)) {
             int rc;
             if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(1, tiles, st, a);
