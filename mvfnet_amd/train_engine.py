@@ -798,9 +798,19 @@ class TrainEngine(_ParamStore):
         import torch.distributed as dist
         side = self.side_stream()
         self.flush_side()
-        side.wait_stream(self.main_stream())
-        with torch.cuda.stream(side):          # torch's current stream: ProcessGroupNCCL orders its stream behind it
-            self._works.append(dist.all_reduce(self.flat_grads[self._tail_off:], async_op=True))
+        # The collective gets a stream of its own that is MEASURED to run beside both the launch stream and the weight-gradient
+        # stream (streams.py: a stream that shares a hardware queue with either would serialise the ~1-2 ms RCCL kernel into it).
+        # It is issued as a synchronous op with that stream current: ProcessGroupNCCL then either runs it on the current stream
+        # (recent PyTorch) or on its internal stream with the current stream waiting for it -- in both cases `comm` is complete
+        # when the collective is, and the optimizer orders itself behind `comm`.
+        if getattr(self, "_comm", None) is None:
+            from .streams import concurrent_stream
+            self._comm = concurrent_stream(self.main_stream(), avoid=[side])
+        comm = self._comm
+        comm.wait_stream(side)                 # weight-gradient GEMMs / tap gradients of layer3, layer4, head
+        comm.wait_stream(self.main_stream())   # BatchNorm / head gradients
+        with torch.cuda.stream(comm):
+            dist.all_reduce(self.flat_grads[self._tail_off:])
         self._tail_launched = True
 
     def allreduce_grads(self):
@@ -810,10 +820,10 @@ class TrainEngine(_ParamStore):
         if not self._ddp_active():
             return 1
         if self._tail_launched:
+            # first order this stream behind the tail bucket's collective (long finished by now), THEN issue the second one: the
+            # two collectives of the communicator never overlap, whatever stream ProcessGroupNCCL runs them on
+            torch.cuda.current_stream().wait_stream(self._comm)
             dist.all_reduce(self.flat_grads[:self._tail_off])
-            for w in self._works:
-                w.wait()                        # stream-level: the current stream waits for the collective's stream
-            del self._works[:]
             self._tail_launched = False
         else:
             dist.all_reduce(self.flat_grads)
