@@ -492,6 +492,42 @@ __global__ void maxpool_bn_fwd_kernel(const ET* z, int n, int h, int w, int c, i
 // ga[input pixel] = sum over the (<=4) windows containing it of g[window] * [this pixel is the window's arg-max].
 // Gather form (no atomics); the forward stored one byte per pooled element (window position of the first max), so the
 // backward reads 4 bytes + one 4-channel gradient per covering window instead of re-evaluating 9 activations.
+// Row form: blockIdx.x = (image, input row), threads over (column, 4-channel group) of that row: the only division left is the
+// per-thread split of the row position (by c4, a shift for the 64-channel stem), instead of three runtime divisions per element.
+template <typename ET>
+__global__ void maxpool_bn_bwd_rows_kernel(const unsigned char* amax, const ET* g, int n, int h, int w, int c, int ho, int wo, ET* ga) {
+    const int c4 = c >> 2;
+    const int row = blockIdx.x, img = row / h, ih = row - img * h;
+    const int per = w * c4;
+    for (int i = threadIdx.x; i < per; i += blockDim.x) {
+        const int iw = i / c4, cq = i - iw * c4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned amv[4];
+        float4 gvv[4];
+        bool okv[4];
+        unsigned mev[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oh = (ih + (k >> 1)) >> 1, ow = (iw + (k & 1)) >> 1;
+            okv[k] = oh < ho && ow < wo && ((k >> 1) == 0 || (ih & 1)) && ((k & 1) == 0 || (iw & 1));
+            const int ohc = min(oh, ho - 1), owc = min(ow, wo - 1);
+            mev[k] = (unsigned)(ih - (oh * 2 - 1)) * 3u + (unsigned)(iw - (ow * 2 - 1));
+            const long oidx = (((long)img * ho + ohc) * wo + owc) * c + cq * 4;
+            amv[k] = *reinterpret_cast<const unsigned*>(amax + oidx);
+            gvv[k] = ld4(g + oidx);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned am = amv[k], me = mev[k];
+            if (okv[k] && (am & 255u) == me) acc[0] += gvv[k].x;
+            if (okv[k] && ((am >> 8) & 255u) == me) acc[1] += gvv[k].y;
+            if (okv[k] && ((am >> 16) & 255u) == me) acc[2] += gvv[k].z;
+            if (okv[k] && (am >> 24) == me) acc[3] += gvv[k].w;
+        }
+        st4(ga + ((long)row * w + iw) * c + cq * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+}
+
 template <typename ET>
 __global__ void maxpool_bn_bwd_kernel(const unsigned char* amax, const ET* g, int n, int h, int w, int c, int ho, int wo, ET* ga) {
     const int c4 = c >> 2;
@@ -884,6 +920,14 @@ int mvf_maxpool_bn_relu_bwd(const unsigned char* argmax, const void* g, int n, i
     MVF_REQUIRE(argmax && g && ga && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool_bn_relu_bwd: bad argument");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
     const long total = (long)n * h * w * (c / 4);
+    if ((long)n * h < (1L << 31) && (long)w * (c / 4) >= 256) {           // row form (see maxpool_bn_bwd_rows_kernel)
+        if (dtype == MVF_F32)
+            hipLaunchKernelGGL(maxpool_bn_bwd_rows_kernel<float>, dim3(n * h), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo, (float*)ga);
+        else
+            hipLaunchKernelGGL(maxpool_bn_bwd_rows_kernel<bf16_t>, dim3(n * h), dim3(256), 0, (hipStream_t)stream, argmax, (const bf16_t*)g, n, h, w, c, ho, wo, (bf16_t*)ga);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     if (dtype == MVF_F32)
         hipLaunchKernelGGL(maxpool_bn_bwd_kernel<float>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo, (float*)ga);
     else
