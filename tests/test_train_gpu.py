@@ -834,6 +834,10 @@ def test_process_group_does_not_cost_the_stream_overlap():
     port = str(29600 + os.getpid() % 300)
     dist_ms = run({"BENCH_FORCE_DIST": "1"}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                                               "--master-addr", "127.0.0.1", "--master-port", port])
+    if dist_ms >= 1.15 * plain:                    # one retry of both legs: a noisy neighbour must not fail the suite
+        plain = min(plain, run({}, [sys.executable]))
+        dist_ms = min(dist_ms, run({"BENCH_FORCE_DIST": "1"}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                                                                "--master-addr", "127.0.0.1", "--master-port", str(int(port) + 1)]))
     assert dist_ms < 1.15 * plain, (plain, dist_ms)
 
 
