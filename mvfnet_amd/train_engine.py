@@ -436,6 +436,8 @@ class _TBlock(object):
                 dx = eng.add(dxp, resid, key=id(self))
             else:
                 dx = dxp
+        if eng.keep_io:      # parity tests: this block's boundary tensors of the step (persistent buffers, valid until the next step)
+            self.io = dict(x=s["x"], out=s["out"], g=g, dx=dx, h=h, w=w, c=c, ho=ho, wo=wo)
         self.saved = None
         eng.flush_side()
         return dx
@@ -504,6 +506,7 @@ class _ParamStore(object):
         return ws
 
     overlap_wgrad = True
+    keep_io = False            # keep references to every block's input / output / gradients after backward (teacher-forced parity tests)
     fuse_stats = True          # BatchNorm batch statistics accumulated in the producing conv's epilogue
     fuse_bn_bwd_sums = os.environ.get("MVF_FUSE_BN_BWD", "1") != "0"    # ... and the backward sums in the data gradient's
     fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes
@@ -777,6 +780,8 @@ class TrainEngine(_ParamStore):
         dz0 = self.stem_bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2)
         self.stem.wgrad(dz0, s["xp"], nt, s["hp"], s["wp"], ho, wo, self)
         self.join_side()
+        if self.keep_io:
+            self.io = dict(p0=self.buf("p0", (g.shape[0], 64)), g_p0=g, gfeat=self.buf("gfeat", tuple(s["feat_shape"])), nt=nt, b=b, t=t)
         self.saved = None
 
     def _ddp_active(self):

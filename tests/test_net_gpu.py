@@ -10,7 +10,7 @@ from mvfnet_amd import synth
 pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-4    # relative to each tensor's max; north_star budget 1e-3 (fp32)
-TOL_BF16 = 2e-2   # bf16 storage end-to-end through 50 layers; per-op budget is 1e-2 (see test_conv_gpu.py)
+TOL_BF16 = 1e-2   # north_star: 1e-2 bf16, relative to the output scale (measured ~2e-3 on the logits; see also test_bf16_parity_gpu.py)
 
 
 def _model(depth, T, average_clips=None, dtype=torch.float32, fcn=False):

@@ -600,28 +600,7 @@ def test_r101_16x4_train_loss_vs_oracle_and_runner_resume(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ bf16 storage
-@pytest.mark.parametrize("name", sorted(BLOCK_CASES))
-def test_bottleneck_train_block_bf16_within_budget(name):
-    """bf16 activation storage (fp32 accumulate / statistics / gradients): north_star budget 1e-2 per op; a whole block
-    chains 4 convs + 5 BNs, so forward 2e-2 (max-norm).  Gradients are compared in relative L2: a ReLU mask flipping on a
-    near-zero bf16 activation moves single elements by O(1) (measured: 0.5 % activation noise -> max-norm error 1.0 on
-    the masked gradient, relative L2 a few %)."""
-    from mvfnet_amd.train_engine import BlockTrainer
-    N, T, Cin, planes, H, W, stride = BLOCK_CASES[name]
-    g = golden("block_cases.npz")
-    blk = _block(name)
-    tr = BlockTrainer(blk, dtype=torch.bfloat16)
-    x = torch.from_numpy(synth.synth_tensor("block_x/" + name, (N * T, Cin, H, W))).cuda()
-    y = tr.forward(x)
-    assert y.dtype == torch.bfloat16
-    assert rel_err(y.float().cpu().numpy(), g[name + "/train/y"]) < 2e-2
-    dy = torch.from_numpy(synth.synth_tensor("block_dy/" + name, tuple(y.shape))).cuda()
-    dx = tr.backward(dy)
-    assert rel_l2(dx.float().cpu().numpy(), g[name + "/train/dx"]) < 0.15      # 100-sample BNs in the strided case: 9 % measured
-    for pn, p in blk.named_parameters():
-        assert tr.grad_of(p).dtype == torch.float32
-        # the MVF tap / BN gradients of these 4-8-channel, 400-pixel toy blocks are heavily cancelling sums: 16 % measured
-        assert rel_l2(tr.grad_of(p).cpu().numpy(), g[name + "/train/grad/" + pn]) < 0.3, pn
+# (the bf16 bottleneck-block comparison lives in tests/test_bf16_parity_gpu.py: against an oracle that rounds where the engine rounds)
 
 
 def _ragged_setup(shape, dtype):
@@ -703,14 +682,14 @@ def test_c1_train_bf16_loss_and_gradients_track_reference():
     eng.backward()
     params = dict(m.named_parameters())
     names, ref = list(g["c1/train/grad_names"]), g["c1/train/grad_norms"]
-    errs = []
     for nme, r in zip(names, ref):
         got = float(eng.grad_of(params[nme]).double().norm())
         assert np.isfinite(got), nme
-        errs.append(abs(got - r) / max(r, 1e-6))
         if nme.startswith("cls_head"):
-            assert errs[-1] < 2e-2, (nme, got, r)
-    assert np.median(errs) < 5e-2 and max(errs) < 0.5, (np.median(errs), max(errs))   # chaotic early layers, see fp32 test
+            assert abs(got - r) / max(r, 1e-6) < 2e-2, (nme, got, r)
+    # the backbone gradients of a bf16 step are NOT compared with the fp32 reference here: on this synthetic network bf16 storage
+    # alone moves them by O(1) (chaotic 2-clip batch statistics); tests/test_bf16_parity_gpu.py compares every block's gradients
+    # with an oracle that rounds where the engine rounds, at a few %
     norm = eng.step()
     assert abs(float(norm[0]) - float(g["c1/train/total_norm/0"])) < 5e-2 * float(g["c1/train/total_norm/0"])
     assert float(eng.forward(imgs, labels)) < float(loss)              # the step reduces the loss
