@@ -233,6 +233,10 @@ int mvf_maxpool_bn_relu_bwd(const unsigned char* argmax, const void* g, int n, i
 int mvf_head_train_fwd(const void* feat, int clips, int t, int hw, int c, const float* fc_w, const float* fc_b, int classes,
                        const long long* labels, const float* drop_mask /* (clips*t, c) pre-scaled keep mask or NULL */,
                        float* pooled, float* scores, float* dscores, float* loss_part, float* loss, int dtype, void* stream);
+/* BaseHead.loss (codes/models/heads/base.py:40-45): loss[0] = mean over clips of softmax cross-entropy(scores[clip], labels[clip]);
+ * loss_part (clips) = the per-clip terms; dscores (clips, classes) = dloss/dscores or NULL.  All fp32. */
+int mvf_ce_loss(const float* scores, const long long* labels, int clips, int classes, float* dscores, float* loss_part, float* loss,
+                void* stream);
 int mvf_head_train_bwd(const float* dscores, const float* pooled, const float* fc_w, const float* drop_mask, int clips, int t,
                        int hw, int c, int classes, float* dfc_w, float* dfc_b, float* dpool_ws /* clips*c */, void* dfeat, int dtype,
                        void* stream);
@@ -272,6 +276,17 @@ size_t mvf_sgd_workspace_bytes(long n);
 int mvf_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, long n, float grad_scale, float max_norm,
                           float lr, float momentum, float weight_decay, int first_step, float* norm_out, void* ws,
                           size_t ws_bytes, void* stream);
+/* The same step with per-segment multipliers = build_optimizer's paramwise_options (codes/core/train.py:117-156: bias_lr_mult,
+ * bias_decay_mult, norm_decay_mult give every parameter its own lr / weight_decay) on the flat buffers: segment k covers elements
+ * [first_k, first_{k+1}) (sorted, first_0 = 0) with lr * lr_mult, weight_decay * decay_mult.  nesterov = 0 gives the plain
+ * momentum update (p -= lr * buf).  The gradient norm / clip coefficient are global, as clip_grad_norm_ over all parameters. */
+typedef struct mvf_sgd_segment {
+    long long first;
+    float lr_mult, decay_mult;
+} mvf_sgd_segment_t;
+int mvf_sgd_step_segments(float* params, const float* grads, float* momentum_buf, long n, float grad_scale, float max_norm, float lr,
+                          float momentum, float weight_decay, int first_step, int nesterov, const mvf_sgd_segment_t* segments, int nseg,
+                          float* norm_out, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

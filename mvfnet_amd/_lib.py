@@ -37,6 +37,10 @@ class PackJob(C.Structure):
                 ("kw_pad", C.c_int32), ("cin_pad", C.c_int32), ("kind", C.c_int32), ("first_block", C.c_int32)]
 
 
+class SgdSegment(C.Structure):
+    _fields_ = [("first", C.c_int64), ("lr_mult", C.c_float), ("decay_mult", C.c_float)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -116,6 +120,8 @@ def _load():
     lib.mvf_maxpool_bn_relu_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp]
     lib.mvf_head_train_fwd.restype = i32
     lib.mvf_head_train_fwd.argtypes = [vp, i32, i32, i32, i32, fp, fp, i32, ll, fp, fp, fp, fp, fp, fp, i32, vp]
+    lib.mvf_ce_loss.restype = i32
+    lib.mvf_ce_loss.argtypes = [fp, ll, i32, i32, fp, fp, fp, vp]
     lib.mvf_head_train_bwd.restype = i32
     lib.mvf_head_train_bwd.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, fp, fp, fp, vp, i32, vp]
     lib.mvf_conv2d_wgrad_workspace_bytes.restype = sz
@@ -134,6 +140,8 @@ def _load():
     lib.mvf_sgd_workspace_bytes.argtypes = [i64]
     lib.mvf_sgd_nesterov_step.restype = i32
     lib.mvf_sgd_nesterov_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, f32, i32, fp, vp, sz, vp]
+    lib.mvf_sgd_step_segments.restype = i32
+    lib.mvf_sgd_step_segments.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, f32, i32, i32, vp, i32, fp, vp, sz, vp]
     return lib
 
 

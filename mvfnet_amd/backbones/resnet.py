@@ -163,11 +163,13 @@ class ResNet(nn.Module):
         if tuple(self.out_indices) != (self.num_stages - 1,):
             raise NotImplementedError("only out_indices=(last stage,) is built (MVFNet configs use (3,))")
         if not self._bn_all_eval():
-            raise NotImplementedError(
-                "mvfnet_amd: the training-mode (batch-statistics BN + backward) conv stack is not built yet; call "
-                ".eval() for the fused HIP inference path. (MVF itself supports training: mvfnet_amd.modules.MVF)")
+            raise RuntimeError(
+                "mvfnet_amd ResNet.forward is the eval-mode (folded BatchNorm) inference path. With BatchNorms in training mode the "
+                "stack runs -- forward with batch statistics AND backward -- inside Recognizer2D.forward_train / "
+                "mvfnet_amd.train_engine.TrainEngine (one fused launch sequence for backbone + head + loss); call .eval() here")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
-            raise NotImplementedError("mvfnet_amd: backward through the conv stack is not built yet; use torch.no_grad()")
+            raise RuntimeError("mvfnet_amd ResNet.forward does not record an autograd graph (inference path); gradients come from "
+                               "Recognizer2D.forward_train(...)['loss_cls'].backward() -- wrap this call in torch.no_grad()")
         feat = self.engine().forward(x, stages)
         return feat.permute(0, 3, 1, 2)
 

@@ -32,9 +32,16 @@ def build(force=False, verbose=True):
         return OUT
     objs = []
     procs = []
+    hdrs = glob.glob(os.path.join(HERE, "csrc", "*.h")) + glob.glob(os.path.join(REPO, "include", "*.h"))
+    flag_file = os.path.join(HERE, "csrc", ".build_flags")
+    flags_now = " ".join(FLAGS)
+    same_flags = os.path.exists(flag_file) and open(flag_file).read() == flags_now
     for src in sources():
         obj = src[:-4] + ".o"
         objs.append(obj)
+        # per-object incremental build: an object is reused when it is newer than its source and every header, built with the same flags
+        if not force and same_flags and os.path.exists(obj) and all(os.path.getmtime(d) < os.path.getmtime(obj) for d in [src] + hdrs):
+            continue
         cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
@@ -43,6 +50,8 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
         if verbose and out.strip():
             print(out.decode())
+    with open(flag_file, "w") as f:
+        f.write(flags_now)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     subprocess.check_call(cmd)
     if verbose:

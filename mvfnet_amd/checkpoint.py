@@ -40,7 +40,9 @@ def load_state_dict(module, state_dict, strict=False, logger=None):
         text = "The model and loaded state dict do not match exactly\n" + "\n".join(msgs)
         if strict:
             raise RuntimeError(text)
-        (logger.warning if logger is not None else print)(text)
+        from .dist import get_dist_info
+        if get_dist_info()[0] == 0:                       # the reference reports on rank 0 only (checkpoint.py:60-68)
+            (logger.warning if logger is not None else print)(text)
     if hasattr(module, "invalidate_engine"):
         module.invalidate_engine()
     for m in module.modules():
@@ -80,3 +82,40 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
         ckpt["optimizer"] = optimizer.state_dict() if hasattr(optimizer, "state_dict") else optimizer
     torch.save(ckpt, filename)
     return filename
+
+
+# ---- optimizer state: torch.optim.SGD's state_dict layout (what the reference's checkpoints hold, checkpoint.py:262-263) ---------
+def sgd_state_dict(momentum_bufs, lr, momentum, weight_decay, nesterov=True, dampening=0.0, multipliers=None):
+    """{'state': {i: {'momentum_buffer': t}}, 'param_groups': [...]} over n parameters in model.parameters() order;
+    momentum_bufs[i] is None for a parameter that has not been stepped (torch creates the buffer at the first step).  One param
+    group -- or, with `multipliers` = [(lr_mult, decay_mult)] per parameter, ONE GROUP PER PARAMETER as the reference's paramwise
+    build_optimizer makes them (codes/core/train.py:131-153), so torch's load_state_dict finds the group structure it expects.
+    Keys of a group = torch.optim.SGD's (older torch ignores the newer ones on load)."""
+    n = len(momentum_bufs)
+    state = {i: {"momentum_buffer": b} for i, b in enumerate(momentum_bufs) if b is not None}
+
+    def group(ids, lr_, wd_):
+        return dict(lr=lr_, momentum=momentum, dampening=dampening, weight_decay=wd_, nesterov=bool(nesterov), maximize=False,
+                    foreach=None, differentiable=False, fused=None, params=ids)
+
+    if multipliers is None:
+        return {"state": state, "param_groups": [group(list(range(n)), lr, weight_decay)]}
+    return {"state": state, "param_groups": [group([i], lr * a, weight_decay * b) for i, (a, b) in enumerate(multipliers)]}
+
+
+def sgd_momentum_buffers(opt_state, n_params):
+    """Inverse: per-parameter momentum buffers (None where absent) in parameter order + the (first) param group's hyper-parameters.
+    Handles any number of param groups (the reference's paramwise build_optimizer makes one group PER parameter,
+    codes/core/train.py:131-153): the packed state ids are the concatenation of the groups' `params` lists."""
+    groups = opt_state.get("param_groups")
+    if not isinstance(groups, (list, tuple)) or "state" not in opt_state:
+        raise ValueError("not a torch optimizer state_dict (keys: %s)" % sorted(opt_state))
+    ids = [i for g in groups for i in g["params"]]
+    if len(ids) != n_params:
+        raise ValueError("optimizer state covers %d parameters, the model has %d" % (len(ids), n_params))
+    state = opt_state["state"]
+    bufs = []
+    for i in ids:
+        st = state.get(i, state.get(str(i)))
+        bufs.append(None if not st else st.get("momentum_buffer"))
+    return bufs, dict(groups[0])

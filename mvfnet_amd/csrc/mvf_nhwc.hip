@@ -8,8 +8,9 @@
 // re-reads of lines the same workgroup is streaming and are served by L1/L2.  HBM traffic = slice read + slice
 // write.  Codes/models/modules/MVF.py:104-137 is the arithmetic being replaced.
 //
-// Training / backward in this layout arrive with the NHWC training engine (they return MVF_EUNSUPPORTED now;
-// the NCHW implementation in mvf_nchw.hip is complete).
+// Training forward / backward in this layout (mvf_fwd_train / mvf_bwd with MVF_NHWC, cs % 4 == 0) are composed below from
+// the engine's primitives: stencil -> batch statistics -> stencil with BN + hard-swish; backward = recomputed stencil, BN
+// backward with the hard-swish mask, tap gradients, transposed stencil.
 #include <algorithm>
 
 #include <stdlib.h>

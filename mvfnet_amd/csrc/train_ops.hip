@@ -610,6 +610,7 @@ __global__ void ce_loss_kernel(const float* scores, const long long* labels, int
     const float den = red[0];
     const int lab = (int)labels[cl];
     if (tid == 0) loss_part[cl] = (logf(den) + mx) - s[lab];
+    if (!dscores) return;
     for (int k = tid; k < classes; k += blockDim.x) {
         const float p = expf(s[k] - mx) / den;
         dscores[(long)cl * classes + k] = (p - (k == lab ? 1.f : 0.f)) / (float)clips;
@@ -734,6 +735,26 @@ __global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, long n
         const float b = first_step ? d : momentum * buf[i] + d;
         buf[i] = b;
         p[i] = pv - lr * (d + momentum * b);
+    }
+}
+// the same update with per-SEGMENT learning-rate / weight-decay multipliers (build_optimizer's paramwise_options, reference
+// codes/core/train.py:117-156) and an optional plain-momentum form: seg[k] = {first element, lr multiplier, decay multiplier},
+// sorted by first element, seg[0].first == 0; a workgroup's 256-element run looks its segment up by binary search per element
+__global__ void sgd_segments_kernel(float* p, const float* g, float* buf, long n, const float* coef_ptr, float gscale, float lr,
+                                    float momentum, float wd, int first_step, int nesterov, const mvf_sgd_segment_t* seg, int nseg) {
+    const float coef = (coef_ptr ? coef_ptr[1] : 1.f) * gscale;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg[mid].first <= i) lo = mid; else hi = mid - 1;
+        }
+        const float lr_i = lr * seg[lo].lr_mult, wd_i = wd * seg[lo].decay_mult;
+        const float pv = p[i];
+        const float d = g[i] * coef + wd_i * pv;
+        const float b = first_step ? d : momentum * buf[i] + d;
+        buf[i] = b;
+        p[i] = pv - lr_i * (nesterov ? d + momentum * b : b);
     }
 }
 
@@ -1020,6 +1041,16 @@ int mvf_head_train_fwd(const void* feat, int clips, int t, int hw, int c, const 
     return MVF_OK;
 }
 
+int mvf_ce_loss(const float* scores, const long long* labels, int clips, int classes, float* dscores, float* loss_part, float* loss, void* stream) {
+    MVF_REQUIRE(scores && labels && loss_part && loss && clips > 0 && classes > 0, MVF_EINVAL, "ce_loss: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(clips), dim3(256), 0, st, scores, labels, clips, classes, loss_part, dscores);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_reduce_kernel, dim3(1), dim3(64), 0, st, loss_part, clips, loss);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
 int mvf_head_train_bwd(const float* dscores, const float* pooled, const float* fc_w, const float* drop_mask, int clips, int t, int hw, int c, int classes,
                        float* dfc_w, float* dfc_b, float* dpool_ws, void* dfeat, int dtype, void* stream) {
     MVF_REQUIRE(dscores && pooled && fc_w && dfc_w && dfc_b && dpool_ws && dfeat, MVF_EINVAL, "head_train_bwd: NULL argument");
@@ -1059,6 +1090,24 @@ int mvf_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, st, part, nb, max_norm, grad_scale, norm_out);
     MVF_LAUNCH_CHECK();
     hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n)), dim3(256), 0, st, params, grads, momentum_buf, n, norm_out, grad_scale, lr, momentum, weight_decay, first_step);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_sgd_step_segments(float* params, const float* grads, float* momentum_buf, long n, float grad_scale, float max_norm, float lr,
+                          float momentum, float weight_decay, int first_step, int nesterov, const mvf_sgd_segment_t* segments, int nseg,
+                          float* norm_out, void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(params && grads && momentum_buf && norm_out && segments && nseg > 0 && n > 0, MVF_EINVAL, "sgd_step_segments: bad argument");
+    MVF_REQUIRE(ws && ws_bytes >= mvf_sgd_workspace_bytes(n), MVF_EWS, "sgd_step_segments: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    const int nb = (int)std::min<long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(sqsum_partial_kernel, dim3(nb), dim3(256), 0, st, grads, n, part);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, st, part, nb, max_norm, grad_scale, norm_out);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sgd_segments_kernel, dim3(grid_for(n)), dim3(256), 0, st, params, grads, momentum_buf, n, norm_out, grad_scale, lr, momentum, weight_decay,
+                       first_step, nesterov, segments, nseg);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

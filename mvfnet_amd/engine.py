@@ -285,10 +285,20 @@ class HeadEngine(object):
 
     KINDS = {None: 0, "score": 1, "prob": 2}
 
-    def __init__(self, fc_weight, fc_bias, device):
-        self.w = fc_weight.detach().to(device=device, dtype=torch.float32).contiguous()
-        self.b = fc_bias.detach().to(device=device, dtype=torch.float32).contiguous() if fc_bias is not None else None
-        self.classes, self.c = self.w.shape
+    def __init__(self, fc, device):
+        """fc: the head's nn.Linear.  Its parameters are read at EVERY call (fp32 contiguous GPU parameters are used in place, no
+        copy): a training engine re-points them at its flat buffer and updates them in place, so a cached copy would score with
+        stale weights after the first optimizer step."""
+        self.fc, self.device = fc, device
+        self.classes, self.c = fc.weight.shape
+
+    @property
+    def w(self):
+        return self.fc.weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    @property
+    def b(self):
+        return self.fc.bias.detach().to(device=self.device, dtype=torch.float32).contiguous() if self.fc.bias is not None else None
 
     def scores(self, feat, num_seg):
         nt, h, w, c = feat.shape
@@ -297,7 +307,8 @@ class HeadEngine(object):
         clips = nt // num_seg
         pooled = torch.empty(clips, c, dtype=torch.float32, device=feat.device)
         out = torch.empty(clips, self.classes, dtype=torch.float32, device=feat.device)
-        check(lib.mvf_head_pool_fc(_p(feat), clips, num_seg, h * w, c, _p(self.w), _p(self.b), self.classes, _p(pooled), _p(out),
+        wgt, bias = self.w, self.b            # kept alive until the launch is queued
+        check(lib.mvf_head_pool_fc(_p(feat), clips, num_seg, h * w, c, _p(wgt), _p(bias), self.classes, _p(pooled), _p(out),
                                    _DT[feat.dtype], _stream()), "mvf_head_pool_fc")
         return out
 

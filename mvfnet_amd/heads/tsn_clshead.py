@@ -51,8 +51,11 @@ class TSNClsHead(nn.Module):
     def engine(self):
         if self._engine is None:
             from ..engine import HeadEngine
-            self._engine = HeadEngine(self.new_fc.weight, self.new_fc.bias, self.new_fc.weight.device)
+            self._engine = HeadEngine(self.new_fc, self.new_fc.weight.device)
         return self._engine
+
+    def invalidate_engine(self):
+        self._engine = None
 
     def forward(self, x, num_seg):
         """x: (N*T, C, h, w) features [or (clips, C, T, h, w) with fcn_testing] -> (clips, num_classes) scores."""
@@ -70,6 +73,20 @@ class TSNClsHead(nn.Module):
         return self.engine().scores(feat, num_seg)
 
     def loss(self, cls_score, labels):
-        """reference heads/base.py:40-45.  Stand-alone use is not needed by the hot path: Recognizer2D.forward_train
-        computes scores, loss and their gradients in one fused HIP head (mvf_head_train_fwd)."""
-        raise RuntimeError("TSNClsHead.loss: use Recognizer2D.forward_train (the loss is fused into the HIP train head)")
+        """reference heads/base.py:40-45: {'loss_cls': F.cross_entropy(cls_score, labels)} (mean over the clips), computed by the
+        HIP cross-entropy kernel of the train head (mvf_ce_loss); no autograd through it -- Recognizer2D.forward_train is the
+        path that trains (scores, loss and their gradients in one fused head)."""
+        import ctypes as C
+        from .._lib import check, lib
+        if not cls_score.is_cuda:
+            raise RuntimeError("TSNClsHead.loss: mvfnet_amd runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
+        s = cls_score.detach().to(torch.float32).contiguous()
+        lab = labels.reshape(-1).to(device=s.device, dtype=torch.int64).contiguous()
+        if lab.numel() != s.shape[0]:
+            raise ValueError("TSNClsHead.loss: %d labels for %d score rows" % (lab.numel(), s.shape[0]))
+        part = torch.empty(s.shape[0], dtype=torch.float32, device=s.device)
+        out = torch.empty(1, dtype=torch.float32, device=s.device)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        check(lib.mvf_ce_loss(P(s), P(lab), s.shape[0], s.shape[1], None, P(part), P(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "mvf_ce_loss")
+        return dict(loss_cls=out.reshape(()))

@@ -84,6 +84,10 @@ class _MVFProper(torch.autograd.Function):
         mean = invstd = None
         g32, b32 = _f32c(gamma), _f32c(beta)
         if use_hs and training:
+            for t in (running_mean, running_var):          # mvf_fwd_train updates them in place as fp32 (cs * 4 bytes each)
+                if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+                    raise TypeError("MVF: BatchNorm running statistics must be contiguous float32 buffers in training mode (got %s); "
+                                    "keep the module's bn in fp32 when casting the model" % t.dtype)
             ws = torch.empty(lib.mvf_fwd_train_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=x.device)
             mean = torch.empty(cs, dtype=torch.float32, device=x.device)
             invstd = torch.empty(cs, dtype=torch.float32, device=x.device)

@@ -17,14 +17,26 @@ class _TrainStepFn(torch.autograd.Function):
     def forward(ctx, eng, imgs, labels, *params):
         ctx.eng = eng
         ctx.n = len(params)
-        return eng.forward(imgs, labels).reshape(())
+        loss = eng.forward(imgs, labels).reshape(())
+        ctx.token = eng.forward_count          # the engine keeps ONE step's activations: backward must belong to the latest forward
+        return loss
 
     @staticmethod
     def backward(ctx, gout):
         eng = ctx.eng
+        if ctx.token != eng.forward_count or eng.saved is None:
+            raise RuntimeError("Recognizer2D: backward() of a loss whose activations are gone -- the HIP train engine keeps one step "
+                               "(call loss.backward() before the next forward_train, and only once)")
         eng.backward()
         eng.flat_grads.mul_(gout)
-        return (None, None, None) + tuple(eng.grad_of(p) for p in eng.model.parameters())
+        grads = []
+        for p in eng.model.parameters():
+            v = eng.grad_of(p)
+            # a parameter whose .grad IS the flat-buffer view (engine.attach_grads()) already holds its gradient: handing the same
+            # memory to autograd's AccumulateGrad would add it to itself; everything else gets its own copy
+            aliased = p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+            grads.append(None if aliased else v.clone())
+        return (None, None, None) + tuple(grads)
 
 
 @RECOGNIZERS.register_module
@@ -95,12 +107,14 @@ class Recognizer2D(nn.Module):
         if getattr(self, "_train_engine", None) is None:
             from ..train_engine import TrainEngine
             self._train_engine = TrainEngine(self, **opt)
+        elif opt:                                  # an engine exists already: the options must not be dropped silently
+            self._train_engine.set_options(**opt)
         return self._train_engine
 
     def forward_train(self, imgs, labels, **kwargs):
         """imgs [B, T, 3, H, W], labels [B, 1] -> {'loss_cls': scalar tensor} (reference recognizer2d.py:132-149).
-        The returned loss supports .backward(): gradients land in the parameters' .grad (views of the engine's flat
-        gradient buffer), as the reference's DistOptimizerHook expects."""
+        The returned loss supports .backward(): gradients land in the parameters' .grad (copies of the engine's flat gradient
+        buffer; after engine.attach_grads() the .grad tensors ARE views of it), as the reference's DistOptimizerHook expects."""
         if not imgs.is_cuda:
             raise RuntimeError("Recognizer2D: mvfnet_amd runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
         # BatchNorms in eval mode (backbone norm_eval=True / frozen stages, reference resnet.py:496-527) normalise with their running

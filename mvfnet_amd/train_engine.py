@@ -66,6 +66,9 @@ class _BN(object):
         self.gamma, self.beta = bn.weight, bn.bias
         self.dgamma, self.dbeta = eng.grad_of(bn.weight), eng.grad_of(bn.bias)
         self.eps, self.momentum = bn.eps, (bn.momentum if bn.momentum is not None else 0.1)
+        for t in (bn.running_mean, bn.running_var):       # the kernels read and update them in place as fp32
+            if t is None or t.dtype != torch.float32 or not t.is_contiguous():
+                raise TypeError("train engine: BatchNorm running statistics must be contiguous float32 buffers (got %s)" % (None if t is None else t.dtype))
         dev = bn.weight.device
         self.mean = torch.empty(self.c, device=dev)
         self.invstd = torch.empty(self.c, device=dev)
@@ -476,6 +479,9 @@ class _ParamStore(object):
                 self._grad_view[id(p)] = gv
                 off += pad(k)
         self.n_params = n
+        for m_ in model.modules():                      # cached inference engines hold packed copies of the old storage
+            if hasattr(m_, "invalidate_engine"):
+                m_.invalidate_engine()
         self._ws = None
         self.norm_out = torch.zeros(2, device=dev)
         self.steps = 0
@@ -572,6 +578,106 @@ class _ParamStore(object):
         check(lib.mvf_bn_apply(_p(a), m, c, _p(one), _p(zero), _p(b), None, None, 0, _p(out), self.dt, _st()), "add")
         return out
 
+    lr, momentum, weight_decay, max_norm = 0.015, 0.9, 1e-4, 40.0
+
+    def trainable_offset(self):
+        """Flat-buffer offset of the first trainable parameter.  Parameters excluded from training (requires_grad False: the
+        reference's frozen_stages, resnet.py:515-527) are supported when they form a PREFIX of model.parameters() -- stem, then
+        layer1..k, which is what frozen_stages produces: the optimizer (norm, clip, weight decay, momentum, update) then simply
+        runs on the rest of the flat buffers, as torch's clip_grad_norm_ / SGD skip parameters without a gradient.  Scattered
+        exclusions (norm_frozen, partial_norm) are refused."""
+        params = list(self.model.parameters())
+        flags = [p.requires_grad for p in params]
+        k = flags.index(True) if True in flags else len(flags)
+        if not all(flags[k:]):
+            raise NotImplementedError("parameters excluded from training must be a prefix of model.parameters() (frozen_stages); "
+                                      "norm_frozen / partial_norm style exclusions are not built")
+        return self._grad_view[id(params[k])].storage_offset() if k < len(params) else self.flat_params.numel()
+
+    nesterov = True
+    param_options = None       # {id(param): (lr_mult, decay_mult)}: build_optimizer's paramwise_options (see set_param_options)
+
+    def set_param_options(self, options):
+        """Per-parameter learning-rate / weight-decay multipliers: {parameter: (lr_mult, decay_mult)} (missing = (1, 1)).
+        The optimizer then runs the segment form of the fused kernel (mvf_sgd_step_segments) on the same flat buffers."""
+        self.param_options = {id(p): (float(a), float(b)) for p, (a, b) in options.items()} if options else None
+        self._seg_tables = {}
+
+    def _segments(self, off):
+        tabs = self.__dict__.setdefault("_seg_tables", {})
+        if off not in tabs:
+            segs, last = [], None
+            for p in self.model.parameters():
+                first = self._grad_view[id(p)].storage_offset()
+                if first + p.numel() <= off:
+                    continue
+                mult = (self.param_options or {}).get(id(p), (1.0, 1.0))
+                if mult != last:                    # neighbours with equal multipliers share a segment (padding elements are zeros)
+                    segs.append(_lib.SgdSegment(max(first - off, 0) if segs else 0, mult[0], mult[1]))
+                    last = mult
+            arr = (_lib.SgdSegment * len(segs))(*segs)
+            tabs[off] = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(segs))
+        return tabs[off]
+
+    def apply_sgd(self, lr=None, world=1):
+        """clip_grad_norm_(max_norm) + SGD on the flat buffers (gradient scaled by 1 / world): one fused launch sequence."""
+        off = self.trainable_offset()
+        n = self.flat_params.numel() - off
+        if n <= 0:
+            return None
+        ws = self.workspace(lib.mvf_sgd_workspace_bytes(n))
+        args = (_p(self.flat_params[off:]), _p(self.flat_grads[off:]), _p(self.flat_mom[off:]), n, C.c_float(1.0 / world),
+                C.c_float(self.max_norm or 0.0), C.c_float(self.lr if lr is None else lr), C.c_float(self.momentum),
+                C.c_float(self.weight_decay), int(self.steps == 0))
+        if self.nesterov and not self.param_options:
+            check(lib.mvf_sgd_nesterov_step(*(args + (_p(self.norm_out), _p(ws), ws.numel(), _st()))), "sgd step")
+        else:
+            tab, nseg = self._segments(off)
+            check(lib.mvf_sgd_step_segments(*(args + (int(self.nesterov), _p(tab), nseg, _p(self.norm_out), _p(ws), ws.numel(), _st()))), "sgd step")
+        self.steps += 1
+        return self.norm_out
+
+    # ---- optimizer state in torch.optim.SGD's wire format (reference checkpoints: codes/utils/checkpoint.py:235-265) ---------
+    def optimizer_state_dict(self):
+        """What torch.optim.SGD(model.parameters(), ...).state_dict() would hold after the same steps: per-parameter
+        `momentum_buffer` in model.parameters() order + one param group -- so `{meta, state_dict, optimizer}` checkpoints written
+        here resume under the reference's runner (optimizer.load_state_dict) and the other way round."""
+        from .checkpoint import sgd_state_dict
+        params = list(self.model.parameters())
+        off = self.trainable_offset()
+        bufs = []
+        for p in params:
+            v = self._grad_view[id(p)]
+            first = v.storage_offset()
+            stepped = self.steps > 0 and first >= off and p.requires_grad
+            bufs.append(self.flat_mom[first:first + p.numel()].view(p.shape).detach().cpu().clone() if stepped else None)
+        mult = [self.param_options.get(id(p), (1.0, 1.0)) for p in params] if self.param_options else None
+        return sgd_state_dict(bufs, self.lr, self.momentum, self.weight_decay, self.nesterov, multipliers=mult)
+
+    def load_optimizer_state_dict(self, opt):
+        """Accepts torch.optim.SGD's state_dict (the reference's checkpoints) or round 1's {'momentum_buffer': flat, 'steps': n}."""
+        from .checkpoint import sgd_momentum_buffers
+        if "momentum_buffer" in opt and "state" not in opt:          # round-1 layout of this repo
+            self.flat_mom.copy_(opt["momentum_buffer"].to(self.flat_mom.device))
+            self.steps = int(opt.get("steps", 1))
+            return
+        params = list(self.model.parameters())
+        bufs, group = sgd_momentum_buffers(opt, len(params))
+        self.flat_mom.zero_()
+        any_buf = False
+        for p, b in zip(params, bufs):
+            if b is None:
+                continue
+            if tuple(b.shape) != tuple(p.shape):
+                raise ValueError("optimizer state: momentum_buffer %s does not match parameter %s" % (tuple(b.shape), tuple(p.shape)))
+            first = self._grad_view[id(p)].storage_offset()
+            self.flat_mom[first:first + p.numel()].view(p.shape).copy_(b.to(device=self.device, dtype=torch.float32))
+            any_buf = True
+        for k in ("momentum", "nesterov") + (() if len(opt["param_groups"]) > 1 else ("lr", "weight_decay")):
+            if k in group:          # (per-parameter groups carry multiplied lr / weight_decay values: the base values stay the engine's)
+                setattr(self, k, group[k])
+        self.steps = max(self.steps, 1) if any_buf else 0          # torch creates a buffer at a parameter's first step
+
     def attach_grads(self):
         """Expose the flat gradient views as .grad of the parameters (for external optimizers / inspection)."""
         for p in self.model.parameters():
@@ -639,6 +745,8 @@ class TrainEngine(_ParamStore):
         for i, m_ in enumerate(bns):
             self._nbt_flat[i] = m_.num_batches_tracked.to(self.device)
             m_.num_batches_tracked = self._nbt_flat[i]
+        self.forward_count = 0
+        self.saved = None
         self._nbt_touched = False
         self._nbt_mods, self._nbt_inc = bns, {}      # increment vectors per pattern of training / eval BatchNorms (frozen ones keep theirs)
         # uint8 input path (preprocess.FramePipeline): decoded frames in, crop / flip / normalise fused into the stem prep;
@@ -679,8 +787,18 @@ class TrainEngine(_ParamStore):
         if not imgs.is_cuda or imgs.dtype not in (torch.float32, torch.uint8):
             raise RuntimeError("TrainEngine.forward: float32 (or uint8 frames) GPU input required")
         self._main = torch.cuda.current_stream()
+        self.forward_count += 1
         with _on_stream(self._main):
             return self._forward(imgs, labels, stages)
+
+    def set_options(self, lr=None, momentum=None, weight_decay=None, max_norm=None, dtype=None):
+        """Update the optimizer hyper-parameters of an existing engine (Recognizer2D.train_engine(**opt) on a model that already
+        has one); the storage dtype is fixed at construction."""
+        if dtype is not None and dtype != self.tdtype:
+            raise RuntimeError("the model's train engine was built with dtype %s; it cannot be switched to %s" % (self.tdtype, dtype))
+        for k, v in (("lr", lr), ("momentum", momentum), ("weight_decay", weight_decay), ("max_norm", max_norm)):
+            if v is not None:
+                setattr(self, k, v)
 
     def _forward(self, imgs, labels, stages=None):
         b, t = imgs.shape[0], imgs.shape[1]
@@ -840,34 +958,13 @@ class TrainEngine(_ParamStore):
         with _on_stream(torch.cuda.current_stream()):
             return self._step(lr)
 
-    def trainable_offset(self):
-        """Flat-buffer offset of the first trainable parameter.  Parameters excluded from training (requires_grad False: the
-        reference's frozen_stages, resnet.py:515-527) are supported when they form a PREFIX of model.parameters() -- stem, then
-        layer1..k, which is what frozen_stages produces: the optimizer (norm, clip, weight decay, momentum, update) then simply
-        runs on the rest of the flat buffers, as torch's clip_grad_norm_ / SGD skip parameters without a gradient.  Scattered
-        exclusions (norm_frozen, partial_norm) are refused."""
-        params = list(self.model.parameters())
-        flags = [p.requires_grad for p in params]
-        k = flags.index(True) if True in flags else len(flags)
-        if not all(flags[k:]):
-            raise NotImplementedError("parameters excluded from training must be a prefix of model.parameters() (frozen_stages); "
-                                      "norm_frozen / partial_norm style exclusions are not built")
-        return self._grad_view[id(params[k])].storage_offset() if k < len(params) else self.flat_params.numel()
-
     def _step(self, lr=None):
         world = self.allreduce_grads()
-        off = self.trainable_offset()
-        n = self.flat_params.numel() - off
-        if n <= 0:
+        if self.apply_sgd(lr, world) is None:
             return self.norm_out
-        ws = self.workspace(lib.mvf_sgd_workspace_bytes(n))
-        check(lib.mvf_sgd_nesterov_step(_p(self.flat_params[off:]), _p(self.flat_grads[off:]), _p(self.flat_mom[off:]), n, C.c_float(1.0 / world),
-                                        C.c_float(self.max_norm or 0.0), C.c_float(self.lr if lr is None else lr), C.c_float(self.momentum),
-                                        C.c_float(self.weight_decay), int(self.steps == 0), _p(self.norm_out), _p(ws), ws.numel(), _st()), "sgd step")
-        self.steps += 1
-        bb = self.model.backbone
-        if hasattr(bb, "invalidate_engine"):
-            bb.invalidate_engine()
+        for m_ in (self.model.backbone, self.model.cls_head):
+            if hasattr(m_, "invalidate_engine"):
+                m_.invalidate_engine()
         return self.norm_out
 
     def train_step(self, imgs, labels, lr=None):

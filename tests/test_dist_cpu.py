@@ -62,6 +62,19 @@ def _worker(rank, world, port, q):
         p.grad = torch.full_like(p, float(rank + 1))
     D.allreduce_grads(net.parameters(), coalesce=True, bucket_size_mb=1e-4)
     assert all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in net.parameters())
+    # multi_gpu_test's result gather (reference codes/core/test.py:147-185) with UNEVEN shards: rank::world interleave, padding
+    # dropped at `size`; then with an EMPTY shard on rank 1 (fewer videos than ranks), which must neither hang nor mis-shape
+    import numpy as np
+    from mvfnet_amd.runner import collect_results
+    rows = {0: [np.full((1, 4), 10.0 + i, np.float32) for i in range(3)], 1: [np.full((1, 4), 20.0 + i, np.float32) for i in range(2)]}[rank]
+    got = collect_results(rows, size=5)
+    if rank == 0:
+        assert [float(r[0, 0]) for r in got] == [10.0, 20.0, 11.0, 21.0, 12.0]
+    else:
+        assert got is None
+    got = collect_results(rows if rank == 0 else [], size=None)
+    if rank == 0:
+        assert [float(r[0, 0]) for r in got] == [10.0, 11.0, 12.0] and got[0].shape == (1, 4)
     if rank == 0:
         q.put(([p.detach().tolist() for p in net.parameters()], float(total), [t.tolist() for t in ref0]))
     dist.barrier()

@@ -834,3 +834,136 @@ def test_wgrad_loader_variants_forced_by_env(env):
                         "conv_dgrad_wgrad or c1_train or norm_eval_training or bottleneck_train or stem_wgrad", "-p", "no:cacheprovider"],
                        env=dict(os.environ, **{k: v}), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ round 2: optimizer wire format, runner shell
+@pytest.mark.parametrize("tag", ["plain", "paramwise"])
+def test_replaying_the_references_optimizer_steps_reproduces_its_checkpoint(tag):
+    """tests/golden/ref_ckpt_block_*.pth: the reference's own Bottleneck+MVF trained for two steps by the torch SGD its
+    build_optimizer makes (plain, and with paramwise_options = one param group per parameter), saved by its save_checkpoint.
+    The same two steps through BlockTrainer + the fused clip/SGD kernel (segment form for the param-wise multipliers) must land on
+    the same parameters, BatchNorm buffers and momentum buffers; the optimizer state written back has torch's layout."""
+    import os
+    from helpers import GOLDEN
+    from mvfnet_amd.runner import paramwise_multipliers
+    from mvfnet_amd.train_engine import BlockTrainer
+    name = "l3_like"
+    N, T, Cin, planes, H, W, stride = BLOCK_CASES[name]
+    g = np.load(os.path.join(GOLDEN, "ref_ckpt_block.npz"))
+    ck = torch.load(os.path.join(GOLDEN, "ref_ckpt_block_%s.pth" % tag), weights_only=False)
+    blk = _block(name)
+    tr = BlockTrainer(blk)
+    tr.lr, tr.momentum, tr.weight_decay, tr.max_norm, tr.nesterov = 0.015, 0.9, 1e-4, 40.0, True
+    if tag == "paramwise":
+        tr.set_param_options(paramwise_multipliers(blk, dict(bias_lr_mult=2.0, bias_decay_mult=0.0, norm_decay_mult=0.0)))
+    x = torch.from_numpy(synth.synth_tensor("block_x/" + name, (N * T, Cin, H, W))).cuda()
+    for step in range(2):
+        y = tr.forward(x)
+        tr.backward(torch.from_numpy(synth.synth_tensor("block_dy/" + name, tuple(y.shape), seed=step)).cuda())
+        tr.apply_sgd()
+        for k, v in blk.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            ref = g["%s/step1/%s" % (tag, k)] if step == 0 else g["%s/%s" % (tag, k)]
+            assert rel_err(v.cpu().numpy(), ref) < (2e-5 if step == 0 else 2e-4), (step, k)
+    opt = tr.optimizer_state_dict()
+    assert len(opt["param_groups"]) == len(ck["optimizer"]["param_groups"]) and len(opt["state"]) == len(ck["optimizer"]["state"])
+    for i, st in ck["optimizer"]["state"].items():
+        assert rel_err(opt["state"][i]["momentum_buffer"].numpy(), st["momentum_buffer"].numpy()) < 2e-4, i
+    # and the other direction: the reference's optimizer entry loads into a fresh engine
+    tr2 = BlockTrainer(_block(name))
+    tr2.load_optimizer_state_dict(ck["optimizer"])
+    assert tr2.steps > 0
+    for p, p2 in zip(blk.parameters(), tr2.model.parameters()):
+        i0 = tr2.grad_of(p2).storage_offset()
+        want = ck["optimizer"]["state"][[id(q) for q in tr2.model.parameters()].index(id(p2))]["momentum_buffer"]
+        assert torch.equal(tr2.flat_mom[i0:i0 + p2.numel()].view(p2.shape).cpu(), want)
+
+
+def test_inference_then_training_then_inference_uses_the_updated_head_and_backbone():
+    """an inference before the train engine exists must not leave a stale packed copy of ANY weight behind -- after an
+    optimizer step the eval path has to score with the updated backbone AND the updated FC (checked against the CPU oracle run on
+    the model's own state_dict)."""
+    from oracle import net_torch
+    m = _model(50, 4)
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 96, 96, seed=3))
+    labels = torch.from_numpy(synth.synth_labels(2, seed=3))
+    m.eval()
+    s0 = m(imgs.cuda(), None, return_loss=False)
+    m.train()
+    eng = m.train_engine(lr=0.5)                     # a big step, so stale weights are unmistakable
+    eng.train_step(imgs.cuda(), labels.cuda())
+    m.eval()
+    s1 = m(imgs.cuda(), None, return_loss=False)
+    with torch.no_grad():
+        ref = net_torch.forward_test(imgs, {k: v.detach().cpu() for k, v in m.state_dict().items()}, 50, 4).numpy()
+    assert rel_err(s1, ref) < 2e-4
+    assert rel_err(s1, s0) > 1e-2                     # the step really moved the scores
+
+
+def test_autograd_api_gradients_are_not_doubled_and_stale_backward_is_refused():
+    """loss.backward() through Recognizer2D.forward_train: .grad = one copy of the engine's gradient (also after attach_grads(),
+    where .grad aliases the flat buffer); a second backward / a backward after the next forward raises."""
+    m = _model(50, 4)
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+    out = m(imgs, labels, return_loss=True)
+    out["loss_cls"].backward()
+    eng = m.train_engine()
+    w = m.backbone.layer4[2].conv3.weight
+    assert torch.equal(w.grad, eng.grad_of(w)) and w.grad.data_ptr() != eng.grad_of(w).data_ptr()
+    want = eng.grad_of(w).clone()
+    eng.attach_grads()
+    out = m(imgs, labels, return_loss=True)
+    out["loss_cls"].backward()
+    # (the second pass is not bit-identical to the first: the BatchNorm running means the conv epilogues shift their sums by have
+    # moved, and this 2-clip 64^2 network is chaotic -- doubling would read 1.0 here)
+    assert rel_l2(w.grad.cpu().numpy(), want.cpu().numpy()) < 0.3 and w.grad.data_ptr() == eng.grad_of(w).data_ptr()
+    with pytest.raises(RuntimeError):
+        out["loss_cls"].backward()
+    stale = m(imgs, labels, return_loss=True)["loss_cls"]
+    m(imgs, labels, return_loss=True)
+    with pytest.raises(RuntimeError, match="activations are gone"):
+        stale.backward()
+    # options passed to an existing engine are applied, not dropped
+    assert m.train_engine(lr=0.123, max_norm=7.0) is eng and eng.lr == 0.123 and eng.max_norm == 7.0
+    with pytest.raises(RuntimeError):
+        m.train_engine(dtype=torch.bfloat16)
+
+
+def test_head_loss_matches_cross_entropy():
+    m = _model(50, 4)
+    g = torch.Generator().manual_seed(5)
+    scores = torch.randn(6, 400, generator=g) * 3
+    labels = torch.randint(0, 400, (6, 1), generator=g)
+    out = m.cls_head.loss(scores.cuda(), labels.cuda())
+    assert abs(float(out["loss_cls"]) - float(F.cross_entropy(scores, labels.squeeze(1)))) < 1e-5
+
+
+def test_train_network_shim_runs_the_config_end_to_end(tmp_path):
+    """train_network(model, dataset, cfg) with the shipped config's sections (optimizer + paramwise_options, optimizer_config,
+    lr_config, checkpoint_config, log_config, fp16 -> bf16 engine, total_epochs), host batches uploaded by the prefetcher;
+    then resume_from picks the checkpoint up (torch-SGD optimizer entry) and continues."""
+    from mvfnet_amd.runner import Config, train_network
+    torch.manual_seed(0)
+    batches = [dict(img_group=torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64, seed=i)), label=torch.from_numpy(synth.synth_labels(2, seed=i)))
+               for i in range(3)]
+    cfg = Config(optimizer=dict(type="SGD", lr=0.015, momentum=0.9, weight_decay=1e-4, nesterov=True,
+                                paramwise_options=dict(bias_lr_mult=2.0, bias_decay_mult=0.0, norm_decay_mult=0.0)),
+                 optimizer_config=dict(grad_clip=dict(max_norm=40, norm_type=2)),
+                 lr_config=dict(policy="step", step=[90, 130], warmup="linear", warmup_iters=10, warmup_ratio=0.01),
+                 checkpoint_config=dict(interval=1), log_config=dict(interval=1), total_epochs=2, work_dir=str(tmp_path),
+                 fp16=dict(loss_scale=512.0), data=dict(videos_per_gpu=2, workers_per_gpu=0), resume_from=None, load_from=None)
+    logs = []
+    m = _model(50, 4)
+    run = train_network(m, batches, cfg, distributed=False, validate=False, logger=logs.append)
+    assert run.epoch == 2 and run.iter == 6 and run.engine.tdtype == torch.bfloat16 and run.engine.param_options
+    assert len(logs) == 6 and all("loss_cls" in l for l in logs)
+    ck = torch.load(str(tmp_path / "latest.pth"), weights_only=False)
+    assert set(ck) == {"meta", "state_dict", "optimizer"} and len(ck["optimizer"]["param_groups"]) == len(list(m.parameters()))
+    assert ck["optimizer"]["param_groups"][1]["weight_decay"] == 0.0           # backbone.bn1.weight: norm_decay_mult = 0
+    m2 = _model(50, 4)
+    cfg2 = Config(dict(cfg, resume_from=str(tmp_path / "latest.pth"), total_epochs=3))
+    run2 = train_network(m2, batches, cfg2, logger=logs.append)
+    assert run2.epoch == 3 and run2.iter == 9
+    assert torch.isfinite(run2.engine.flat_params).all()
