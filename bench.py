@@ -64,9 +64,10 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="train mode: keep the weight-gradient GEMMs on the launch stream (profiling: every kernel runs alone, as in "
                          "the roofline pass)")
-    ap.add_argument("--eager-compare", action="store_true",
-                    help="also time the same restatement under PyTorch-ROCm eager on this GPU (cudnn.benchmark=True as the reference "
-                         "config sets it; MIOpen's kernel search makes this take 3-25 minutes, so it is opt-in)")
+    ap.add_argument("--no-eager-compare", action="store_true",
+                    help="skip the PyTorch-ROCm eager comparators (tools/eager_compare.py: the same train step under eager fp32 and under "
+                         "autocast(bf16)+channels_last on this GPU, cudnn.benchmark=False; ~70 s each on a fresh box, bounded by --eager-seconds)")
+    ap.add_argument("--eager-seconds", type=float, default=150.0, help="wall-clock bound per eager comparator run")
     ap.add_argument("--streams", type=int, default=2, help="infer: independent clip-group launch chains (HIP streams)")
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch timing table to stderr")
     return ap.parse_args()
@@ -173,12 +174,15 @@ def roofline_infer(model, imgs, dtype, per_layer):
     finally:
         undo()
         model.backbone.engine().streams = streams
-    return _roof(tot, reps, dtype, event_pair_overhead_ms(), dtype + "_infer")
+    return _roof(tot, reps, dtype, event_pair_overhead_ms(), dtype + "_infer", "conv_igemm_* (conv_tile instantiations, csrc/conv_nhwc.hip)")
 
 
-def roofline_train(eng, imgs, labels, dtype, per_layer):
+def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
+    """Instrumented passes (weight gradients on the launch stream, every launch alone): HIP-event brackets around every launch of
+    the four kernel groups of the step -- implicit-GEMM convs (forward + data gradients), weight gradients, BatchNorm streaming
+    kernels, MVF stencils -- with each launch's ALGORITHMIC bytes / flops from its shapes."""
     from mvfnet_amd import train_engine as TE
-    tc, tw = _Timer(), _Timer()
+    tc, tw, tb, tm = _Timer(), _Timer(), _Timer(), _Timer()
     esz = 4 if dtype == "f32" else 2
 
     def dfwd(self, out, d, x, x2, z, ws, part, shift):
@@ -204,65 +208,109 @@ def roofline_train(eng, imgs, labels, dtype, per_layer):
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * (4 if self.stem else self.cin)) + 4 * self.w.numel()
         return (2.0 * n * ho * wo * self.cout * k_alg, "wgrad M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)
 
+    # BatchNorm streaming kernels: tensors read + written (the sign-bit byte per 4 channels where it is used)
+    def dbap(self, out, z, m, act, residual=None, rbn=None, bits=False):
+        nb = esz * m * self.c * (3 if residual is not None else 2) + (m * self.c // 4 if bits else 0)
+        return (0.0, "bn apply%s M%d C%d" % ("+res" if residual is not None else "", m, self.c), nb)
+
+    def dbre(self, out, g, g_pitch, z, m, eng_, mask_mode, ymask, gm_out):
+        nb = esz * m * self.c * 2 + (m * self.c // 4 if mask_mode == 4 else 0)
+        return (0.0, "bn bwd reduce<%d> M%d C%d" % (mask_mode, m, self.c), nb)
+
+    def dbab(self, out, g, g_pitch, z, m, eng_, mask_mode, ymask, gm_out):
+        nb = esz * m * self.c * 3 + (m * self.c // 4 if mask_mode == 4 else 0)
+        return (0.0, "bn bwd apply<%d> M%d C%d" % (mask_mode, m, self.c), nb)
+
+    def dmvf(self, out, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits):
+        m = d.nt * d.h * d.w
+        nb = esz * m * d.cs * (3 if addend is not None else 2)          # slice read + slice write (+ the gated skip-connection slice)
+        taps = 3 * bin(d.mode).count("1")
+        return (2.0 * m * d.cs * taps, "mvf stencil%s M%d Cs%d" % ("^T" if flip else "", m, d.cs), nb)
+
     undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb),
-            tw.wrap(TE._TConv, "wgrad", dwgr)]
+            tw.wrap(TE._TConv, "wgrad", dwgr), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
+            tm.wrap(TE._TMvf, "launch_stencil", dmvf)]
     overlap = eng.overlap_wgrad
     eng.overlap_wgrad = False          # time every kernel alone on the launch stream (the timed steps overlap wgrad on a side stream)
+    timers = (("igemm", tc), ("wgrad", tw), ("bn", tb), ("mvf", tm))
     try:
-        totc, totw = [0.0, 0.0, 0.0, 0], [0.0, 0.0, 0.0, 0]
+        tot = {k: [0.0, 0.0, 0.0, 0] for k, _ in timers}
         reps = 2
         for i in range(reps):
-            del tc.rec[:], tw.rec[:]
+            for _, t in timers:
+                del t.rec[:]
             eng.forward(imgs, labels)
             eng.backward()
             torch.cuda.synchronize()
-            totc = [a + b for a, b in zip(totc, _summ(tc.rec, per_layer and i == reps - 1, "igemm", PEAK_TFLOPS[dtype]))]
-            totw = [a + b for a, b in zip(totw, _summ(tw.rec, per_layer and i == reps - 1, "wgrad", PEAK_TFLOPS[dtype]))]
+            for k, t in timers:
+                tot[k] = [a + b for a, b in zip(tot[k], _summ(t.rec, per_layer and i == reps - 1 and k in ("igemm", "wgrad"), k, PEAK_TFLOPS[dtype]))]
     finally:
         for u in undo:
             u()
         eng.overlap_wgrad = overlap
     ovh = event_pair_overhead_ms()
-    r = _roof(totc, reps, dtype, ovh, dtype + "_train")
-    w = _roof(totw, reps, dtype, ovh, dtype + "_train_wgrad")
-    r["wgrad"] = {k: w[k] for k in ("traffic", "bound", "achieved", "peak", "unit", "frac", "tflops", "mfma_frac", "launches_per_step", "avg_launch_us",
-                                    "avg_launch_us_raw", "flop_per_launch", "alg_bytes_per_launch", "ms_per_step")}
-    r["wgrad"]["kernel"] = "wgrad_kernel (+ its partial-slab reduce)"
+    r = _roof(tot["igemm"], reps, dtype, ovh, dtype + "_train", "conv_igemm_* (conv_tile instantiations: lowk / glds / streamk, csrc/conv_nhwc.hip)")
+    groups = {"wgrad": _roof(tot["wgrad"], reps, dtype, ovh, dtype + "_train_wgrad", "wgrad_*_kernel + wgrad_reduce_kernel (csrc/wgrad_nhwc.hip)"),
+              "bn": _roof(tot["bn"], reps, dtype, ovh, dtype + "_train_bn", "bn_apply / bn_bwd_reduce / bn_bwd_apply kernels (csrc/train_ops.hip)"),
+              "mvf": _roof(tot["mvf"], reps, dtype, ovh, dtype + "_train_mvf", "mvf_nhwc_apply (stencil and transposed stencil, csrc/mvf_nhwc.hip)")}
+    for k, g in groups.items():
+        r[k] = g
+    # whole step against the fully fused floor: every conv input / output read / written exactly once, forward + two backward GEMMs
+    from mvfnet_amd.arch import fused_activation_elems_per_image
+    clips, t = imgs.shape[0], imgs.shape[1]
+    floor = 3.0 * fused_activation_elems_per_image(eng_depth(eng), imgs.shape[-1]) * t * clips * esz
+    moved = sum(tot[k][2] for k in tot) / reps
+    r["step"] = {"ms_per_step": round(ms_step, 3), "fused_floor_bytes": int(floor), "fused_floor_ms_at_peak": round(floor / PEAK_HBM_GBS / 1e6, 3),
+                 "step_hbm_frac": round(floor / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                 "alg_bytes_of_timed_groups": int(moved), "alg_bytes_frac_of_peak": round(moved / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                 "note": "fused_floor = 3 x (conv-in + conv-out elements) x esz x frames (SURVEY 8d: 348 MB bf16 per R50 8-frame clip and pass); "
+                         "alg_bytes_of_timed_groups = what the un-fused launches of the four groups move by their shapes"}
     return r
+
+
+def eng_depth(eng):
+    return eng.model.backbone.depth
 
 
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured ceiling)
 
 
-def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None):
-    """fp32: the conv GEMMs are MFMA-bound (94 FLOP/B fused vs ~20 machine balance).  bf16: the same network is HBM-bound even
-    when perfectly fused (188 FLOP/B vs ~310), so the fraction is algorithmic bytes/s over the HBM peak."""
-    ms_raw, fl, by, n = tot
-    ms = max(ms_raw - n * event_overhead_ms, 1e-6)     # net of the empty-bracket reading (see event_pair_overhead_ms)
-    achieved = fl / (ms * 1e-3) / 1e12
+def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None, kernel=None):
+    """One kernel group's roofline object.  Time = the GROSS sum of the HIP-event brackets (no overhead subtraction: rocprofv3's kernel
+    durations agree with the gross figure, profiles/README.md); `event_pair_overhead_us` is printed for information only.
+    fp32: the conv GEMMs are MFMA-bound (94 FLOP/B fused vs ~20 machine balance).  bf16: the same network is HBM-bound even when
+    perfectly fused (188 FLOP/B vs ~310), so `frac` is algorithmic bytes/s over the HBM peak; both fractions
+    are always printed (`hbm_frac`, `mfma_frac`)."""
+    ms, fl, by, n = tot
+    ms = max(ms, 1e-6)
+    n = max(n, 1)
+    tflops = fl / (ms * 1e-3) / 1e12
+    gbs = by / (ms * 1e-3) / 1e9
     peak = PEAK_TFLOPS[dtype]
-    traffic = None
+    traffic, source = None, None
     pmc = os.path.join(REPO, "profiles", "pmc_conv_bytes_per_launch.json")
-    if os.path.exists(pmc):
+    if pmc_key and os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(pmc_key)
+            d = json.load(open(pmc))
+            traffic, source = d.get(pmc_key), d.get("source_" + pmc_key)
         except Exception:
             traffic = None
-    common = {"kernel": "conv_igemm_* (conv_tile instantiations: lowk / glds / streamk, csrc/conv_nhwc.hip)", "traffic": traffic, "alg_bytes_per_launch": round(by / n),
-              "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2), "avg_launch_us_raw": round(ms_raw * 1e3 / n, 2),
+    common = {"kernel": kernel, "traffic": traffic,
+              "traffic_source": ("STATIC, not measured in this run: " + source) if (traffic and source) else None,
+              "alg_bytes_per_launch": round(by / n), "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
               "event_pair_overhead_us": round(event_overhead_ms * 1e3, 2), "flop_per_launch": round(fl / n),
-              "ms_per_step": round(ms / reps, 3), "tflops": round(achieved, 2), "mfma_frac": round(achieved / peak, 4)}
-    if dtype == "bf16":
-        gbs = by / (ms * 1e-3) / 1e9
+              "ms_per_step": round(ms / reps, 3), "tflops": round(tflops, 2), "mfma_frac": round(tflops / peak, 4),
+              "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
+    if dtype == "bf16" or fl == 0.0:
         common.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
     else:
-        common.update({"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4)})
+        common.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4)})
     return common
 
 
-def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=False):
-    """The CPU restatement of the same step (oracle/net_torch.py) on the host cores, bounded sample; and the same
-    restatement executed by PyTorch-ROCm eager (MIOpen / rocBLAS) on this GPU."""
+def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=None):
+    """The CPU restatement of the same step (oracle/net_torch.py) on the host cores, bounded sample; `eager_compare` = the results
+    of eager_comparators() (the same restatement executed by PyTorch-ROCm eager on this GPU), attached to the object."""
     from mvfnet_amd import synth
     from mvfnet_amd.arch import state_dict_shapes
     from oracle import net_torch
@@ -321,33 +369,89 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=False):
         rate = clips * n / el
         if best is None or rate > best[0]:
             best = (rate, thr, n, el)
-    eager = None
-    try:
-        if not eager_compare:
-            raise RuntimeError("skipped (run bench.py --eager-compare; last measured values are in DESIGN.md section 5)")
-        gsd, gmom = make_sd("cuda"), {}
-        gim = torch.randn(gpu_clips, T_FRAMES, 3, SIZE, SIZE, device="cuda")
-        glab = torch.randint(0, 400, (gpu_clips, 1), device="cuda")
-        torch.backends.cudnn.benchmark = True
-        for _ in range(3):
-            one_step(gsd, gim, glab, gmom)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            one_step(gsd, gim, glab, gmom)
-        torch.cuda.synchronize()
-        eager = round(gpu_clips * 5 / (time.perf_counter() - t0), 2)
-    except Exception as e:   # comparator only
-        eager = str(e)[:110]
+    eager = eager_compare if isinstance(eager_compare, dict) else None
     what = "fp32 train step (fwd+bwd+clip+SGD)" if train else "fp32 eval forward"
     if best is None:
-        return {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "torch_eager_gpu_clips_per_s": eager,
+        return {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "torch_eager_gpu": eager,
                 "sample": "no thread count finished in %.0f s" % seconds}
     rate, thr, n, el = best
     return {"value": round(rate, 2), "unit": "clips/s", "cores": thr, "kind": "port", "host_hw_threads": cores,
-            "torch_eager_gpu_clips_per_s": eager,
+            "torch_eager_gpu": eager,
             "sample": "%d x %d clips of %dx3x%dx%d, %s, torch CPU (oneDNN) %d threads (best of %s), %.1f s" % (
                 n, clips, T_FRAMES, SIZE, SIZE, what, thr, cands, el)}
+
+
+def eager_comparators(depth, clips, frames, size, seconds, engine_value, dtype):
+    """BASELINE.json's '>= 1.5x the reference PyTorch-ROCm clips/sec' comparator, measured in THIS run: tools/eager_compare.py runs
+    the same train step (oracle/net_torch.py's restatement of the reference graph) under PyTorch-ROCm eager on this GPU, once in
+    the reference's shipped precision (fp32) and once like-for-like with the bf16 engine (autocast(bfloat16) + channels_last).
+    Each in its own process with a wall-clock bound (MIOpen compiles its kernels on first use: ~70 s on a fresh box;
+    cudnn.benchmark=False -- the exhaustive search of benchmark=True takes 3-25 minutes and measured the same 234 clips/s in fp32)."""
+    import subprocess
+    out = {}
+    for dt in ("bf16", "f32"):
+        cmd = [sys.executable, os.path.join(REPO, "tools", "eager_compare.py"), "--dtype", dt, "--clips", str(clips), "--frames", str(frames),
+               "--size", str(size), "--depth", str(depth), "--steps", "3", "--warmup", "1"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=seconds)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            out[dt] = json.loads(line[-1]) if line else "failed rc=%d: %s" % (p.returncode, (p.stderr or "")[-160:])
+        except subprocess.TimeoutExpired:
+            out[dt] = "no result within %.0f s (MIOpen kernel compilation)" % seconds
+        except Exception as e:      # comparator only
+            out[dt] = str(e)[:160]
+    res = {"torch_eager_gpu_clips_per_s": {k: (v["eager_clips_per_s"] if isinstance(v, dict) else v) for k, v in out.items()},
+           "detail": out}
+    same = out.get(dtype)
+    if isinstance(same, dict) and same.get("eager_clips_per_s"):
+        res["engine_over_eager_same_dtype"] = round(engine_value / same["eager_clips_per_s"], 2)
+    f32 = out.get("f32")
+    if isinstance(f32, dict) and f32.get("eager_clips_per_s"):
+        res["engine_over_eager_fp32_reference_precision"] = round(engine_value / f32["eager_clips_per_s"], 2)
+    return res
+
+
+def verify_replicas(dist, eng, step, world):
+    """Self-check of the data-parallel run, AFTER the timed steps (every rank calls it): (1) the replicas started from the same
+    formula-generated weights and applied the same all-reduced gradient, so their parameters must be BIT-identical -- an integer
+    checksum of the fp32 bit patterns is all-gathered and compared; (2) how much of the gradient all-reduce is exposed: a few steps
+    with the tail bucket overlapped with backward (default), with the single un-overlapped collective, and with no exchange at all
+    (the replicas diverge after that one, so it comes last)."""
+    bits = eng.flat_params.view(torch.int32).to(torch.int64)
+    chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum()])
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    equal = all(torch.equal(allc[0], c) for c in allc)
+
+    def timed(n=3):
+        step()                                   # settle the new setting
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / n * 1e3], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    on = timed()
+    eng.overlap_allreduce = False
+    off = timed()
+    eng.overlap_allreduce = True
+    eng.exchange_enabled = False
+    none = timed()
+    eng.exchange_enabled = True
+    out = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "params_bit_identical_across_ranks": bool(equal),
+           "gradient_bytes": int(eng.flat_grads.numel() * 4), "allreduce_ms": {"tail_bucket_overlapped_with_backward": round(on, 3),
+                                                                               "single_collective_after_backward": round(off, 3),
+                                                                               "no_exchange": round(none, 3), "exposed": round(on - none, 3)}}
+    if not equal:
+        raise SystemExit("bench.py: replicas hold DIFFERENT parameters after the timed steps: %s" % [c.tolist() for c in allc])
+    return out
 
 
 def main():
@@ -420,6 +524,9 @@ def main():
         t = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    replicas = None
+    if dist is not None and train:
+        replicas = verify_replicas(dist, eng, step, world)
 
     if rank == 0:
         from mvfnet_amd.arch import conv_macs_per_image
@@ -443,14 +550,20 @@ def main():
                                       ("replicas x%d (clips sharded, no collective)" % world)},
             "model_tflops": round(value * flop_clip / 1e12, 2),
         }
+        if replicas is not None:
+            res["replicas"] = replicas
         if video:
             res["videos_per_s"] = round(value / 30.0, 2)
         if train:
-            res["roofline"] = roofline_train(eng, imgs, labels, args.dtype, args.per_layer)
+            res["roofline"] = roofline_train(eng, imgs, labels, args.dtype, args.per_layer, ms)
         else:
             res["roofline"] = roofline_infer(model, imgs, args.dtype, args.per_layer)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds, args.mode, args.clips, args.eager_compare)
+            eager = None
+            if train and not args.no_eager_compare:
+                # (the engine's buffers stay allocated: 288 GB of HBM hold both; the timed region is long over)
+                eager = eager_comparators(args.depth, args.clips, T_FRAMES, SIZE, args.eager_seconds, value, args.dtype)
+            res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds, args.mode, args.clips, eager)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -298,7 +298,7 @@ class _TMvf(object):
         m = nt * h * w
         d = self.desc(nt, h, w, c)
         y = self.eng.buf((id(self), "y"), (m, self.cs))
-        check(lib.mvf_nhwc_stencil(C.byref(d), _p(x), c, _p(y), self.cs, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 0, None, 0, None, _st()), "mvf stencil")
+        self.launch_stencil(d, x, c, y, self.cs, 0, None, 0, None)
         if not self.use_hs:
             return y, y
         self.bn.stats(y, m, eng)
@@ -330,8 +330,13 @@ class _TMvf(object):
             def launch():
                 check(lib.mvf_nhwc_tapgrad(C.byref(d), _p(x), c, _p(dy), self.cs, _p(self.dwt), _p(dwh), _p(dww), _p(ws), ws.numel(), _st()), "mvf tapgrad")
             eng.on_side(launch)
-        check(lib.mvf_nhwc_stencil(C.byref(d), _p(dy), self.cs, _p(dxp), c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, 1,
-                                   _p(addend), c if addend is not None else 0, _p(addend_bits), _st()), "mvf stencil^T")
+        self.launch_stencil(d, dy, self.cs, dxp, c, 1, addend, c if addend is not None else 0, addend_bits)
+
+    def launch_stencil(self, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits):
+        """Exactly one MVF stencil launch (plain: y = taps * x-slice; flip: the transposed stencil of the backward, + gated addend);
+        bench.py brackets this call with HIP events."""
+        check(lib.mvf_nhwc_stencil(C.byref(d), _p(src), src_c, _p(dst), dst_c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, flip,
+                                   _p(addend), addend_c, _p(addend_bits), _st()), "mvf stencil")
 
 
 class _TBlock(object):
@@ -902,9 +907,11 @@ class TrainEngine(_ParamStore):
             self.io = dict(p0=self.buf("p0", (g.shape[0], 64)), g_p0=g, gfeat=self.buf("gfeat", tuple(s["feat_shape"])), nt=nt, b=b, t=t)
         self.saved = None
 
+    exchange_enabled = True       # False: skip the gradient exchange (bench.py's "how much of the all-reduce is exposed" measurement only)
+
     def _ddp_active(self):
         import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_allreduce)
+        return self.exchange_enabled and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_allreduce)
 
     overlap_allreduce = os.environ.get("MVF_DDP_OVERLAP", "1") != "0"
 

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single C-ABI kernels at the R50 8x8 x 32-clip (C3) tensor sizes: HIP-event timing, algorithmic GB/s.
+
+    python tools/kbench.py bn        # BatchNorm streaming kernels (apply / backward reduce / backward apply) per stage
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvfnet_amd import _lib  # noqa: E402
+
+lib, check = _lib.lib, _lib.check
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3      # us
+
+
+def bench_bn(dt=1):
+    tdt = torch.bfloat16 if dt else torch.float32
+    esz = 2 if dt else 4
+    dev = "cuda"
+    # (rows, channels) of the block-final tensors (bn3 / residual) and the mid-block ones (bn1 / bn2) per stage, NT = 256
+    stages = [("layer1", 256 * 56 * 56, 256, 64), ("layer2", 256 * 28 * 28, 512, 128), ("layer3", 256 * 14 * 14, 1024, 256), ("layer4", 256 * 7 * 7, 2048, 512)]
+    for name, m, c, cm in stages:
+        for cc, tag in ((c, "final"), (cm, "mid")):
+            z = torch.randn(m, cc, device=dev).to(tdt)
+            r = torch.randn(m, cc, device=dev).to(tdt)
+            g = torch.randn(m, cc, device=dev).to(tdt)
+            out, dz = torch.empty_like(z), torch.empty_like(z)
+            bits = torch.zeros(m, cc // 4, dtype=torch.uint8, device=dev)
+            f = lambda: torch.rand(cc, device=dev) + 0.5  # noqa: E731
+            scale, shift, mean, invstd, gamma = f(), f() - 1, f() - 1, f(), f()
+            dg, db = torch.empty(cc, device=dev), torch.empty(cc, device=dev)
+            ws = torch.empty(lib.mvf_bn_workspace_bytes(m, cc), dtype=torch.uint8, device=dev)
+            nb = m * cc * esz
+            if tag == "final":
+                t = timeit(lambda: check(lib.mvf_bn_apply_bits(P(z), m, cc, P(scale), P(shift), P(r), None, None, 1, P(out), P(bits), dt, None)))
+                print("%-7s %-5s apply+res+bits  %8.1f us  %6.2f TB/s" % (name, tag, t, (3 * nb + m * cc // 4) / t / 1e6))
+                t = timeit(lambda: check(lib.mvf_bn_bwd_reduce(P(g), cc, P(z), P(bits), m, cc, P(mean), P(invstd), P(scale), P(shift), 4, None, P(dg), P(db), P(ws), ws.numel(), dt, None)))
+                print("%-7s %-5s bwd_reduce<4>   %8.1f us  %6.2f TB/s" % (name, tag, t, (2 * nb + m * cc // 4) / t / 1e6))
+                t = timeit(lambda: check(lib.mvf_bn_bwd_apply_masked(P(g), cc, P(z), P(bits), m, cc, P(gamma), P(mean), P(invstd), P(scale), P(shift), P(dg), P(db), 4, P(dz), dt, None)))
+                print("%-7s %-5s bwd_apply<4>    %8.1f us  %6.2f TB/s" % (name, tag, t, (3 * nb + m * cc // 4) / t / 1e6))
+            else:
+                t = timeit(lambda: check(lib.mvf_bn_apply_bits(P(z), m, cc, P(scale), P(shift), None, None, None, 1, P(out), None, dt, None)))
+                print("%-7s %-5s apply           %8.1f us  %6.2f TB/s" % (name, tag, t, 2 * nb / t / 1e6))
+                t = timeit(lambda: check(lib.mvf_bn_bwd_apply_masked(P(g), cc, P(z), None, m, cc, P(gamma), P(mean), P(invstd), P(scale), P(shift), P(dg), P(db), 2, P(dz), dt, None)))
+                print("%-7s %-5s bwd_apply<2>    %8.1f us  %6.2f TB/s" % (name, tag, t, 3 * nb / t / 1e6))
+            del z, r, g, out, dz, bits
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "bn"
+    if what == "bn":
+        bench_bn(1)
