@@ -124,6 +124,14 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
 size_t mvf_conv2d_workspace_bytes(const mvf_conv_desc_t* d);
 int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                            const float* bias, const void* residual, void* y, void* ws, size_t ws_bytes, void* stream);
+/* The MVF module FUSED into its wrapped 1x1 conv (MVF.forward, codes/models/modules/MVF.py:104-138, followed by conv1 -> bn1 -> relu of
+ * Bottleneck.forward, resnet.py:213-215, eval mode): y = relu(conv1x1(x') + bias) where x' = x with channels [0, cs) replaced by
+ * act(scale * (T/H/W 3-tap views of x, zero padded inside the clip / image) + shift) -- computed in the conv's A-operand loader from
+ * the seven neighbours of each pixel; no slice buffer, no separate stencil launch.  d: kh = kw = 1, stride 1, ho x wo = h x w,
+ * x_pix_stride = cin, d->n = clips * n_segment frames, relu = 1.  mvf_coef: [cs][12] fp32 = {w_t[3], w_h[3], w_w[3], scale, shift, 0} per
+ * channel (absent views: zeros); act = 1: affine + hard-swish (use_hs), 0: the bare tap sum.  cs % 64 == 0 (bf16) / 32 (fp32). */
+int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void* w_packed, const float* bias, const float* mvf_coef,
+                            int cs, int n_segment, int act, void* y, void* ws, size_t ws_bytes, void* stream);
 /* ... with the residual gated per element by sign bits ([n*ho*wo][cout/4] bytes, see mvf_bn_apply_bits); stride-1 launches */
 int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                                 const float* bias, const void* residual, const unsigned char* res_sign_bits, void* y,
@@ -248,7 +256,9 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
                           void* stream);
 /* Every weight pack of a training step in one launch.  jobs_dev = DEVICE array of njobs records sorted by first_block;
  * job k owns workgroups [first_block, first_block + ceil(elements / 2048)), total_blocks = their sum.  kind 0 = the forward
- * pack of mvf_pack_conv_weight (no scale), kind 1 = the data-gradient pack of mvf_pack_conv_weight_dgrad. */
+ * pack of mvf_pack_conv_weight (no scale), kind 1 = the data-gradient pack of mvf_pack_conv_weight_dgrad.  kind 2 / 3 = the
+ * same two packs as an LDS-tiled transpose for cout % 32 == 0, cin % 32 == 0, kh * kw <= 9, kw_pad == kw, cin_pad == cin:
+ * such a job owns (cout / 32) * (cin / 32) workgroups. */
 typedef struct {
     const float* w;      /* fp32 OIHW parameter */
     void* out;           /* packed operand in `dtype` */

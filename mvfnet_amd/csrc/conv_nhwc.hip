@@ -65,6 +65,12 @@ struct ConvArgs {
     // gm = y * [bn_scale*z + bn_shift > 0], xhat = (z - bn_mean) * bn_invstd; z has the output's shape
     const char* bn_z;
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
+    // MVFL (inference, MVF fused into the wrapped 1x1 conv's A-operand load, reference MVF.py:104-138): channels [0, mvf_cs) of the
+    // input are replaced ON THE FLY by hswish(scale * (9-tap T/H/W stencil) + shift); mvf_coef = [mvf_cs][12] floats per channel:
+    // {wt[0..2], wh[0..2], ww[0..2], scale, shift, 0}; mvf_act = 1: affine + hard-swish, 0: the bare tap sum (use_hs = False)
+    const float* mvf_coef;
+    int mvf_cs, mvf_T, mvf_act;
+    unsigned fd_t_mul, fd_t_shr;     // magic number of n / mvf_T
     int M;
     int cpt;       // chunks per tap = ceil(Cin*esz / 128)
     int nchunks;   // KH*KW*cpt
@@ -136,7 +142,8 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
 // lane-linearly (M0 base + 16 * lane), so a wave instruction lands 8 rows x 128 B; the bank-conflict-free image is made on the
 // SOURCE side: position p of row r holds the 16-byte unit p ^ ((r >> 1) & 7), and the operand fetch applies the same XOR.
 // Out-of-range buffer offsets DMA zeros (tools/probes/glds_probe.hip), so padding taps stay branch-free.
-template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0, bool PW = false, int GLDS = 0>
+template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0, bool PW = false, int GLDS = 0,
+          bool MVFL = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -152,6 +159,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
 #endif
     __syncthreads();                                   // LDS hand-over from a previous segment of this workgroup
     static_assert(!GLDS || (!GEN && !PF2 && !LOWK), "the LDS-DMA loop is its own variant");
+    static_assert(!MVFL || (((LOWK && PW) || GLDS == 1 || GLDS == 2) && !GEN), "the fused MVF loader: single-buffer register-staged pointwise kernel or the 4-wave LDS-DMA kernels");
     constexpr int NBUF = GLDS ? GLDS : (LOWK ? 1 : 2);
     constexpr int PITCH = GLDS ? 128 : kPitch;         // LDS-DMA rows are unpadded (lane-linear destination)
     constexpr int kSmem = GLDS ? kGldsLds<BM, BN, GLDS ? GLDS : 1>() : (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch);
@@ -277,8 +285,98 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const unsigned lds_a0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)As + wave * 8 * PITCH);
     const unsigned lds_b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)Bs + wave * 8 * PITCH);
+    // MVFL: the A rows of a chunk below mvf_cs = hswish(bn(stencil)) of the block input, built straight into the LDS tile.
+    // A thread owns ONE channel quad (its 9 taps + scale + shift stay in 11 x 4 registers) and walks BM * CE / (4 * NT) rows;
+    // per row the seven neighbours (t-1, t+1: +- one frame; h-1, h+1: +- W pixels; w-1, w+1: +- 1 pixel; centre) are loaded
+    // unconditionally -- a neighbour outside the clip / image gets an out-of-range buffer offset and reads zeros, which IS the
+    // zero padding of the reference's Conv3d views (MVF.py:65-81).  The arithmetic order is mvf_nhwc_apply's.
+    auto mvf_rows = [&](int buf, int scc) {
+        constexpr int QPR = CE / 4, RST = NT / QPR, RPT = BM / RST;     // quads per row, row step, rows per thread
+        const int cq4 = tid % QPR, r00 = tid / QPR;
+        const int c0 = scc * CE + cq4 * 4;
+        float wt_[4][3], wh_[4][3], ww_[4][3], sc_[4], sh_[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 c_a = *reinterpret_cast<const float4*>(a.mvf_coef + (long)(c0 + i) * 12);
+            const float4 c_b = *reinterpret_cast<const float4*>(a.mvf_coef + (long)(c0 + i) * 12 + 4);
+            const float4 c_c = *reinterpret_cast<const float4*>(a.mvf_coef + (long)(c0 + i) * 12 + 8);
+            wt_[i][0] = c_a.x; wt_[i][1] = c_a.y; wt_[i][2] = c_a.z; wh_[i][0] = c_a.w;
+            wh_[i][1] = c_b.x; wh_[i][2] = c_b.y; ww_[i][0] = c_b.z; ww_[i][1] = c_b.w;
+            ww_[i][2] = c_c.x; sc_[i] = c_c.y; sh_[i] = c_c.z;
+        }
+        const int hw = a.H * a.W;
+        const int img0 = fd_div(m0, a.fd_hw_mul, a.fd_hw_shr);
+        const int imgb = img0 > 0 ? img0 - 1 : 0;                      // the tile's first rows may need the frame before img0
+        const long img_bytes = (long)hw * a.xps * ESZ;
+        const long left = (long)(a.N - imgb) * img_bytes;
+        const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long)imgb * img_bytes), 0,
+                                                                                (unsigned)(left < 0x7ffffff0L ? left : 0x7ffffff0L), 0x00020000);
+        const unsigned d_t = (unsigned)img_bytes, d_h = (unsigned)(a.W * a.xps * ESZ), d_w = (unsigned)(a.xps * ESZ);
+        typedef typename std::conditional<sizeof(ET) == 2, unsigned __attribute__((ext_vector_type(2))), u32x4>::type q_t;
+        auto ldq = [&](unsigned off, float (&f)[4]) {
+            if constexpr (sizeof(ET) == 2) {
+                const q_t v = __builtin_amdgcn_raw_buffer_load_b64(rsm, off, 0, 0);
+                f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+                f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+            } else {
+                const q_t v = __builtin_amdgcn_raw_buffer_load_b128(rsm, off, 0, 0);
+                f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+            }
+        };
+        char* dst = As + buf * BM * PITCH + (GLDS ? 0 : cq4 * (4 * ESZ));
+        // LDS-DMA image: 16-byte unit u of row r sits at position u ^ ((r >> 1) & 7) (the source-side swizzle of load_chunk)
+        auto dst_off = [&](int r) {
+            if constexpr (GLDS > 0) {
+                const int u = (cq4 * 4 * ESZ) >> 4, sub = (cq4 * 4 * ESZ) & 15;
+                return r * PITCH + ((u ^ ((r >> 1) & 7)) << 4) + sub;
+            } else {
+                return r * PITCH;
+            }
+        };
+#pragma unroll 2
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r00 + RST * k, m = m0 + r;
+            const int img = fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * hw;
+            const int oh = fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.W;
+            const int t = img - fd_div(img, a.fd_t_mul, a.fd_t_shr) * a.mvf_T;
+            const bool ok = m < a.M;
+            const unsigned oc = (unsigned)(((img - imgb) * hw + rem) * a.xps + c0) * ESZ;
+            float prev[4], cur[4], next[4], up[4], dn[4], lf[4], rt[4];
+            ldq(ok ? oc : kOOB, cur);
+            ldq(ok && t > 0 ? oc - d_t : kOOB, prev);
+            ldq(ok && t + 1 < a.mvf_T ? oc + d_t : kOOB, next);
+            ldq(ok && oh > 0 ? oc - d_h : kOOB, up);
+            ldq(ok && oh + 1 < a.H ? oc + d_h : kOOB, dn);
+            ldq(ok && ow > 0 ? oc - d_w : kOOB, lf);
+            ldq(ok && ow + 1 < a.W ? oc + d_w : kOOB, rt);
+            float y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float yt = wt_[i][0] * prev[i] + wt_[i][1] * cur[i] + wt_[i][2] * next[i];
+                const float yh = wh_[i][0] * up[i] + wh_[i][1] * cur[i] + wh_[i][2] * dn[i];
+                const float yw = ww_[i][0] * lf[i] + ww_[i][1] * cur[i] + ww_[i][2] * rt[i];
+                float v = (yt + yh) + yw;
+                if (a.mvf_act) {
+                    const float u = sc_[i] * v + sh_[i];
+                    v = u * (fminf(fmaxf(u + 3.0f, 0.0f), 6.0f) / 6.0f);
+                }
+                y[i] = ok ? v : 0.f;
+            }
+            if constexpr (sizeof(ET) == 2) {
+                uint2 pk;
+                pk.x = pack_bf16x2(y[0], y[1]);
+                pk.y = pack_bf16x2(y[2], y[3]);
+                *reinterpret_cast<uint2*>(dst + dst_off(r)) = pk;
+            } else {
+                *reinterpret_cast<float4*>(dst + dst_off(r)) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+    };
+    int staged_cc = 0;                   // K chunk (within the tap) of the Stage registers: MVFL builds its A rows at store time
     auto load_chunk = [&](Stage& st, int buf = 0) {
         (void)buf;
+        staged_cc = cc;
+        const bool mvf_chunk = MVFL && cc * CE < a.mvf_cs;
         const int ci = cc * CE + q * UE;                       // first channel of this thread's unit
         const bool cok = ci < a.Cin;
         const bool from2 = (a.split_c > 0) && (cc * CE < a.split_c);
@@ -320,6 +418,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             const __amdgpu_buffer_rsrc_t rs = from2 ? rs_x2 : rs_x;
 #pragma unroll
             for (int i = 0; i < A_ROWS_PT; ++i) {
+                if constexpr (MVFL) {
+                    if (mvf_chunk) break;                      // wave-uniform: the A rows of this chunk are computed in store_chunk
+                }
                 unsigned voff;
                 if constexpr (PW) {
                     voff = (a_off[i] + (unsigned)(cc * CE) * ESZ) | cbad;              // kOOB + small stays out of range
@@ -345,12 +446,24 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 }
             }
         }
+        if constexpr (MVFL && GLDS > 0) {
+            if (mvf_chunk) mvf_rows(buf, cc);              // the chunk's A rows: computed and written into the DMA image by the waves themselves
+        }
         advance();
     };
     auto store_chunk = [&](int buf, const Stage& st) {
         char* ad = As + buf * BM * PITCH + lrow * PITCH + q * 16;
+        bool a_done = false;
+        if constexpr (MVFL) {
+            if (staged_cc * CE < a.mvf_cs) {
+                mvf_rows(buf, staged_cc);
+                a_done = true;
+            }
+        }
+        if (!a_done) {
 #pragma unroll
-        for (int i = 0; i < A_ROWS_PT; ++i) *reinterpret_cast<uint4*>(ad + RP * i * PITCH) = st.a[i];
+            for (int i = 0; i < A_ROWS_PT; ++i) *reinterpret_cast<uint4*>(ad + RP * i * PITCH) = st.a[i];
+        }
         char* bd = Bs + buf * BN * PITCH + lrow * PITCH + q * 16;
 #pragma unroll
         for (int i = 0; i < B_ROWS_PT; ++i) *reinterpret_cast<uint4*>(bd + RP * i * PITCH) = st.b[i];
@@ -644,6 +757,125 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         const u32x4 mv = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (unsigned)(row * (a.Cout / 4) + n0 / 4 + seg * 16), 0, 0);
         *reinterpret_cast<uint4*>(smem + kMaskOff + row * (BN / 4) + seg * 16) = make_uint4(mv.x, mv.y, mv.z, mv.w);
     }
+    // ---- bf16 training epilogues (EPI 1 forward + BN statistics, 2 plain data gradient; written for 6 = data gradient + BN-backward sums too):
+    // nothing is added to the accumulators before the store, so they are rounded to bf16 IN REGISTERS and the C tile is staged
+    // as bf16 -- half the LDS bytes (8-byte instead of 16-byte staging writes), the whole 128-row tile in ONE pass instead of two
+    // halves (one barrier less), and each thread handles 8 channels of a row: 16-byte loads of z, 16-byte stores, half the
+    // per-row offset arithmetic.  Identical numerics: the statistics were always taken from the ROUNDED values.
+    if constexpr (sizeof(ET) == 2 && (EPI == 1 || EPI == 2) && BM == kBM) {      // (EPI 6 measured 0...+12 % slower this way: its z loads already fill the registers)
+        if ((a.Cout & 7) == 0) {
+            constexpr int CPB = BN * 2 + 8;                  // pitch: 2 dwords past a multiple of 32 banks -> conflict-free 8-byte writes
+            static_assert(BM * CPB <= kSmem, "bf16 C tile must fit in the A/B LDS buffers");
+            constexpr int TPR8 = BN / 8, RPP8 = NT / TPR8, NPS8 = BM / RPP8;
+            static_assert(2 * 2 * RPP8 * TPR8 * 16 <= kSmem, "statistics scratch");
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    char* cp = smem + ((wm * TM + i) * 32 + (lane & 31)) * CPB + ((wn * TN + j) * 32 + 4 * (lane >> 5)) * 2;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(acc[i][j][4 * g], acc[i][j][4 * g + 1]);
+                        pk.y = pack_bf16x2(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                        *reinterpret_cast<uint2*>(cp + g * 16) = pk;
+                    }
+                }
+            const int cq8 = tid % TPR8, r08 = tid / TPR8;
+            const int col8 = n0 + cq8 * 8;
+            const bool cok8 = col8 < a.Cout;
+            float kk8[8], mu8[8], rs8[8], sc8[8], sh8[8], s1[8], s2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { kk8[k] = mu8[k] = rs8[k] = sc8[k] = sh8[k] = s1[k] = s2[k] = 0.f; }
+            auto ld8 = [&](const float* p, float (&f)[8]) {
+                const float4 u = *reinterpret_cast<const float4*>(p + col8), v = *reinterpret_cast<const float4*>(p + col8 + 4);
+                f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w; f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
+            };
+            if (EPI == 1 && a.stats_shift && cok8) ld8(a.stats_shift, kk8);
+            if (e_bnb && cok8) { ld8(a.bn_mean, mu8); ld8(a.bn_invstd, rs8); ld8(a.bn_scale, sc8); ld8(a.bn_shift, sh8); }
+            unsigned offs8[NPS8];
+            u32x4 zraw[NPS8];
+            {
+                const int mrow0 = m0 + r08;
+#pragma unroll
+                for (int ps = 0; ps < NPS8; ++ps) {
+                    const int m = mrow0 + ps * RPP8;
+                    unsigned off;
+                    if (e_scatter) {
+                        const int img = fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * (a.Ho * a.Wo);
+                        const int oh = fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
+                        off = (unsigned)((((img - eimg0) * a.o_hfull + oh * a.o_s + a.o_ph) * a.o_wfull + ow * a.o_s + a.o_pw) * a.Cout + col8) * 2u;
+                    } else {
+                        off = (unsigned)((m - m0) * a.Cout + col8) * 2u;
+                    }
+                    offs8[ps] = (cok8 && m < a.M) ? off : kOOB;
+                    if constexpr (e_bnb) zraw[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, offs8[ps], 0, 0);
+                }
+            }
+            __syncthreads();
+            auto unpack8 = [](const u32x4& t, float (&f)[8]) {
+                f[0] = __uint_as_float(t.x << 16); f[1] = __uint_as_float(t.x & 0xffff0000u);
+                f[2] = __uint_as_float(t.y << 16); f[3] = __uint_as_float(t.y & 0xffff0000u);
+                f[4] = __uint_as_float(t.z << 16); f[5] = __uint_as_float(t.z & 0xffff0000u);
+                f[6] = __uint_as_float(t.w << 16); f[7] = __uint_as_float(t.w & 0xffff0000u);
+            };
+#pragma unroll
+            for (int ps = 0; ps < NPS8; ++ps) {
+                const unsigned off = offs8[ps];
+                const bool ok = off != kOOB;
+                const char* src = smem + (r08 + ps * RPP8) * CPB + cq8 * 16;
+                const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+                u32x4 pk;
+                pk.x = lo.x; pk.y = lo.y; pk.z = hi.x; pk.w = hi.y;
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, off, 0, 0);
+                if constexpr (EPI == 1 || e_bnb) {
+                    float v[8];
+                    unpack8(pk, v);
+                    if constexpr (e_bnb) {
+                        float zv[8];
+                        unpack8(zraw[ps], zv);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float gm = (ok && (zv[k] * sc8[k] + sh8[k]) > 0.f) ? v[k] : 0.f;
+                            s1[k] += gm;
+                            s2[k] += gm * ((zv[k] - mu8[k]) * rs8[k]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float d = ok ? v[k] - kk8[k] : 0.f;        // rows past M contribute nothing
+                            s1[k] += d;
+                            s2[k] += d * d;
+                        }
+                    }
+                }
+            }
+            if constexpr (EPI == 1 || e_bnb) {               // column sums over the RPP8 row-threads, fixed order, one writer per column
+                __syncthreads();
+                float4* red = reinterpret_cast<float4*>(smem);
+                red[((r08 * 2 + 0) * 2 + 0) * TPR8 + cq8] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                red[((r08 * 2 + 0) * 2 + 1) * TPR8 + cq8] = make_float4(s1[4], s1[5], s1[6], s1[7]);
+                red[((r08 * 2 + 1) * 2 + 0) * TPR8 + cq8] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                red[((r08 * 2 + 1) * 2 + 1) * TPR8 + cq8] = make_float4(s2[4], s2[5], s2[6], s2[7]);
+                __syncthreads();
+                // 2 * TPR8 threads finish: thread (h, cq8) sums 4 of the 8 columns of group cq8 over the RPP8 row-threads
+                if (tid < 2 * TPR8) {
+                    const int h = tid / TPR8, cq = tid - h * TPR8, c4 = n0 + cq * 8 + 4 * h;
+                    if (c4 < a.Cout && tm_i * kBM < a.M) {
+                        float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+                        for (int r = 0; r < RPP8; ++r) {
+                            const float4 p1 = red[((r * 2 + 0) * 2 + h) * TPR8 + cq], p2 = red[((r * 2 + 1) * 2 + h) * TPR8 + cq];
+                            t1.x += p1.x; t1.y += p1.y; t1.z += p1.z; t1.w += p1.w;
+                            t2.x += p2.x; t2.y += p2.y; t2.z += p2.z; t2.w += p2.w;
+                        }
+                        float* p = a.stats_part + ((long)tm_i * a.Cout + c4) * 2;
+                        p[0] = t1.x; p[1] = t2.x; p[2] = t1.y; p[3] = t2.y; p[4] = t1.z; p[5] = t2.z; p[6] = t1.w; p[7] = t2.w;
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
         if (hf > 0) __syncthreads();                     // previous half fully read out
@@ -797,19 +1029,19 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_pf2_kernel(ConvArgs a) {
     conv_tile<ET, WM, WN, TM, TN, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
-template <typename ET, int WM, int WN, int TM, int TN, int EPI = 0, bool PW = false>
+template <typename ET, int WM, int WN, int TM, int TN, int EPI = 0, bool PW = false, bool MVFL = false>
 __global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
-    conv_tile<ET, WM, WN, TM, TN, true, false, false, EPI, PW>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+    conv_tile<ET, WM, WN, TM, TN, true, false, false, EPI, PW, 0, MVFL>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
 // LDS-DMA staged variant for the long-K (matrix-core bound) launches
-template <typename ET, int WM, int WN, int TM, int TN, int EPI, int NB>
-__global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
+template <typename ET, int WM, int WN, int TM, int TN, int EPI, int NB, bool MVFL = false>
+__global__ __launch_bounds__(kThreads, (NB == 1 && !MVFL) ? 4 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
-    conv_tile<ET, WM, WN, TM, TN, false, false, false, EPI, false, NB>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+    conv_tile<ET, WM, WN, TM, TN, false, false, false, EPI, false, NB, MVFL>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
 // The long-K tile: 256 x 128 outputs per workgroup of 8 waves (4 x 2, 64 x 64 each), three 48 KB LDS-DMA buffers = one
@@ -1048,6 +1280,36 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         sk_wins = skh.ws && skh.ws_bytes >= sk_ws_bytes() && tail0 > 0 && (long)tail0 * a.nchunks >= slots &&
                   (1.0f - (float)tail0 / slots) * wave_us0 > 60.0f;
     }
+    if (a.mvf_coef) {                            // MVF fused into this pointwise conv's A loader (inference epilogue: bias + ReLU)
+        MVF_REQUIRE(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.o_s <= 0 && a.bias && a.relu &&
+                        !a.res && !a.stats_part && !a.bn_z, MVF_EINVAL, "conv2d_mvf: needs a plain 1x1 stride-1 conv with bias + ReLU");
+        MVF_REQUIRE(img_bytes * (span_imgs + 1) < 0x7ffffff0L, MVF_EUNSUPPORTED, "conv2d_mvf: image too large for tile-relative 32-bit addressing");
+        fd_make((unsigned)a.mvf_T, a.fd_t_mul, a.fd_t_shr);
+        // which kernel carries the fused loader: MVF_FUSE_KERNEL = 0 register-staged single buffer, 1 / 2 LDS-DMA with 1 / 2 buffers,
+        // -1 (default) = by K: one DMA buffer up to 16 chunks, two beyond (the policy of the unfused inference launches)
+        static const int fk_env = getenv("MVF_FUSE_KERNEL") ? atoi(getenv("MVF_FUSE_KERNEL")) : -1;
+        const int fk = fk_env >= 0 ? fk_env : (a.nchunks <= 16 ? 1 : 2);
+        if (fk == 0) {
+            auto k = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, 4, true, true>;
+            constexpr size_t lds_mvf = (size_t)kLowkLds<BM, BN>();
+            hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds_mvf, st, a);
+        } else if (fk == 1) {
+            auto k = conv_igemm_glds_kernel<ET, WM, WN, TM, TN, 4, 1, true>;
+            constexpr size_t lds_mvf = (size_t)kGldsLds<BM, BN, 1>();
+            hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds_mvf, st, a);
+        } else {
+            auto k = conv_igemm_glds_kernel<ET, WM, WN, TM, TN, 4, 2, true>;
+            constexpr size_t lds_mvf = (size_t)kGldsLds<BM, BN, 2>();
+            static bool attr_mvf = false;
+            if (!attr_mvf) {
+                MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mvf));
+                attr_mvf = true;
+            }
+            hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds_mvf, st, a);
+        }
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     if (a.bn_z) sk_wins = false;                 // the BatchNorm-backward epilogue lives in the single-buffer kernel only
     if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();
@@ -1166,9 +1428,24 @@ struct BnBwdSums {            // optional: the data gradient also accumulates th
     const void* z;
     const float *mean, *invstd, *scale, *shift;
 };
+struct MvfFuse {              // optional: MVF-proper applied to channels [0, cs) inside the A loader (see ConvArgs::mvf_coef)
+    const float* coef;
+    int cs, T, act;
+};
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream, const unsigned char* res_mask = nullptr, const BnBwdSums* bnb = nullptr);
+                         void* stream, const unsigned char* res_mask = nullptr, const BnBwdSums* bnb = nullptr, const MvfFuse* mf = nullptr);
+
+int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void* w_packed, const float* bias, const float* mvf_coef,
+                            int cs, int n_segment, int act, void* y, void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && mvf_coef && bias && cs > 0 && n_segment > 0, MVF_EINVAL, "conv2d_fwd_mvf: bad argument");
+    const int ce = d->dtype == MVF_F32 ? 32 : 64;
+    MVF_REQUIRE(cs % ce == 0 && cs <= d->cin && d->n % n_segment == 0 && d->ho == d->h && d->wo == d->w && d->x_pix_stride == d->cin, MVF_ESHAPE,
+                "conv2d_fwd_mvf: cs=%d must be a multiple of %d (one K chunk), n a multiple of n_segment, output size = input size", cs, ce);
+    MVF_REQUIRE((uintptr_t)mvf_coef % 16 == 0, MVF_EINVAL, "conv2d_fwd_mvf: mvf_coef must be 16-byte aligned");
+    const MvfFuse mf = {mvf_coef, cs, n_segment, act};
+    return conv_fwd_impl(d, x, nullptr, w_packed, bias, nullptr, y, nullptr, nullptr, ws, ws_bytes, stream, nullptr, nullptr, &mf);
+}
 
 int mvf_conv2d_nhwc_dgrad_bnsums(const mvf_conv_desc_t* d, const void* dz, const void* w_packed_dgrad, void* y, const void* bn_z,
                                  const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
@@ -1213,7 +1490,7 @@ int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const voi
 
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream, const unsigned char* res_mask, const BnBwdSums* bnb) {
+                         void* stream, const unsigned char* res_mask, const BnBwdSums* bnb, const MvfFuse* mf) {
     MVF_REQUIRE(d && x && w_packed && y, MVF_EINVAL, "conv2d: NULL argument");
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -1262,6 +1539,9 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     (void)esz;
     a.pad_w = d->pad; a.w_kh0 = 0; a.w_kw0 = 0; a.w_ts = 1; a.w_kwfull = d->kw;
     a.stats_part = stats_part; a.stats_shift = stats_shift;
+    if (mf) {
+        a.mvf_coef = mf->coef; a.mvf_cs = mf->cs; a.mvf_T = mf->T; a.mvf_act = mf->act;
+    }
     if (bnb) {
         a.bn_z = (const char*)bnb->z; a.bn_mean = bnb->mean; a.bn_invstd = bnb->invstd; a.bn_scale = bnb->scale; a.bn_shift = bnb->shift;
     }

@@ -531,8 +531,16 @@ __global__ void pack_dgrad_weight_kernel(const float* w, int cout, int cin, int 
 // by one): workgroup b serves the job whose [first_block, next first_block) range holds b, 2048 elements per workgroup.
 // kind 0: out[co][kh][kw_pad][cin_pad] = w[co][ci][kh][kw] (zero padded)      (= pack_weight_kernel, no scale)
 // kind 1: out[ci][kh'][kw'][co] = w[co][ci][KH-1-kh'][KW-1-kw']               (= pack_dgrad_weight_kernel)
+// kind 2 / 3: the same two packs as kind 0 / 1 for cout % 32 == 0, cin % 32 == 0, kh * kw <= 9, no padding, done as an LDS-tiled
+// transpose: a workgroup owns 32 output x 32 input channels x all taps, reads 32 contiguous runs of 32 * taps floats (whole
+// cache lines; the gather of kind 0 / 1 touches one line per LANE for the data-gradient layout) and writes 64-byte runs.
+// LDS image [co][ci * taps + tap] with a row pitch of 32 * taps + 1 floats: lanes along ci step by `taps` (odd -> conflict-free),
+// lanes along co by the odd pitch.  The two batched packs took 0.36 ms of every training step (0.8 TB/s); blocks per job =
+// (cout / 32) * (cin / 32).
+constexpr int kPackT = 32, kPackTapsMax = 9;
 template <typename ET>
 __global__ __launch_bounds__(256) void pack_batched_kernel(const mvf_pack_job_t* jobs, int njobs) {
+    __shared__ float tile[kPackT * (kPackT * kPackTapsMax + 1)];
     int lo = 0, hi = njobs - 1;                          // last job with first_block <= blockIdx.x (wave-uniform binary search)
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -541,6 +549,29 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const mvf_pack_job_t*
     const mvf_pack_job_t j = jobs[lo];
     const float* w = j.w;
     ET* out = reinterpret_cast<ET*>(j.out);
+    if (j.kind >= 2) {
+        const int taps = j.kh * j.kw, run = kPackT * taps, pitch = run + 1;
+        const int b = (int)blockIdx.x - j.first_block, tiles_ci = j.cin / kPackT;
+        const int co0 = (b / tiles_ci) * kPackT, ci0 = (b % tiles_ci) * kPackT;
+        for (int e = threadIdx.x; e < kPackT * run; e += 256) {            // row co0 + r: floats [ci0 * taps, (ci0 + 32) * taps)
+            const int r = e / run, q = e - r * run;
+            tile[r * pitch + q] = w[((long)(co0 + r) * j.cin + ci0) * taps + q];
+        }
+        __syncthreads();
+        const int l = threadIdx.x & 31, g = threadIdx.x >> 5;               // 8 groups of 32 lanes
+        if (j.kind == 2) {                                                  // out[co][tap][ci]: lanes along ci
+            for (int p = g; p < kPackT * taps; p += 8) {
+                const int r = p / taps, t = p - r * taps;
+                stf(out + ((long)(co0 + r) * taps + t) * j.cin + ci0 + l, tile[r * pitch + l * taps + t]);
+            }
+        } else {                                                            // out[ci][flipped tap][co]: lanes along co
+            for (int p = g; p < kPackT * taps; p += 8) {
+                const int c = p / taps, t = p - c * taps;
+                stf(out + ((long)(ci0 + c) * taps + t) * j.cout + co0 + l, tile[l * pitch + c * taps + (taps - 1 - t)]);
+            }
+        }
+        return;
+    }
     const long base = (long)((int)blockIdx.x - j.first_block) * 2048;
     const long total = j.kind == 0 ? (long)j.cout * j.kh * j.kw_pad * j.cin_pad : (long)j.cin * j.kh * j.kw * j.cout;
 #pragma unroll

@@ -32,6 +32,11 @@ def _stream():
 
 
 _SK_WS = {}
+# MVF computed INSIDE conv1's A-operand loader (mvf_conv2d_nhwc_fwd_mvf: one launch, no slice buffer) instead of the stencil kernel +
+# split-A conv.  Parity-tested (tests/test_conv_gpu.py, tests/test_net_gpu.py), but measured 3-5 % SLOWER end to end on MI355X (bf16
+# inference 7090-7270 vs 7480 clips/s, fp32 1622-1656 vs 1672): every n-tile of the conv recomputes the stencil of its rows (2-4x
+# redundant VALU + loads) and the loader's extra registers cost a workgroup per CU -- so it is opt-in (MVF_FUSE_LOADER=1).
+FUSE_MVF_LOADER = __import__("os").environ.get("MVF_FUSE_LOADER", "0") == "1"
 
 
 def _sk_workspace(device):
@@ -96,6 +101,15 @@ class _Conv(object):
                                          _stream()), "mvf_conv2d_nhwc_fwd")
         return y, ho, wo
 
+    def run_mvf(self, x, n, h, w, mvf, out=None):
+        """conv1 with the MVF module fused into its A-operand load (one launch: no slice buffer, no stencil kernel)."""
+        y = out if out is not None else torch.empty(n, h, w, self.cout, dtype=self.dt, device=x.device)
+        d = ConvDesc(n, h, w, self.cin, self.cout, 1, 1, 1, 0, h, w, self.cin, _DT[self.dt], 1, 0, 0)
+        ws = _sk_workspace(x.device)
+        check(lib.mvf_conv2d_nhwc_fwd_mvf(C.byref(d), _p(x), _p(self.wp), _p(self.bias), _p(mvf.coef), mvf.cs, mvf.T, mvf.act, _p(y), _p(ws),
+                                          ws.numel(), _stream()), "mvf_conv2d_nhwc_fwd_mvf")
+        return y, h, w
+
 
 class _MvfStage(object):
     def __init__(self, mvf, dtype, device):
@@ -114,6 +128,13 @@ class _MvfStage(object):
             check(lib.mvf_bn_fold(_p(f32(bn.weight)), _p(f32(bn.bias)), _p(f32(bn.running_mean)), _p(f32(bn.running_var)),
                                   C.c_float(bn.eps), cs, _p(self.scale), _p(self.shift), _stream()), "mvf_bn_fold")
         self.dt = dtype
+        # coefficient table of the FUSED path (mvf_conv2d_nhwc_fwd_mvf): [cs][12] = {w_t[3], w_h[3], w_w[3], scale, shift, 0}
+        z3 = torch.zeros(cs, 3, dtype=torch.float32, device=device)
+        one, zero = torch.ones(cs, 1, dtype=torch.float32, device=device), torch.zeros(cs, 1, dtype=torch.float32, device=device)
+        self.act = int(mvf.use_hs)
+        self.coef = torch.cat([self.wt, self.wh if self.wh is not None else z3, self.ww if self.ww is not None else z3,
+                               self.scale.view(cs, 1) if self.scale is not None else one,
+                               self.shift.view(cs, 1) if self.shift is not None else zero, zero], dim=1).contiguous()
 
     def run_slice(self, x, nt, h, w, c):
         out = torch.empty(nt, h, w, self.cs, dtype=self.dt, device=x.device)
@@ -147,10 +168,14 @@ class _Block(object):
             self.down = _Conv(blk.downsample[0], blk.downsample[1], dtype, False, device)
         ce = 32 if dtype == torch.float32 else 64
         self.split_ok = self.mvf is not None and self.mvf.cs % ce == 0
+        # MVF fused into conv1's loader (opt-in, see FUSE_MVF_LOADER); default: stencil kernel into a slice buffer + split-A conv
+        self.fuse_mvf = self.split_ok and FUSE_MVF_LOADER and self.c1.kh == 1 and self.c1.stride == 1 and self.c1.relu
 
     def run(self, x, nt, h, w, c, out=None):
         if self.mvf is None:
             o1, _, _ = self.c1.run(x, nt, h, w, c)
+        elif self.fuse_mvf:
+            o1, _, _ = self.c1.run_mvf(x, nt, h, w, self.mvf)
         elif self.split_ok:
             sl = self.mvf.run_slice(x, nt, h, w, c)
             o1, _, _ = self.c1.run(x, nt, h, w, c, x2=sl, split_c=self.mvf.cs)

@@ -773,8 +773,9 @@ class TrainEngine(_ParamStore):
                         continue
                     w, out, cout, cin, kh, kw, kwp, cinp, kd = j
                     total = cout * kh * kwp * cinp if kd == 0 else cin * kh * kw * cout
-                    jobs.append(_lib.PackJob(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, kwp, cinp, kd, first))
-                    first += (total + 2047) // 2048
+                    tiled = cout % 32 == 0 and cin % 32 == 0 and kh * kw <= 9 and kwp == kw and cinp == cin     # LDS-tiled transpose (kinds 2 / 3)
+                    jobs.append(_lib.PackJob(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, kwp, cinp, kd + 2 if tiled else kd, first))
+                    first += (cout // 32) * (cin // 32) if tiled else (total + 2047) // 2048
                 if not jobs:
                     self._pack_tables[k] = None
                     continue

@@ -189,3 +189,82 @@ def test_conv_kernel_variants_forced_by_env(env):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not forced_by_env",
                         "-p", "no:cacheprovider"], env=child_env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ MVF fused into the conv's loader
+# (clips, T, h, w, C, cout, cs): ragged M (rows past the last tile), clips shorter than a tile, both tile shapes, several K chunks of MVF
+MVF_FUSED_CASES = [(2, 4, 7, 7, 128, 64, 64), (3, 3, 5, 9, 256, 128, 128), (1, 8, 14, 14, 512, 256, 64), (40, 2, 2, 2, 128, 128, 64), (2, 1, 6, 6, 256, 64, 64)]
+
+
+@pytest.mark.parametrize("case", MVF_FUSED_CASES, ids=lambda c: "n%d_t%d_%dx%d_c%d_o%d_cs%d" % c)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("mode,use_hs", [("THW", True), ("TH", True), ("T", False)])
+def test_mvf_fused_into_conv_loader_equals_stencil_then_conv(case, dtype, mode, use_hs):
+    """mvf_conv2d_nhwc_fwd_mvf (MVF-proper computed inside the 1x1 conv's A-operand loader, reference MVF.py:104-138 + resnet.py:213-215)
+    against the two-launch path it replaces (mvf_fwd_infer_slice into a slice buffer, then the split-A conv) and against the numpy
+    oracle of MVF-proper followed by a torch conv."""
+    from mvfnet_amd import _lib
+    from oracle import mvf_numpy
+    lib, check = _lib.lib, _lib.check
+    clips, T, h, w, Cc, cout, cs = case
+    if dtype == torch.float32:
+        cs = cs // 2 if cs > 64 else 32                        # fp32 chunks are 32 channels
+    nt = clips * T
+    dt = _lib.MVF_F32 if dtype == torch.float32 else _lib.MVF_BF16
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    g = torch.Generator().manual_seed(nt * 7 + Cc + cs)
+    x = torch.randn(nt, h, w, Cc, generator=g).to(dtype).cuda()
+    wt, wh, ww = (torch.randn(cs, 3, generator=g).cuda() * 0.5 for _ in range(3))
+    bits = {"T": 1, "TH": 3, "THW": 7}[mode]
+    wh_, ww_ = (wh if bits & 2 else None), (ww if bits & 4 else None)
+    scale, shift = ((torch.rand(cs, generator=g) + 0.5).cuda(), (torch.randn(cs, generator=g) * 0.3).cuda()) if use_hs else (None, None)
+    wgt = (torch.randn(cout, Cc, 1, 1, generator=g) * (2.0 / Cc) ** 0.5).cuda()
+    bias = (torch.randn(cout, generator=g) * 0.2).cuda()
+    wp = torch.empty(cout, 1, 1, Cc, dtype=dtype, device="cuda")
+    check(lib.mvf_pack_conv_weight(p(wgt), cout, Cc, 1, 1, 1, Cc, None, p(wp), dt, None))
+    # two launches: stencil -> slice buffer -> split-A conv
+    sl = torch.empty(nt, h, w, cs, dtype=dtype, device="cuda")
+    md = _lib.MvfDesc(nt, Cc, h, w, T, cs, bits, _lib.MVF_NHWC, dt)
+    check(lib.mvf_fwd_infer_slice(C.byref(md), p(x), p(sl), p(wt), p(wh_), p(ww_), p(scale), p(shift), None))
+    y2 = torch.empty(nt, h, w, cout, dtype=dtype, device="cuda")
+    d2 = _lib.ConvDesc(nt, h, w, Cc, cout, 1, 1, 1, 0, h, w, Cc, dt, 1, cs, cs)
+    check(lib.mvf_conv2d_nhwc_fwd(C.byref(d2), p(x), p(sl), p(wp), p(bias), None, p(y2), None))
+    # one launch
+    z3 = torch.zeros(cs, 3, device="cuda")
+    coef = torch.cat([wt, wh_ if wh_ is not None else z3, ww_ if ww_ is not None else z3,
+                      scale.view(cs, 1) if use_hs else torch.ones(cs, 1, device="cuda"),
+                      shift.view(cs, 1) if use_hs else torch.zeros(cs, 1, device="cuda"), torch.zeros(cs, 1, device="cuda")], 1).contiguous()
+    y1 = torch.empty(nt, h, w, cout, dtype=dtype, device="cuda")
+    d1 = _lib.ConvDesc(nt, h, w, Cc, cout, 1, 1, 1, 0, h, w, Cc, dt, 1, 0, 0)
+    ws = torch.zeros(max(lib.mvf_conv2d_workspace_bytes(C.byref(d1)), 16), dtype=torch.uint8, device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd_mvf(C.byref(d1), p(x), p(wp), p(bias), p(coef), cs, T, int(use_hs), p(y1), p(ws), ws.numel(), None))
+    torch.cuda.synchronize()
+    assert rel_err(y1.float().cpu().numpy(), y2.float().cpu().numpy()) < (1e-6 if dtype == torch.float32 else 8e-3)
+    # oracle: numpy MVF-proper (eval BN folded into scale / shift) on the stored input, then the conv in fp32
+    xn = x.float().cpu().permute(0, 3, 1, 2).contiguous().numpy()
+    s = xn[:, :cs].reshape(clips, T, cs, h, w).astype(np.float64)
+    y = np.zeros_like(s)
+    for dim, wv, on in ((1, wt, True), (3, wh, bits & 2), (4, ww, bits & 4)):
+        if not on:
+            continue
+        wv = wv.double().cpu().numpy()
+        for j in range(3):
+            sh_ = np.zeros_like(s)
+            dd = j - 1
+            src = [slice(None)] * 5
+            dst = [slice(None)] * 5
+            n_ = s.shape[dim]
+            if abs(dd) < n_:
+                src[dim] = slice(max(dd, 0), n_ + min(dd, 0))
+                dst[dim] = slice(max(-dd, 0), n_ + min(-dd, 0))
+                sh_[tuple(dst)] = s[tuple(src)]
+            y += wv[:, j].reshape(1, 1, cs, 1, 1) * sh_
+    if use_hs:
+        u = y * scale.double().cpu().numpy().reshape(1, 1, cs, 1, 1) + shift.double().cpu().numpy().reshape(1, 1, cs, 1, 1)
+        y = u * np.clip(u + 3.0, 0.0, 6.0) / 6.0
+    xin = xn.copy()
+    o = torch.from_numpy(y.reshape(nt, cs, h, w)).to(dtype).float().numpy()          # the engine stores / stages o in `dtype`
+    xin[:, :cs] = o
+    wq = wgt.to(dtype).float().cpu()
+    ref = F.relu(F.conv2d(torch.from_numpy(xin), wq, bias.cpu())).permute(0, 2, 3, 1).numpy()
+    assert rel_err(y1.float().cpu().numpy(), ref) < (2e-5 if dtype == torch.float32 else 1e-2)

@@ -100,3 +100,17 @@ def test_c2_full_batch_clip_independence_and_oracle():
     outp = m(batch[perm], None, return_loss=False, return_numpy=False)
     assert rel_err(outp.cpu().numpy(), out[perm].cpu().numpy()) < 1e-5
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_c1_logits_with_mvf_fused_into_the_conv_loader(dtype, monkeypatch):
+    """The opt-in single-launch MVF + conv1 (mvf_conv2d_nhwc_fwd_mvf) through the whole network: the reference's logits again."""
+    from mvfnet_amd import engine
+    monkeypatch.setattr(engine, "FUSE_MVF_LOADER", True)
+    g = golden("net_cases.npz")
+    m = _model(50, 4, dtype=dtype)
+    assert all(b.fuse_mvf for b in m.backbone.engine().blocks if b.mvf is not None)
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 224, 224)).cuda()
+    logits = m(imgs, None, return_loss=False)
+    assert rel_err(logits, g["c1/eval/logits"]) < (TOL_F32 if dtype == torch.float32 else TOL_BF16)
+    assert (logits.argmax(1) == g["c1/eval/logits"].argmax(1)).all()
