@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const mvf_pack_job_t*
 }
 
 int plan_split(int M, int tiles) {
-    int want = std::max(1, 1024 / std::max(tiles, 1));
+    static const int target = getenv("MVF_WGRAD_WGS") ? std::max(64, atoi(getenv("MVF_WGRAD_WGS"))) : 1024;     // workgroups aimed at per launch (A/B switch)
+    int want = std::max(1, target / std::max(tiles, 1));
     int rows = std::max((M + want - 1) / want, 256);
     rows = (rows + 63) / 64 * 64;          // multiple of both chunk heights (32 fp32 / 64 bf16)
     return rows;

@@ -51,9 +51,22 @@ class _on_stream(object):
         _STREAM[0] = self.old
 
 
+_SIDE_WS = {}
+
+
 def _conv_ws(device):
+    """Stream-K scratch of the conv kernel: one buffer per stream the engine launches convs on (two convs running at the same time
+    must not share the partial-tile slots and flags)."""
     from .engine import _sk_workspace
-    return _sk_workspace(device)
+    h = _STREAM[0]
+    if h is None or h.value == torch.cuda.current_stream().cuda_stream:
+        return _sk_workspace(device)
+    key = (str(device), h.value)
+    ws = _SIDE_WS.get(key)
+    if ws is None:
+        ws = torch.empty(lib.mvf_conv2d_workspace_bytes(None), dtype=torch.uint8, device=device)
+        _SIDE_WS[key] = ws
+    return ws
 
 
 class _BN(object):
@@ -362,6 +375,13 @@ class _TBlock(object):
     def forward(self, x, nt, h, w, c, eng):
         m = nt * h * w
         s = dict(x=x, h=h, w=w, c=c)
+        # The downsample branch conv -> BN statistics only depends on the block input: it runs on the side stream (idle during the
+        # forward pass) beside conv1 -> bn1 -> conv2 -> bn2 -> conv3 and is joined before bn3's apply adds the two branches.
+        side = eng.side_stream() if (self.cd is not None and eng.overlap_downsample and eng.fuse_stats) else None
+        if side is not None:
+            side.wait_stream(eng.main_stream())
+            with _on_stream(side):
+                zd, _, _ = self.cd.forward(x, nt, h, w, bn=self.bd)
         if self.mvf is not None:
             s["y"], o = self.mvf.forward(x, nt, h, w, c, eng)
             if self.split_ok:
@@ -380,7 +400,10 @@ class _TBlock(object):
         a2 = self.b2.apply(z2, m2, 1)
         z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3)
         if self.cd is not None:
-            zd, _, _ = self.cd.forward(x, nt, h, w, bn=self.bd)
+            if side is not None:
+                eng.main_stream().wait_stream(side)               # the downsample branch (queued before conv1, see above)
+            else:
+                zd, _, _ = self.cd.forward(x, nt, h, w, bn=self.bd)
             out, bits = self.b3.apply(z3, m2, 1, residual=zd, rbn=self.bd, bits=True)
             s["zd"] = zd
         else:
@@ -517,6 +540,7 @@ class _ParamStore(object):
         return ws
 
     overlap_wgrad = True
+    overlap_downsample = os.environ.get("MVF_SIDE_DOWNSAMPLE", "1") != "0"     # forward: downsample branch on the side stream
     keep_io = False            # keep references to every block's input / output / gradients after backward (teacher-forced parity tests)
     fuse_stats = True          # BatchNorm batch statistics accumulated in the producing conv's epilogue
     fuse_bn_bwd_sums = os.environ.get("MVF_FUSE_BN_BWD", "1") != "0"    # ... and the backward sums in the data gradient's
