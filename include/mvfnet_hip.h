@@ -289,7 +289,9 @@ int mvf_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf
 /* The same step with per-segment multipliers = build_optimizer's paramwise_options (codes/core/train.py:117-156: bias_lr_mult,
  * bias_decay_mult, norm_decay_mult give every parameter its own lr / weight_decay) on the flat buffers: segment k covers elements
  * [first_k, first_{k+1}) (sorted, first_0 = 0) with lr * lr_mult, weight_decay * decay_mult.  nesterov = 0 gives the plain
- * momentum update (p -= lr * buf).  The gradient norm / clip coefficient are global, as clip_grad_norm_ over all parameters. */
+ * momentum update (p -= lr * buf).  The gradient norm / clip coefficient are global, as clip_grad_norm_ over all parameters.
+ * lr_mult < 0 marks a segment EXCLUDED from training (requires_grad False: norm_frozen / partial_norm, resnet.py:496-527): its
+ * gradient does not enter the norm, its parameters and momentum are left untouched. */
 typedef struct mvf_sgd_segment {
     long long first;
     float lr_mult, decay_mult;

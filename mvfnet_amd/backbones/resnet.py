@@ -37,8 +37,10 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style="pytorch",
                  norm_cfg=dict(type="BN"), with_cp=False, avd=False, avd_first=False):
         super().__init__()
-        if style != "pytorch" or dilation != 1 or with_cp or avd:
-            raise NotImplementedError("Bottleneck: only style='pytorch', dilation=1, with_cp=False, avd=False are built "
+        # with_cp (activation checkpointing, reference resnet.py:237-240) trades recomputation for memory and changes no result: the
+        # engine keeps every activation of a step resident (a C3 step holds ~25 GB of the 288 GB), so the flag is accepted and ignored
+        if style != "pytorch" or dilation != 1 or avd:
+            raise NotImplementedError("Bottleneck: only style='pytorch', dilation=1, avd=False are built "
                                       "(the options the MVFNet configs use)")
         self.inplanes, self.planes = inplanes, planes
         self.conv1_stride, self.conv2_stride = 1, stride
@@ -87,7 +89,7 @@ class ResNet(nn.Module):
         super().__init__()
         if depth not in self.arch_settings:
             raise KeyError("invalid depth %s for resnet (bottleneck depths 50/101/152 are built)" % depth)
-        if deep_stem or avg_down or avd or with_cp or tuple(dilations) != (1,) * len(dilations) or tuple(strides)[:num_stages] != (1, 2, 2, 2)[:num_stages]:
+        if deep_stem or avg_down or avd or tuple(dilations) != (1,) * len(dilations) or tuple(strides)[:num_stages] != (1, 2, 2, 2)[:num_stages]:
             raise NotImplementedError("ResNet: only the plain stem / stride (1,2,2,2) / dilation 1 variant is built")
         if not (1 <= num_stages <= 4) or max(out_indices) >= num_stages:
             raise ValueError("bad num_stages / out_indices")

@@ -737,6 +737,26 @@ __global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, long n
         p[i] = pv - lr * (d + momentum * b);
     }
 }
+// sum of squares over the elements of the segments that take part in training (lr_mult >= 0): the clip norm of
+// torch.nn.utils.clip_grad_norm_(filter(requires_grad, params)) when parameters are excluded in scattered places
+__device__ __forceinline__ int seg_of(const mvf_sgd_segment_t* seg, int nseg, long i) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg[mid].first <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ void sqsum_segments_kernel(const float* g, long n, const mvf_sgd_segment_t* seg, int nseg, float* part) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        if (seg[seg_of(seg, nseg, i)].lr_mult >= 0.f) s += g[i] * g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
 // the same update with per-SEGMENT learning-rate / weight-decay multipliers (build_optimizer's paramwise_options, reference
 // codes/core/train.py:117-156) and an optional plain-momentum form: seg[k] = {first element, lr multiplier, decay multiplier},
 // sorted by first element, seg[0].first == 0; a workgroup's 256-element run looks its segment up by binary search per element
@@ -744,11 +764,8 @@ __global__ void sgd_segments_kernel(float* p, const float* g, float* buf, long n
                                     float momentum, float wd, int first_step, int nesterov, const mvf_sgd_segment_t* seg, int nseg) {
     const float coef = (coef_ptr ? coef_ptr[1] : 1.f) * gscale;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = nseg - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (seg[mid].first <= i) lo = mid; else hi = mid - 1;
-        }
+        const int lo = seg_of(seg, nseg, i);
+        if (seg[lo].lr_mult < 0.f) continue;                 // excluded from training (requires_grad False): parameter and momentum untouched
         const float lr_i = lr * seg[lo].lr_mult, wd_i = wd * seg[lo].decay_mult;
         const float pv = p[i];
         const float d = g[i] * coef + wd_i * pv;
@@ -1102,7 +1119,7 @@ int mvf_sgd_step_segments(float* params, const float* grads, float* momentum_buf
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)ws;
     const int nb = (int)std::min<long>((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(sqsum_partial_kernel, dim3(nb), dim3(256), 0, st, grads, n, part);
+    hipLaunchKernelGGL(sqsum_segments_kernel, dim3(nb), dim3(256), 0, st, grads, n, segments, nseg, part);
     MVF_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, st, part, nb, max_norm, grad_scale, norm_out);
     MVF_LAUNCH_CHECK();

@@ -134,3 +134,38 @@ class DistOptimizerHook(object):
             total = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], **self.grad_clip)
         optimizer.step()
         return total
+
+
+class Fp16OptimizerHook(DistOptimizerHook):
+    """The reference's mixed-precision hook (codes/core/fp16/hooks.py:12-136: fp16 model copy, fp32 master weights in the optimizer,
+    loss scaling, gradients copied / un-scaled / clipped in fp32, weights copied back) mapped onto this build's mixed-precision mode:
+    the train engine's bf16 STORAGE -- activations and packed conv weights in bf16, accumulation / BatchNorm statistics / every
+    parameter gradient / master weights / optimizer state in fp32 (what the reference keeps in fp32, plus the gradients).  bf16 has
+    fp32's exponent range, so `loss_scale` is accepted and not needed; there is no fp16 copy of the model to synchronise.
+
+    before_run(model): build the model's train engine in bf16 (call before the first forward_train; a model whose engine already
+    exists in fp32 is refused) and set the `fp16_enabled` flags the reference's wrap_fp16_model sets (hooks.py:108-112).
+    after_train_iter: the DistOptimizerHook sequence; the all-reduce is skipped when distributed=False (hooks.py:84-86)."""
+
+    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, loss_scale=512.0, distributed=True):
+        super().__init__(grad_clip, coalesce, bucket_size_mb)
+        self.loss_scale, self.distributed = loss_scale, distributed
+
+    def before_run(self, model):
+        model = model.module if hasattr(model, "module") else model
+        model.train_engine(dtype=torch.bfloat16)
+        for m in model.modules():
+            if hasattr(m, "fp16_enabled"):
+                m.fp16_enabled = True
+        return model
+
+    def after_train_iter(self, model, optimizer, loss):
+        optimizer.zero_grad()
+        loss.backward()
+        if self.distributed:
+            allreduce_grads(model.parameters(), self.coalesce, self.bucket_size_mb)
+        total = None
+        if self.grad_clip is not None:
+            total = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], **self.grad_clip)
+        optimizer.step()
+        return total

@@ -117,9 +117,9 @@ class Recognizer2D(nn.Module):
         buffer; after engine.attach_grads() the .grad tensors ARE views of it), as the reference's DistOptimizerHook expects."""
         if not imgs.is_cuda:
             raise RuntimeError("Recognizer2D: mvfnet_amd runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
-        # BatchNorms in eval mode (backbone norm_eval=True / frozen stages, reference resnet.py:496-527) normalise with their running
-        # statistics and keep them; parameters excluded from training are supported as a prefix of model.parameters()
-        # (frozen_stages), scattered exclusions (norm_frozen, partial_norm) raise NotImplementedError here
+        # BatchNorms in eval mode (backbone norm_eval=True / frozen stages / partial_norm, reference resnet.py:496-527) normalise with
+        # their running statistics and keep them; parameters excluded from training (frozen_stages: a prefix of model.parameters();
+        # norm_frozen / partial_norm: BatchNorm weights / biases in scattered places) are skipped by the optimizer kernel
         eng = self.train_engine()
         eng.trainable_offset()
         eng.input_pipeline, eng.input_window = getattr(self, "input_pipeline", None), kwargs.get("window")

@@ -610,17 +610,15 @@ class _ParamStore(object):
     lr, momentum, weight_decay, max_norm = 0.015, 0.9, 1e-4, 40.0
 
     def trainable_offset(self):
-        """Flat-buffer offset of the first trainable parameter.  Parameters excluded from training (requires_grad False: the
-        reference's frozen_stages, resnet.py:515-527) are supported when they form a PREFIX of model.parameters() -- stem, then
-        layer1..k, which is what frozen_stages produces: the optimizer (norm, clip, weight decay, momentum, update) then simply
-        runs on the rest of the flat buffers, as torch's clip_grad_norm_ / SGD skip parameters without a gradient.  Scattered
-        exclusions (norm_frozen, partial_norm) are refused."""
+        """Flat-buffer offset of the first trainable parameter.  A PREFIX of model.parameters() excluded from training
+        (requires_grad False: the reference's frozen_stages, resnet.py:515-527 -- stem, then layer1..k) is simply cut off: the
+        optimizer (norm, clip, weight decay, momentum, update) runs on the rest of the flat buffers, as torch's clip_grad_norm_ /
+        SGD skip parameters without a gradient.  Exclusions in scattered places behind it (norm_frozen: every BatchNorm weight /
+        bias, partial_norm; resnet.py:496-513) are handled by the segment form of the optimizer kernel (_segments: lr_mult -1)."""
         params = list(self.model.parameters())
         flags = [p.requires_grad for p in params]
         k = flags.index(True) if True in flags else len(flags)
-        if not all(flags[k:]):
-            raise NotImplementedError("parameters excluded from training must be a prefix of model.parameters() (frozen_stages); "
-                                      "norm_frozen / partial_norm style exclusions are not built")
+        self._scattered_frozen = not all(flags[k:])
         return self._grad_view[id(params[k])].storage_offset() if k < len(params) else self.flat_params.numel()
 
     nesterov = True
@@ -633,20 +631,23 @@ class _ParamStore(object):
         self._seg_tables = {}
 
     def _segments(self, off):
+        """Device table of optimizer segments for the flat range [off, end): neighbours with equal (lr_mult, decay_mult) share a
+        segment; a parameter with requires_grad False gets lr_mult -1 = excluded (norm, update and momentum skip it)."""
         tabs = self.__dict__.setdefault("_seg_tables", {})
-        if off not in tabs:
+        key = (off, tuple(p.requires_grad for p in self.model.parameters()))
+        if key not in tabs:
             segs, last = [], None
             for p in self.model.parameters():
                 first = self._grad_view[id(p)].storage_offset()
                 if first + p.numel() <= off:
                     continue
-                mult = (self.param_options or {}).get(id(p), (1.0, 1.0))
-                if mult != last:                    # neighbours with equal multipliers share a segment (padding elements are zeros)
+                mult = (self.param_options or {}).get(id(p), (1.0, 1.0)) if p.requires_grad else (-1.0, 0.0)
+                if mult != last:                    # (padding elements between parameters are zeros: they may join either side)
                     segs.append(_lib.SgdSegment(max(first - off, 0) if segs else 0, mult[0], mult[1]))
                     last = mult
             arr = (_lib.SgdSegment * len(segs))(*segs)
-            tabs[off] = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(segs))
-        return tabs[off]
+            tabs[key] = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(segs))
+        return tabs[key]
 
     def apply_sgd(self, lr=None, world=1):
         """clip_grad_norm_(max_norm) + SGD on the flat buffers (gradient scaled by 1 / world): one fused launch sequence."""
@@ -658,7 +659,7 @@ class _ParamStore(object):
         args = (_p(self.flat_params[off:]), _p(self.flat_grads[off:]), _p(self.flat_mom[off:]), n, C.c_float(1.0 / world),
                 C.c_float(self.max_norm or 0.0), C.c_float(self.lr if lr is None else lr), C.c_float(self.momentum),
                 C.c_float(self.weight_decay), int(self.steps == 0))
-        if self.nesterov and not self.param_options:
+        if self.nesterov and not self.param_options and not self._scattered_frozen:
             check(lib.mvf_sgd_nesterov_step(*(args + (_p(self.norm_out), _p(ws), ws.numel(), _st()))), "sgd step")
         else:
             tab, nseg = self._segments(off)

@@ -543,13 +543,51 @@ def test_frozen_stages_training_vs_reference_golden():
             assert rel_err(a[: g[k].size], g[k]) < 0.1, k
 
 
-def test_scattered_parameter_exclusion_is_refused():
+def test_norm_frozen_scattered_exclusions_vs_reference_golden():
+    """norm_eval=True + norm_frozen=True (reference resnet.py:496-505): every BatchNorm in eval mode and its weight / bias excluded
+    from training -- 124 parameters in SCATTERED places of model.parameters().  The optimizer's segment kernel leaves them (and their
+    momentum) untouched and keeps their gradients out of the clip norm (max_norm 5 so the clip is active).  Two steps against the
+    reference's own run."""
     import mvfnet_amd
-    m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(50, 4), None, dict(average_clips=None)).cuda().train()
-    m.backbone.layer3[0].bn2.weight.requires_grad = False          # what norm_frozen / partial_norm produce: not a prefix
-    imgs = torch.zeros(1, 4, 3, 64, 64, device="cuda")
-    with pytest.raises(NotImplementedError):
-        m(imgs, torch.zeros(1, 1, dtype=torch.int64, device="cuda"))
+    g = golden("normfrozen_cases.npz")
+    cfg = mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0)
+    cfg["backbone"]["norm_eval"] = True
+    cfg["backbone"]["norm_frozen"] = True
+    m = mvfnet_amd.build_recognizer(cfg, None, dict(average_clips=None))
+    sd = m.state_dict()
+    vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in sd}, strict=True)
+    m = m.cuda().train()
+    frozen = sorted(n for n, p in m.named_parameters() if not p.requires_grad)
+    assert frozen == sorted(g["frozen_names"]) and len(frozen) == 124
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    eng = m.train_engine(max_norm=5.0)
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 96, 96, seed=79)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+    loss = eng.forward(imgs, labels)
+    assert abs(float(loss) - float(g["loss/0"])) < 1e-4 * float(g["loss/0"])
+    eng.backward()
+    params = dict(m.named_parameters())
+    for nme, r in zip(list(g["grad_names"]), g["grad_norms"]):
+        got = float(eng.grad_of(params[nme]).double().norm())
+        assert abs(got - r) < 2e-3 * max(r, 1e-6), (nme, got, r)        # frozen statistics: no batch-statistics chaos
+    norm = eng.step()
+    assert abs(float(norm[0]) - float(g["total_norm/0"])) < 1e-3 * float(g["total_norm/0"])
+    loss1 = eng.forward(imgs, labels)
+    assert abs(float(loss1) - float(g["loss/1"])) < 2e-3 * float(g["loss/1"])
+    eng.backward()
+    norm = eng.step()
+    assert abs(float(norm[0]) - float(g["total_norm/1"])) < 5e-3 * float(g["total_norm/1"])
+    sd = m.state_dict()
+    for k in frozen:
+        assert torch.equal(sd[k], sd0[k]), k                      # excluded parameters did not move
+    for k in g.files:
+        if k.startswith("after2/"):
+            a = sd[k[7:]].detach().float().cpu().numpy().ravel()
+            assert rel_err(a[: g[k].size], g[k]) < 2e-3, k
+    opt = eng.optimizer_state_dict()                              # torch creates no state for parameters without a gradient
+    idx = {n: i for i, (n, _) in enumerate(m.named_parameters())}
+    assert all(idx[n] not in opt["state"] for n in frozen) and len(opt["state"]) == len(idx) - len(frozen)
 
 
 def test_forward_train_autograd_api_and_external_optimizer():
@@ -967,3 +1005,24 @@ def test_train_network_shim_runs_the_config_end_to_end(tmp_path):
     run2 = train_network(m2, batches, cfg2, logger=logs.append)
     assert run2.epoch == 3 and run2.iter == 9
     assert torch.isfinite(run2.engine.flat_params).all()
+
+
+def test_fp16_optimizer_hook_maps_to_the_bf16_engine():
+    """codes/core/fp16/hooks.py:12-136 -> Fp16OptimizerHook(before_run, after_train_iter) with a torch optimizer: the model trains
+    through the bf16-storage engine, master weights and gradients stay fp32, the loss goes down."""
+    from mvfnet_amd.dist import Fp16OptimizerHook
+    m = _model(50, 4)
+    hook = Fp16OptimizerHook(grad_clip=dict(max_norm=40, norm_type=2), loss_scale=512.0, distributed=False)
+    hook.before_run(m)
+    assert m.fp16_enabled and m.train_engine().tdtype == torch.bfloat16
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64, seed=5)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2, seed=5)).cuda()
+    opt = torch.optim.SGD(m.parameters(), lr=0.015, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    losses = []
+    for _ in range(3):
+        out = m(imgs, labels, return_loss=True)
+        total = hook.after_train_iter(m, opt, out["loss_cls"])
+        losses.append(float(out["loss_cls"]))
+        assert float(total) > 0 and all(p.grad.dtype == torch.float32 for p in m.parameters())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert all(p.dtype == torch.float32 for p in m.parameters())
