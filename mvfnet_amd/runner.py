@@ -174,12 +174,15 @@ class DevicePrefetcher(object):
         self.dataset = getattr(loader, "dataset", None)
         self._copy = None
         self._pinned = [{}, {}]
+        self._slot_event = [None, None]      # the upload that last READ each staging slot: must be complete before the host refills it
 
     def __len__(self):
         return len(self.loader)
 
     def _upload(self, batch, slot):
         out, any_host = {}, False
+        if self._slot_event[slot] is not None:
+            self._slot_event[slot].synchronize()      # two batches old: normally long done, never skipped
         for k, v in batch.items():
             if not isinstance(v, torch.Tensor) or v.is_cuda:
                 out[k] = v
@@ -195,6 +198,7 @@ class DevicePrefetcher(object):
         if any_host:
             ev = torch.cuda.Event()
             ev.record()
+        self._slot_event[slot] = ev
         return out, ev
 
     def __iter__(self):

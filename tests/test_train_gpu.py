@@ -1026,3 +1026,52 @@ def test_fp16_optimizer_hook_maps_to_the_bf16_engine():
         assert float(total) > 0 and all(p.grad.dtype == torch.float32 for p in m.parameters())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert all(p.dtype == torch.float32 for p in m.parameters())
+
+
+def test_eight_step_training_trajectory_vs_oracle_norm_eval():
+    """Eight clip + SGD-nesterov steps (norm_eval: frozen statistics keep the synthetic network well-conditioned, so a trajectory is
+    comparable at all) through the fused engine vs the CPU oracle stepping the same state_dict: every loss of the trajectory and the
+    parameters after it -- no drift of forward, backward, clip or momentum over steps; the bf16 engine follows within its noise."""
+    import mvfnet_amd
+    from oracle import net_torch
+    cfg = mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0)
+    cfg["backbone"]["norm_eval"] = True
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64, seed=31))
+    labels = torch.from_numpy(synth.synth_labels(2, seed=31))
+
+    def fresh():
+        m = mvfnet_amd.build_recognizer(cfg, None, dict(average_clips=None))
+        sd = m.state_dict()
+        vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()})
+        m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in sd}, strict=True)
+        return m.cuda().train()
+
+    LR = 0.003          # (the config's 0.015 makes this 2-clip problem overshoot: 5.8, 1.8, 0.7, 1.2, 8.9, ... -- fp32 still agrees to 2e-3, bf16 noise does not)
+    m = fresh()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    mom, ref_losses = {}, []
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    for _ in range(8):
+        for p in params.values():
+            p.grad = None
+        f = net_torch.backbone(imgs.reshape(-1, 3, 64, 64), sd, 50, 4, training=False)
+        loss = F.cross_entropy(net_torch.head(f, sd, 4), labels.squeeze(1))
+        loss.backward()
+        with torch.no_grad():
+            net_torch.sgd_nesterov_step(params, {k: v.grad for k, v in params.items()}, mom, lr=LR)
+        ref_losses.append(float(loss.detach()))
+    eng = m.train_engine(lr=LR)
+    losses = [float(eng.train_step(imgs.cuda(), labels.cuda())) for _ in range(8)]
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 2e-3 * abs(b), (losses, ref_losses)
+    assert ref_losses[-1] < 0.7 * ref_losses[0]                       # the trajectory really trains
+    got = dict(m.named_parameters())
+    for k in ("backbone.conv1.weight", "backbone.layer2.1.conv2.weight", "backbone.layer3.2.conv1.shift_conv.weight", "backbone.layer4.2.bn3.weight",
+              "cls_head.new_fc.weight"):
+        assert rel_err(got[k].detach().cpu().numpy(), params[k].detach().numpy()) < 5e-3, k
+    m16 = fresh()
+    e16 = m16.train_engine(dtype=torch.bfloat16, lr=LR)
+    l16 = [float(e16.train_step(imgs.cuda(), labels.cuda())) for _ in range(8)]
+    for a, b in zip(l16, ref_losses):
+        assert abs(a - b) < 5e-2 * abs(b) + 2e-2, (l16, ref_losses)
