@@ -143,11 +143,11 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
 // SOURCE side: position p of row r holds the 16-byte unit p ^ ((r >> 1) & 7), and the operand fetch applies the same XOR.
 // Out-of-range buffer offsets DMA zeros (tools/probes/glds_probe.hip), so padding taps stay branch-free.
 template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0, bool PW = false, int GLDS = 0,
-          bool MVFL = false>
+          bool MVFL = false, bool ILV = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    static_assert(BM == kBM || (BM == 2 * kBM && GLDS == 3), "BM is 128 (256 for the 8-wave LDS-DMA tile)");
+    static_assert(BM == kBM || (BM == 2 * kBM && GLDS >= 2), "BM is 128 (256 for the 8-wave LDS-DMA tiles)");
     static_assert(WM * WN == 4 || (WM * WN == 8 && GLDS >= 2), "4 waves (8 for the LDS-DMA experiments)");
     constexpr int NT = WM * WN * 64;        // threads per workgroup
     constexpr int RP = NT / 8;              // rows per loader pass (8 lanes x 16 B per row)
@@ -160,6 +160,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     __syncthreads();                                   // LDS hand-over from a previous segment of this workgroup
     static_assert(!GLDS || (!GEN && !PF2 && !LOWK), "the LDS-DMA loop is its own variant");
     static_assert(!MVFL || (((LOWK && PW) || GLDS == 1 || GLDS == 2) && !GEN), "the fused MVF loader: single-buffer register-staged pointwise kernel or the 4-wave LDS-DMA kernels");
+    static_assert(!ILV || (GLDS == 2 && !MVFL), "interleaved DMA issue: the two-buffer LDS-DMA loop");
     constexpr int NBUF = GLDS ? GLDS : (LOWK ? 1 : 2);
     constexpr int PITCH = GLDS ? 128 : kPitch;         // LDS-DMA rows are unpadded (lane-linear destination)
     constexpr int kSmem = GLDS ? kGldsLds<BM, BN, GLDS ? GLDS : 1>() : (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch);
@@ -451,6 +452,38 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         }
         advance();
     };
+    // ILV: the next chunk's DMA pieces are issued BETWEEN the MFMAs of the current chunk's first k-step instead of in a block
+    // before them: a wave's VMEM issue (60-185 cycles per LDS-DMA piece in a loaded phase) then hides under the 32-cycle matrix
+    // instructions already in the pipe -- with one workgroup per CU (the 256 x 256 tile) the two waves of a SIMD run in lockstep,
+    // so a DMA block ahead of the MFMAs leaves the matrix pipe idle for its whole length.  prep_chunk() does the offset
+    // arithmetic of load_chunk() for the chunk at (cc, kh, kw) and advances; issue_piece(n) issues piece n of it.
+    unsigned pv[A_ROWS_PT + B_ROWS_PT];
+    unsigned p_lds_a = 0, p_lds_b = 0;
+    bool p_from2 = false;
+    auto prep_chunk = [&](int buf) {
+        const int ci = cc * CE + q * UE;
+        const unsigned cbad = ci < a.Cin ? 0u : kOOB;
+        p_from2 = (a.split_c > 0) && (cc * CE < a.split_c);
+        const int ps = p_from2 ? a.x2ps : a.xps;
+        const unsigned toff = (unsigned)((kh * a.W + kw) * ps + cc * CE) * ESZ;
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PT; ++i) {
+            const bool ok = ((hmask[i] >> kh) & (wmask[i] >> kw) & 1u) != 0u;
+            pv[i] = ok ? (((p_from2 ? a_off2[i] : a_off[i]) + toff) | cbad) : kOOB;
+        }
+        const unsigned koff = (unsigned)(((a.w_kh0 + kh * a.w_ts) * a.w_kwfull + (a.w_kw0 + kw * a.w_ts)) * a.Cin + cc * CE) * ESZ;
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PT; ++i) pv[A_ROWS_PT + i] = (b_off[i] + koff) | cbad;
+        p_lds_a = lds_a0 + (unsigned)(buf * BM * PITCH);
+        p_lds_b = lds_b0 + (unsigned)(buf * BN * PITCH);
+        advance();
+    };
+    auto issue_piece = [&](int n) {
+        if constexpr (GLDS > 0) {
+            if (n < A_ROWS_PT) glds16(p_from2 ? gs_x2 : gs_x, p_lds_a + (unsigned)(RP * n * PITCH), pv[n]);
+            else glds16(gs_w, p_lds_b + (unsigned)(RP * (n - A_ROWS_PT) * PITCH), pv[n]);
+        }
+    };
     auto store_chunk = [&](int buf, const Stage& st) {
         char* ad = As + buf * BM * PITCH + lrow * PITCH + q * 16;
         bool a_done = false;
@@ -483,7 +516,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // FPIPE: the operand fragments of k-step ks+2 are fetched from LDS behind the MFMAs of k-step ks (two fragment register
     // sets), so the ds_read round trip is exposed once per chunk instead of once per k-step
     constexpr bool FPIPE = GLDS != 0;
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, bool ilv_more = false) {
+        (void)ilv_more;
         const char* Ab = As + buf * BM * PITCH + (wm * TM * 32) * PITCH + frag_off;
         const char* Bb = Bs + buf * BN * PITCH + (wn * TN * 32) * PITCH + frag_off;
         auto fetch = [&](int ks, uint4 (&fa)[TM], uint4 (&fb)[TN]) {
@@ -493,7 +527,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bb + j * 32 * PITCH + ko);
         };
-        auto mma = [&](const uint4 (&fa)[TM], const uint4 (&fb)[TN]) {
+        auto mma = [&](const uint4 (&fa)[TM], const uint4 (&fb)[TN], int piece0 = -1) {
+            (void)piece0;
             if constexpr (ESZ == 4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -514,6 +549,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                         __builtin_memcpy(&av, &fa[i], 16);
                         __builtin_memcpy(&bv, &fb[j], 16);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[i][j], 0, 0, 0);
+                        if constexpr (ILV) {                   // one DMA piece of the next chunk behind each matrix instruction
+                            if (piece0 >= 0 && piece0 + i * TN + j < A_ROWS_PT + B_ROWS_PT) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(piece0 + i * TN + j);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
                     }
             }
         };
@@ -524,11 +566,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             fetch(0, fa0, fb0);
             fetch(1, fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(fa0, fb0);
+            mma(fa0, fb0, ilv_more ? 0 : -1);
             __builtin_amdgcn_sched_barrier(0);
             fetch(2, fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
-            mma(fa1, fb1);
+            mma(fa1, fb1, ilv_more ? TM * TN : -1);
             __builtin_amdgcn_sched_barrier(0);
             fetch(3, fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
@@ -582,8 +624,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             if (kc + 1 < nseg && !(a.prio & 4)) load_chunk(s0, (kc + 1) & 1);      // ablation: bit 2 = no loads, bit 1 = no MFMAs
             if (!(a.prio & 2)) compute(kc & 1);
 #else
-            if (kc + 1 < nseg) load_chunk(s0, (kc + 1) & 1);
-            compute(kc & 1);
+            if constexpr (ILV) {
+                const bool more = kc + 1 < nseg;
+                if (more) prep_chunk((kc + 1) & 1);
+                compute(kc & 1, more);
+            } else {
+                if (kc + 1 < nseg) load_chunk(s0, (kc + 1) & 1);
+                compute(kc & 1);
+            }
 #endif
         }
         __syncthreads();
@@ -752,10 +800,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     constexpr int MSEG = BN / 64;                        // 16-byte segments per mask row
     static_assert(kMaskOff + BM * (BN / 4) <= kSmem, "mask tile must fit behind the C tile");
     const bool mask_lds = e_res && a.res_mask && (a.Cout % 64 == 0) && a.mask_lds;
-    if (mask_lds && tid < BM * MSEG) {
-        const int row = tid / MSEG, seg = tid - row * MSEG;
-        const u32x4 mv = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (unsigned)(row * (a.Cout / 4) + n0 / 4 + seg * 16), 0, 0);
-        *reinterpret_cast<uint4*>(smem + kMaskOff + row * (BN / 4) + seg * 16) = make_uint4(mv.x, mv.y, mv.z, mv.w);
+    if (mask_lds) {
+#pragma unroll
+        for (int it = tid; it < BM * MSEG; it += NT) {       // (one trip for the 128 x 128 / 128 x 64 tiles, two for 256 x 256)
+            const int row = it / MSEG, seg = it - row * MSEG;
+            const u32x4 mv = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (unsigned)(row * (a.Cout / 4) + n0 / 4 + seg * 16), 0, 0);
+            *reinterpret_cast<uint4*>(smem + kMaskOff + row * (BN / 4) + seg * 16) = make_uint4(mv.x, mv.y, mv.z, mv.w);
+        }
     }
     // ---- bf16 training epilogues (EPI 1 forward + BN statistics, 2 plain data gradient; written for 6 = data gradient + BN-backward sums too):
     // nothing is added to the accumulators before the store, so they are rounded to bf16 IN REGISTERS and the C tile is staged
@@ -1063,6 +1114,38 @@ __global__ __launch_bounds__(512) void conv_igemm_glds8_kernel(ConvArgs a) {
     conv_tile<ET, 4, 2, 1, 2, false, false, false, EPI, false, 2>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
+// 256 x 256 outputs per workgroup of 8 waves (4 x 2, 64 x 128 each), two 64 KB LDS-DMA buffers, one workgroup per CU: per SIMD 16 DMA
+// instructions feed 2048 cycles of MFMA work per chunk -- twice the ratio of the 128 x 128 and 256 x 128 tiles, which plateau on the DMA
+// issue path.  Only for launches whose tile count suits 256 single-workgroup slots (MVF_CONV_BIG2).
+template <typename ET, int EPI, bool ILV>
+__global__ __launch_bounds__(512) void conv_igemm_big2_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<ET, 4, 2, 2, 4, false, false, false, EPI, false, 2, false, ILV>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+template <typename ET, int EPI>
+int launch_big2(hipStream_t st, const ConvArgs& a0) {
+    ConvArgs a = a0;
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.Cout + 255) / 256;
+    constexpr int lds = kGldsLds<256, 256, 2>();
+    // experiment switch MVF_CONV_ILV=1: the next chunk's DMA pieces issued one behind each MFMA of the first k-step instead of in a block
+    // ahead of them.  Measured neutral on the K = 2304 launches and 6-8 % SLOWER on the K = 1024 ones (0.234 -> 0.25 ms): off.
+    static const int ilv = getenv("MVF_CONV_ILV") ? atoi(getenv("MVF_CONV_ILV")) : 0;
+    auto k0 = conv_igemm_big2_kernel<ET, EPI, false>;
+    auto k1 = conv_igemm_big2_kernel<ET, EPI, true>;
+    static bool attr = false;
+    if (!attr) {
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    if (ilv) hipLaunchKernelGGL(k1, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(k0, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+    return MVF_OK;
+}
+
 template <typename ET, int EPI>
 int launch_big(hipStream_t st, const ConvArgs& a0) {
     ConvArgs a = a0;
@@ -1198,6 +1281,9 @@ int g_glds1_f32_infer = 1;       // fp32: only the inference epilogues (bias + R
 int g_glds1_max = -1;            // single-buffer LDS-DMA kernel (4 workgroups per CU) up to this many K chunks: -1 = default policy
                                  // (bf16: 8), 0 = off (MVF_CONV_GLDS1)
 int g_big_min = 0;               // 256 x 128 LDS-DMA tile from this many K chunks on (MVF_CONV_BIG; 0 = off)
+int g_big2_min = 16;             // 256 x 256 LDS-DMA tile (bf16) from this many K chunks on, when the tile count suits it (MVF_CONV_BIG2; 0 = off).
+                                 // Measured on the R50 bf16 train step: layer3's K = 1024 pointwise launches -16...-19 %, its 3x3 convs -5...-7 %
+                                 // (conv family 9.59 -> 9.42 ms per step); from 8 chunks on the K = 512 launches lose (9.49)
 int g_glds_min = -1, g_glds_nb = 2;  // LDS-DMA variant: -1 = the measured default policy (see launch_conv), 0 = off, n = from n K chunks on;
                                      // with 1 or 2 LDS buffers (MVF_CONV_GLDS=min[,nb])
 
@@ -1214,6 +1300,8 @@ int sk_slots() {
         if (e && e[0] >= '0' && e[0] <= '9') g_glds1_max = atoi(e);
         e = getenv("MVF_CONV_BIG");
         if (e && e[0] >= '0' && e[0] <= '9') g_big_min = atoi(e);
+        e = getenv("MVF_CONV_BIG2");
+        if (e && e[0] >= '0' && e[0] <= '9') g_big2_min = atoi(e);
         e = getenv("MVF_CONV_GLDS");
         if (e && ((e[0] >= '0' && e[0] <= '9') || e[0] == '-')) {
             g_glds_min = atoi(e);
@@ -1320,6 +1408,25 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
         const bool bnsum_epi = (epi_spec & 1) && a.bn_z && !a.bias && !a.relu && !a.res;      // contiguous or a scattered parity class
         // long K, wide output: the 256 x 128 LDS-DMA tile (MVF_CONV_BIG = <min chunks>, 0 = off)
+        if (BN == 128 && sizeof(ET) == 2 && g_big2_min > 0 && a.nchunks >= g_big2_min && a.Cout % 256 == 0 && a.o_s <= 0) {
+            const long t2 = (long)((a.M + 255) / 256) * (a.Cout / 256);
+            const int cus = slots / 2;
+            const long rounds = (t2 + cus - 1) / cus;
+            static const bool force2 = getenv("MVF_CONV_BIG2_FORCE") != nullptr;      // tests: every eligible shape, whatever its tile count
+            if (force2 || (t2 >= cus / 2 && (double)t2 / (double)(rounds * cus) >= 0.75)) {       // the last round at least 3/4 full
+                int rc;
+                if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_big2<ET, 1>(st, a);
+                else if (bnsum_epi) rc = launch_big2<ET, 6>(st, a);
+                else if (train_like && !a.stats_part && !a.res) rc = launch_big2<ET, 2>(st, a);
+                else if (train_like && !a.stats_part && a.res) rc = launch_big2<ET, 3>(st, a);
+                else if (infer_like && !a.res) rc = launch_big2<ET, 4>(st, a);
+                else if (infer_like && a.res) rc = launch_big2<ET, 5>(st, a);
+                else rc = launch_big2<ET, 0>(st, a);
+                if (rc != MVF_OK) return rc;
+                MVF_LAUNCH_CHECK();
+                return MVF_OK;
+            }
+        }
         if (BN == 128 && g_big_min > 0 && a.nchunks >= g_big_min && a.Cout >= 128 && a.M >= 256) {
             int rc;
             if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_big<ET, 1>(st, a);

@@ -175,17 +175,19 @@ def test_conv_streamk_tail_matches_plain_launch_and_oracle(case, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["MVF_CONV_GLDS=0", "MVF_CONV_GLDS=1,1", "MVF_CONV_GLDS=1,2", "MVF_CONV_BIG=1"],
-                         ids=["register_staged_only", "lds_dma_1buf_everywhere", "lds_dma_2buf_everywhere", "tile_256x128_everywhere"])
+@pytest.mark.parametrize("env", ["MVF_CONV_GLDS=0", "MVF_CONV_GLDS=1,1", "MVF_CONV_GLDS=1,2", "MVF_CONV_BIG=1", "MVF_CONV_BIG2=1,MVF_CONV_BIG2_FORCE=1"],
+                         ids=["register_staged_only", "lds_dma_1buf_everywhere", "lds_dma_2buf_everywhere", "tile_256x128_everywhere",
+                              "tile_256x256_everywhere"])
 def test_conv_kernel_variants_forced_by_env(env):
     """The loader variant is a per-process policy (environment, read once), so each forced policy re-runs this file's oracle
     comparisons in a child process: register staging only, the LDS-DMA loop with one and two buffers for EVERY launch (the
-    default policy uses it from 32 K chunks on), and the 8-wave 256 x 128 LDS-DMA tile for every Cout >= 128 launch."""
+    default policy uses it from 32 K chunks on), the 8-wave 256 x 128 LDS-DMA tile for every Cout >= 128 launch and the 8-wave
+    256 x 256 tile (default policy: bf16, >= 16 chunks, tile counts that fill the 256 single-workgroup slots) for every bf16
+    Cout % 256 == 0 launch whatever its size."""
     import os
     import subprocess
     import sys
-    k, v = env.split("=")
-    child_env = dict(os.environ, **{k: v})
+    child_env = dict(os.environ, **dict(kv.split("=") for kv in env.split(",MVF")[:1] + ["MVF" + x for x in env.split(",MVF")[1:]]))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not forced_by_env",
                         "-p", "no:cacheprovider"], env=child_env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
