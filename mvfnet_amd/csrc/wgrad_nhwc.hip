@@ -216,8 +216,8 @@ typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 // XOR swizzle of the 16-byte units of an LDS row with U units (U = 16: 256-B rows, U = 8: 128-B rows), see wgrad_bf16_kernel
 template <int U>
 __device__ __forceinline__ int swz16(int row) {
-    static_assert(U == 8 || U == 16, "64- or 128-channel tile rows");
-    return U == 16 ? (row & 3) << 2 : ((row >> 1) & 1) << 2;
+    static_assert(U == 8 || U == 16 || U == 32, "64-, 128- or 256-channel tile rows");
+    return U >= 16 ? (row & 3) << 2 : ((row >> 1) & 1) << 2;          // (U = 32: 512-B rows, the XOR stays inside a 256-B bank row)
 }
 constexpr int BMR16 = 64;                            // pixels per chunk = 4 MFMA k-steps
 
@@ -226,9 +226,12 @@ constexpr int BMR16 = 64;                            // pixels per chunk = 4 MFM
 // position q of row r fetches unit q ^ swz16(r) (constant per thread: every pass advances the row by a multiple of 4).  Padding /
 // out-of-range taps, rows past the split and channel tails are out-of-range buffer offsets = DMA'd zeros.  Not for the MVF
 // split operand (two source tensors inside one wave instruction).
-template <int TM, int TN, bool DMA = false>
-__global__ __launch_bounds__(kThreads) void wgrad_bf16_kernel(WgArgs a) {
-    constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
+// WMG = wave rows (2: four waves, 4: eight waves = the 256 x 256 tile with TM = 2, TN = 4: half the L2 -> LDS bytes per flop of the
+// 128 x 128 tile, one workgroup per CU)
+template <int TM, int TN, bool DMA = false, int WMG = 2>
+__global__ __launch_bounds__(WMG * 128) void wgrad_bf16_kernel(WgArgs a) {
+    constexpr int kThreads = WMG * 128;
+    constexpr int BCO = WMG * TM * 32, BK = 2 * TN * 32;
     // LDS images stay in the natural [pixel][channel] layout (16-byte coalesced staging writes, no padding); the MFMA
     // operands (8 consecutive PIXELS of one channel per lane) come out of it with the gfx950 transpose read
     // ds_read_b64_tr_b16: every 16-lane group hands in a [4 pixel][16 channel] block (lane i: pixel i>>2, channels
@@ -480,6 +483,19 @@ int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
     return MVF_OK;
 }
 
+int launch_wgrad_bf16_big(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * BMR16 * (256 * 2 + 256 * 2);
+    auto kd = wgrad_bf16_kernel<2, 4, true, 4>;
+    static bool attr_d = false;
+    if (!attr_d) {
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_d = true;
+    }
+    hipLaunchKernelGGL(kd, dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(512), lds, st, a);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
 // dW_oihw[co][ci][kh][kw] = sum_s part[s][co][(kh*KWP + kw)*CINP + ci]   (KWP/CINP = packed extents; stem: 8 / 4)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
                                     float* dw) {
@@ -597,8 +613,9 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const mvf_pack_job_t*
     }
 }
 
-int plan_split(int M, int tiles) {
-    static const int target = getenv("MVF_WGRAD_WGS") ? std::max(64, atoi(getenv("MVF_WGRAD_WGS"))) : 1024;     // workgroups aimed at per launch (A/B switch)
+int plan_split(int M, int tiles, int target_override = 0) {
+    static const int target_env = getenv("MVF_WGRAD_WGS") ? std::max(64, atoi(getenv("MVF_WGRAD_WGS"))) : 1024;     // workgroups aimed at per launch (A/B switch)
+    const int target = target_override > 0 ? target_override : target_env;
     int want = std::max(1, target / std::max(tiles, 1));
     int rows = std::max((M + want - 1) / want, 256);
     rows = (rows + 63) / 64 * 64;          // multiple of both chunk heights (32 fp32 / 64 bf16)
@@ -616,13 +633,34 @@ WgTile pick_tile(int cout, int K) {
 
 extern "C" {
 
+// the 256 x 256 eight-wave tile (bf16, LDS-DMA): shape eligibility (pointer alignment is checked at launch) and its pixel split --
+// ~256 workgroups (one per CU), i.e. the same number of splits as the 128 x 128 plan's ~1024
+static bool wg_big_shape(const mvf_conv_desc_t* d) {
+    // MVF_WGRAD_BIG: 0 never, 1 (default) every eligible shape, 2 pointwise convs only, 3 pointwise convs with cout >= 512.
+    // Measured on the R50 bf16 train step, two alternations: weight gradients ALONE 5.23 (0) / 5.17 (1) / 5.13 (2) / 5.13 (3) ms -- the
+    // tile wins -10...-18 % on the wide pointwise layers and loses 5-10 % on the 3x3 ones --, but the STEP is 22.24 / 22.16 / 22.37 /
+    // 22.39 ms: one 8-wave workgroup per CU (252 of them for a 3x3 layer) leaves the launch stream's kernels more of the chip than
+    // 1008 four-wave workgroups do.
+    static const int big_env = getenv("MVF_WGRAD_BIG") ? atoi(getenv("MVF_WGRAD_BIG")) : 1;
+    const long K = (long)d->kh * d->kw * d->cin;
+    if (big_env >= 2 && (d->kh != 1 || d->kw != 1)) return false;
+    if (big_env >= 3 && d->cout < 512) return false;
+    return big_env && d->dtype == MVF_BF16 && d->cout % 256 == 0 && K % 256 == 0 && d->cin % 8 == 0 && d->x_pix_stride % 4 == 0 &&
+           (d->split_c == 0 || (d->split_c % 256 == 0 && d->cin % 256 == 0));
+}
+static int wg_big_rows(const mvf_conv_desc_t* d) {
+    const int M = d->n * d->ho * d->wo, K = d->kh * d->kw * d->cin;
+    return plan_split(M, (d->cout / 256) * (K / 256), 256);
+}
+
 size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
     if (!d || d->cout <= 0 || d->cin <= 0) return 0;
     const int M = d->n * d->ho * d->wo, K = d->kh * d->kw * d->cin;
     const WgTile t = pick_tile(d->cout, K);
     const int tiles = ((d->cout + t.bco - 1) / t.bco) * ((K + t.bk - 1) / t.bk);
     const int rows = plan_split(M, tiles);
-    const int nsplit = (M + rows - 1) / rows;
+    int nsplit = (M + rows - 1) / rows;
+    if (wg_big_shape(d)) nsplit = std::max(nsplit, (M + wg_big_rows(d) - 1) / wg_big_rows(d));
     return align_up((size_t)nsplit * d->cout * K * sizeof(float), 256);
 }
 
@@ -642,10 +680,18 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->ho; a.Wo = d->wo; a.xps = d->x_pix_stride;
     a.split_c = d->split_c; a.x2ps = d->x2_pix_stride;
     a.M = d->n * d->ho * d->wo; a.K = d->kh * d->kw * d->cin;
-    const WgTile t = pick_tile(d->cout, a.K);
+    WgTile t = pick_tile(d->cout, a.K);
+    // 256 x 256 tile: the shapes of wg_big_shape() when the LDS-DMA address ranges and alignments hold and every split has >= 4 chunks
+    bool big = wg_big_shape(d) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
+               (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 2 < 0x7ffffff0L;
+    if (big) {
+        const int rows = wg_big_rows(d);
+        big = rows >= 4 * 64 && ((long)rows + 6 * 64) * d->cout * 2 < 0x7ffffff0L;
+        if (big) t = WgTile{256, 256};
+    }
     a.tiles_k = (a.K + t.bk - 1) / t.bk;
     const int tiles = ((d->cout + t.bco - 1) / t.bco) * a.tiles_k;
-    a.rows_per_split = plan_split(a.M, tiles);
+    a.rows_per_split = big ? wg_big_rows(d) : plan_split(a.M, tiles);
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
     a.tiles = tiles;
     a.nsplit = nsplit;
@@ -671,7 +717,8 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
                ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
                ((long)a.rows_per_split + 6 * 64) * d->cout * 2 < 0x7ffffff0L) {      // 32-bit split-relative dz offsets (incl. look-ahead chunks)
         int rc;
-        if (t.bco == 64) rc = launch_wgrad_bf16<1, 2>(a, tiles, nsplit, st);
+        if (big) rc = launch_wgrad_bf16_big(a, tiles, nsplit, st);
+        else if (t.bco == 64) rc = launch_wgrad_bf16<1, 2>(a, tiles, nsplit, st);
         else if (t.bk == 64) rc = launch_wgrad_bf16<2, 1>(a, tiles, nsplit, st);
         else rc = launch_wgrad_bf16<2, 2>(a, tiles, nsplit, st);
         if (rc) return rc;

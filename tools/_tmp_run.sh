@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-echo "== forced big2 (ILV default 1): conv + train tests"; MVF_CONV_BIG2=1 MVF_CONV_BIG2_FORCE=1 python -m pytest tests/test_conv_gpu.py tests/test_train_gpu.py -m gpu -q -x -k "not forced_by_env" 2>&1 | grep -n "passed\|failed\|^E  " | head
-for v in 0 1 0 1; do echo "== MVF_CONV_ILV=$v"; MVF_CONV_ILV=$v python bench.py --no-cpu-baseline --steps 20 --warmup 3 --per-layer 2>/tmp/pl.txt | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(d['value'], d['ms_per_step'], 'conv', r['ms_per_step'])"; grep "M50176 N256 K2304\|M50176 N256 K1024" /tmp/pl.txt | grep igemm; done
+for v in 0 1 2 3 0 1 2 3; do echo "== MVF_WGRAD_BIG=$v"; MVF_WGRAD_BIG=$v python bench.py --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(d['value'], d['ms_per_step'], 'wgrad', r['wgrad']['ms_per_step'])"; done
