@@ -230,6 +230,14 @@ int mvf_bn_apply_bits(const void* z, long m, int c, const float* scale, const fl
 int mvf_bn_bwd_apply_masked(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* gamma,
                             const float* mean, const float* invstd, const float* scale, const float* shift,
                             const float* dgamma, const float* dbeta, int mask_mode, void* dz, int dtype, void* stream);
+/* PAIRED backward of the two BatchNorms of a downsample block, out = relu(bn3(z3) + bnd(zd)) (Bottleneck.forward, resnet.py:227-233): both
+ * receive the same masked gradient g * [out > 0] (sign_bits as written by mvf_bn_apply_bits), so g and the bits are read once for
+ * both: dgamma / dbeta of a and b, then dz_a, dz_b.  Results are bit-identical to two mvf_bn_bwd_reduce + mvf_bn_bwd_apply_masked
+ * (mask_mode 4) calls.  ws: 2 x mvf_bn_workspace_bytes(m, c). */
+int mvf_bn_bwd_pair(const void* g, int g_pitch, const void* z_a, const void* z_b, const unsigned char* sign_bits, long m, int c,
+                    const float* gamma_a, const float* mean_a, const float* invstd_a, float* dgamma_a, float* dbeta_a,
+                    const float* gamma_b, const float* mean_b, const float* invstd_b, float* dgamma_b, float* dbeta_b,
+                    void* dz_a, void* dz_b, void* ws, size_t ws_bytes, int dtype, void* stream);
 /* stem: y = maxpool3x3/2(relu(z*scale+shift)) (resnet.py:482-484).  argmax (optional, one byte per element of y) receives
  * the window position dy*3+dx of the first maximum; the backward routes g to it: ga = dL/d relu(bn(z)). */
 int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,

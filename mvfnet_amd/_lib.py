@@ -122,6 +122,8 @@ def _load():
     lib.mvf_head_train_fwd.argtypes = [vp, i32, i32, i32, i32, fp, fp, i32, ll, fp, fp, fp, fp, fp, fp, i32, vp]
     lib.mvf_conv2d_nhwc_fwd_mvf.restype = i32
     lib.mvf_conv2d_nhwc_fwd_mvf.argtypes = [cp, vp, vp, fp, fp, i32, i32, i32, vp, vp, sz, vp]
+    lib.mvf_bn_bwd_pair.restype = i32
+    lib.mvf_bn_bwd_pair.argtypes = [vp, i32, vp, vp, vp, i64, i32, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp, vp, vp, sz, i32, vp]
     lib.mvf_ce_loss.restype = i32
     lib.mvf_ce_loss.argtypes = [fp, ll, i32, i32, fp, fp, fp, vp]
     lib.mvf_head_train_bwd.restype = i32

@@ -438,6 +438,171 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const ET* g, int
     }
 }
 
+// ---- PAIRED BatchNorm backward for a block with a downsample branch: out = relu(bn3(z3) + bnd(zd)), so both BatchNorms receive the
+// ---- SAME masked gradient gm = g * [out > 0] (mask = the sign bits bn_apply wrote).  One kernel reads g and the bits once for both:
+// ---- the two separate backward passes move 2 x (g + z + bits [+ dz]) = 10 tensor passes, the pair 8.  Same column plan, same row
+// ---- order and the same per-BatchNorm arithmetic as bn_bwd_reduce_kernel<.., 4> / bn_bwd_apply_kernel<.., 4>: bit-identical results.
+template <typename ET, int VN>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce2_kernel(const ET* g, int g_pitch, const ET* za, const ET* zb, const void* bits, long M, int C,
+                                                                  const float* mean_a, const float* invstd_a, const float* mean_b, const float* invstd_b,
+                                                                  int cqb, int rows, float* part_a, float* part_b) {
+    __shared__ float red[2 * VN * kThreads];
+    const int rl = kThreads / cqb;
+    const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
+    const bool ok = cq * VN < C;
+    const int c = cq * VN;
+    float mua[VN], rsa[VN], mub[VN], rsb[VN], a1[VN], a2[VN], b1[VN], b2[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) mua[j] = rsa[j] = mub[j] = rsb[j] = a1[j] = a2[j] = b1[j] = b2[j] = 0.f;
+    if (ok) {
+        ldp<VN>(mean_a, c, mua); ldp<VN>(invstd_a, c, rsa);
+        ldp<VN>(mean_b, c, mub); ldp<VN>(invstd_b, c, rsb);
+    }
+    const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
+    if (ok) {
+        auto body = [&](float (&gv)[VN], const float (&zav)[VN], const float (&zbv)[VN], unsigned mb) {
+            bn_mask<ET, VN>(gv, zav, zav, mua, mua, 4, mb);
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                a1[j] += gv[j];
+                a2[j] += gv[j] * ((zav[j] - mua[j]) * rsa[j]);
+                b1[j] += gv[j];
+                b2[j] += gv[j] * ((zbv[j] - mub[j]) * rsb[j]);
+            }
+        };
+        long r = r0 + lane_r;
+        for (; r + rl < r1; r += 2 * rl) {
+            float g0[VN], g1[VN], x0[VN], x1[VN], y0[VN], y1[VN];
+            ldv<ET, VN>(g + r * g_pitch + c, g0); ldv<ET, VN>(g + (r + rl) * g_pitch + c, g1);
+            ldv<ET, VN>(za + r * C + c, x0); ldv<ET, VN>(za + (r + rl) * C + c, x1);
+            ldv<ET, VN>(zb + r * C + c, y0); ldv<ET, VN>(zb + (r + rl) * C + c, y1);
+            const unsigned m0 = ld_maskbits<VN>(bits, r, C, c), m1 = ld_maskbits<VN>(bits, r + rl, C, c);
+            body(g0, x0, y0, m0);
+            body(g1, x1, y1, m1);
+        }
+        for (; r < r1; r += rl) {
+            float g0[VN], x0[VN], y0[VN];
+            ldv<ET, VN>(g + r * g_pitch + c, g0);
+            ldv<ET, VN>(za + r * C + c, x0);
+            ldv<ET, VN>(zb + r * C + c, y0);
+            body(g0, x0, y0, ld_maskbits<VN>(bits, r, C, c));
+        }
+    }
+    rowlane_reduce<VN>(a1, a2, cqb, rl, red);
+    if (ok && lane_r == 0) {
+        float* p = part_a + ((long)blockIdx.y * C + c) * 2;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { p[2 * j] = a1[j]; p[2 * j + 1] = a2[j]; }
+    }
+    __syncthreads();
+    rowlane_reduce<VN>(b1, b2, cqb, rl, red);
+    if (ok && lane_r == 0) {
+        float* p = part_b + ((long)blockIdx.y * C + c) * 2;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { p[2 * j] = b1[j]; p[2 * j + 1] = b2[j]; }
+    }
+}
+
+// both BatchNorms' partials in one launch: workgroups [0, gA) finalize a, [gA, 2 gA) finalize b
+__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(int C, int nblk, const float* part_a, const float* part_b, float* dgamma_a, float* dbeta_a,
+                                                               float* dgamma_b, float* dbeta_b) {
+    const int gA = (C + kFinCh - 1) / kFinCh;
+    const bool second = (int)blockIdx.x >= gA;
+    int c;
+    double s1, s2;
+    // reduce_partials() derives the channel from blockIdx.x: re-base it for the second BatchNorm
+    constexpr int CH = kFinCh, LN = 256 / kFinCh, U = 8;
+    __shared__ double sh[2][LN][CH];
+    const float* part = second ? part_b : part_a;
+    const int cl = threadIdx.x % CH, bl = threadIdx.x / CH;
+    c = ((int)blockIdx.x - (second ? gA : 0)) * CH + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        double aa[U], bb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) aa[u] = bb[u] = 0.0;
+        int k = bl;
+        for (; k + (U - 1) * LN < nblk; k += U * LN) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float2*>(part + ((long)(k + u * LN) * C + c) * 2);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { aa[u] += v[u].x; bb[u] += v[u].y; }
+        }
+        for (; k < nblk; k += LN) {
+            const float2 v = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
+            aa[0] += v.x;
+            bb[0] += v.y;
+        }
+        a = ((aa[0] + aa[1]) + (aa[2] + aa[3])) + ((aa[4] + aa[5]) + (aa[6] + aa[7]));
+        b = ((bb[0] + bb[1]) + (bb[2] + bb[3])) + ((bb[4] + bb[5]) + (bb[6] + bb[7]));
+    }
+    sh[0][bl][cl] = a;
+    sh[1][bl][cl] = b;
+    __syncthreads();
+    if (bl != 0 || c >= C) return;
+    s1 = s2 = 0.0;
+    for (int k = 0; k < LN; ++k) {
+        s1 += sh[0][k][cl];
+        s2 += sh[1][k][cl];
+    }
+    (second ? dbeta_b : dbeta_a)[c] = (float)s1;
+    (second ? dgamma_b : dgamma_a)[c] = (float)s2;
+}
+
+template <typename ET, int VN>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply2_kernel(const ET* g, int g_pitch, const ET* za, const ET* zb, const void* bits, long M, int C,
+                                                                 const float* gamma_a, const float* mean_a, const float* invstd_a, const float* dgamma_a, const float* dbeta_a,
+                                                                 const float* gamma_b, const float* mean_b, const float* invstd_b, const float* dgamma_b, const float* dbeta_b,
+                                                                 ET* dza, ET* dzb, int cqb, int rows) {
+    const int rl = kThreads / cqb;
+    const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
+    if (cq * VN >= C) return;
+    const int c = cq * VN;
+    const float inv_m = 1.0f / (float)M;
+    float aa[VN], da[VN], ka[VN], mua[VN], ab[VN], db_[VN], kb[VN], mub[VN];
+    {
+        float ga[VN], rs[VN], dg[VN], db[VN];
+        ldp<VN>(gamma_a, c, ga); ldp<VN>(invstd_a, c, rs); ldp<VN>(dgamma_a, c, dg); ldp<VN>(dbeta_a, c, db); ldp<VN>(mean_a, c, mua);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { aa[j] = ga[j] * rs[j]; da[j] = db[j] * inv_m; ka[j] = rs[j] * dg[j] * inv_m; }
+        ldp<VN>(gamma_b, c, ga); ldp<VN>(invstd_b, c, rs); ldp<VN>(dgamma_b, c, dg); ldp<VN>(dbeta_b, c, db); ldp<VN>(mean_b, c, mub);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { ab[j] = ga[j] * rs[j]; db_[j] = db[j] * inv_m; kb[j] = rs[j] * dg[j] * inv_m; }
+    }
+    const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
+    auto one = [&](long row, float (&gv)[VN], const float (&zav)[VN], const float (&zbv)[VN]) {
+        bn_mask<ET, VN>(gv, zav, zav, mua, mua, 4, ld_maskbits<VN>(bits, row, C, c));
+        float oa[VN], ob[VN];
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            oa[j] = aa[j] * (gv[j] - da[j] - (zav[j] - mua[j]) * ka[j]);
+            ob[j] = ab[j] * (gv[j] - db_[j] - (zbv[j] - mub[j]) * kb[j]);
+        }
+        stv<ET, VN>(dza + row * C + c, oa);
+        stv<ET, VN>(dzb + row * C + c, ob);
+    };
+    long row = r0 + lane_r;
+    for (; row + rl < r1; row += 2 * rl) {
+        float g0[VN], g1[VN], x0[VN], x1[VN], y0[VN], y1[VN];
+        ldv<ET, VN>(g + row * g_pitch + c, g0);
+        ldv<ET, VN>(g + (row + rl) * g_pitch + c, g1);
+        ldv<ET, VN>(za + row * C + c, x0);
+        ldv<ET, VN>(za + (row + rl) * C + c, x1);
+        ldv<ET, VN>(zb + row * C + c, y0);
+        ldv<ET, VN>(zb + (row + rl) * C + c, y1);
+        one(row, g0, x0, y0);
+        one(row + rl, g1, x1, y1);
+    }
+    for (; row < r1; row += rl) {
+        float g0[VN], x0[VN], y0[VN];
+        ldv<ET, VN>(g + row * g_pitch + c, g0);
+        ldv<ET, VN>(za + row * C + c, x0);
+        ldv<ET, VN>(zb + row * C + c, y0);
+        one(row, g0, x0, y0);
+    }
+}
+
 // ---- max-pool 3x3/2 pad 1 over relu(bn(z)) (stem), forward and backward (argmax recomputed: first max in scan order) ----
 template <typename ET>
 __global__ void maxpool_bn_fwd_kernel(const ET* z, int n, int h, int w, int c, int ho, int wo, const float* scale,
@@ -939,6 +1104,33 @@ int mvf_bn_bwd_apply(const void* g, int g_pitch, const void* z, long m, int c, c
                      int dtype, void* stream) {
     MVF_REQUIRE(mask_mode == 0 || mask_mode == 2 || mask_mode == 3, MVF_EINVAL, "bn_bwd_apply: mask_mode must be 0, 2 or 3 (use mvf_bn_bwd_apply_masked)");
     return mvf_bn_bwd_apply_masked(g, g_pitch, z, nullptr, m, c, gamma, mean, invstd, scale, shift, dgamma, dbeta, mask_mode, dz, dtype, stream);
+}
+
+int mvf_bn_bwd_pair(const void* g, int g_pitch, const void* z_a, const void* z_b, const unsigned char* sign_bits, long m, int c,
+                    const float* gamma_a, const float* mean_a, const float* invstd_a, float* dgamma_a, float* dbeta_a,
+                    const float* gamma_b, const float* mean_b, const float* invstd_b, float* dgamma_b, float* dbeta_b,
+                    void* dz_a, void* dz_b, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    MVF_REQUIRE(g && z_a && z_b && sign_bits && gamma_a && mean_a && invstd_a && dgamma_a && dbeta_a && gamma_b && mean_b && invstd_b && dgamma_b && dbeta_b &&
+                    dz_a && dz_b && m > 0 && c > 0 && c % 4 == 0 && g_pitch >= c && g_pitch % 4 == 0, MVF_EINVAL, "bn_bwd_pair: bad argument");
+    MVF_REQUIRE(ws && ws_bytes >= 2 * mvf_bn_workspace_bytes(m, c), MVF_EWS, "bn_bwd_pair: workspace too small (2 x mvf_bn_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    float* part_a = (float*)ws;
+    float* part_b = (float*)((char*)ws + mvf_bn_workspace_bytes(m, c));
+    {   // reductions: the 8-byte-lane plan of mvf_bn_bwd_reduce (wide = false there)
+        const bool wide = false;
+        const int gy = col_plan(m, c, 4).gy;
+        MVF_BN_DISPATCH(bn_bwd_reduce2_kernel, wide, 2048, (const ET*)g, g_pitch, (const ET*)z_a, (const ET*)z_b, (const void*)sign_bits, m, c, mean_a, invstd_a,
+                        mean_b, invstd_b, p.cqb, p.rows, part_a, part_b);
+        MVF_LAUNCH_CHECK();
+        const int gA = (c + kFinCh - 1) / kFinCh;
+        hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(2 * gA), dim3(256), 0, st, c, gy, part_a, part_b, dgamma_a, dbeta_a, dgamma_b, dbeta_b);
+        MVF_LAUNCH_CHECK();
+    }
+    const bool wide = c % 8 == 0 && g_pitch % 8 == 0 && al16(g) && al16(z_a) && al16(z_b) && al16(dz_a) && al16(dz_b) && ((uintptr_t)sign_bits & 1) == 0;
+    MVF_BN_DISPATCH(bn_bwd_apply2_kernel, wide, 4096, (const ET*)g, g_pitch, (const ET*)z_a, (const ET*)z_b, (const void*)sign_bits, m, c, gamma_a, mean_a, invstd_a,
+                    dgamma_a, dbeta_a, gamma_b, mean_b, invstd_b, dgamma_b, dbeta_b, (ET*)dz_a, (ET*)dz_b, p.cqb, p.rows);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
 }
 
 int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,

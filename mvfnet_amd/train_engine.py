@@ -142,6 +142,18 @@ class _BN(object):
             self._reduce(g, g_pitch, z, m, eng, mask_mode, ymask, gm_out)
         return self._apply_bwd(g, g_pitch, z, m, eng, mask_mode, ymask, gm_out)
 
+    @staticmethod
+    def backward_pair(a, b, g, g_pitch, za, zb, m, eng, bits):
+        """Backward of both BatchNorms of a downsample block, out = relu(a(za) + b(zb)): the shared g and sign bits are read once
+        (mvf_bn_bwd_pair).  Returns (dza, dzb); results equal a.backward(...), b.backward(...) bit for bit."""
+        nb = lib.mvf_bn_workspace_bytes(m, a.c)
+        ws = eng.workspace(2 * nb)
+        dza, dzb = eng.buf((id(a), "dz"), za.shape, za.dtype), eng.buf((id(b), "dz"), zb.shape, zb.dtype)
+        check(lib.mvf_bn_bwd_pair(_p(g), g_pitch, _p(za), _p(zb), _p(bits), m, a.c, _p(a.gamma), _p(a.mean), _p(a.invstd), _p(a.dgamma), _p(a.dbeta),
+                                  _p(b.gamma), _p(b.mean), _p(b.invstd), _p(b.dgamma), _p(b.dbeta), _p(dza), _p(dzb), _p(ws), ws.numel(), eng.dt, _st()),
+              "mvf_bn_bwd_pair")
+        return dza, dzb
+
     def _reduce(self, g, g_pitch, z, m, eng, mask_mode, ymask, gm_out):
         ws = eng.workspace(lib.mvf_bn_workspace_bytes(m, self.c))
         check(lib.mvf_bn_bwd_reduce(_p(g), g_pitch, _p(z), _p(ymask), m, self.c, _p(self.mean), _p(self.invstd), _p(self.scale),
@@ -421,7 +433,11 @@ class _TBlock(object):
         # data-gradient GEMM that shares its dz has been queued on the main stream, so it starts when the main stream
         # moves on to the (HBM-bound) BatchNorm-backward kernels of the next layer -- MFMA work under memory work --
         # instead of fighting the data-gradient GEMM for the matrix cores.
-        dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 4, ymask=bits)
+        dzd = None
+        if self.cd is not None and eng.pair_bn_bwd and not (self.b3.frozen or self.bd.frozen):
+            dz3, dzd = _BN.backward_pair(self.b3, self.bd, g, self.c3.cout, s["z3"], s["zd"], m2, eng, bits)
+        else:
+            dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 4, ymask=bits)
         fuse = eng.fuse_bn_bwd_sums
         if fuse:       # the data gradient's epilogue also produces the BatchNorm-backward sums of the BN its output feeds
             da2 = self.c3.dgrad_bnsums(dz3, nt, ho, wo, ho, wo, self.b2, s["z2"])
@@ -444,7 +460,8 @@ class _TBlock(object):
         del da1
         resid, rbits = g, bits
         if self.cd is not None:
-            dzd = self.bd.backward(g, self.cd.cout, s["zd"], m2, eng, 4, ymask=bits)
+            if dzd is None:
+                dzd = self.bd.backward(g, self.cd.cout, s["zd"], m2, eng, 4, ymask=bits)
             resid, rbits = self.cd.dgrad(dzd, nt, ho, wo, h, w), None
             self.cd.wgrad(dzd, s["x"], nt, h, w, ho, wo, eng, x_pitch=c)
             del dzd
@@ -544,6 +561,7 @@ class _ParamStore(object):
     keep_io = False            # keep references to every block's input / output / gradients after backward (teacher-forced parity tests)
     fuse_stats = True          # BatchNorm batch statistics accumulated in the producing conv's epilogue
     fuse_bn_bwd_sums = os.environ.get("MVF_FUSE_BN_BWD", "1") != "0"    # ... and the backward sums in the data gradient's
+    pair_bn_bwd = os.environ.get("MVF_PAIR_BN_BWD", "1") != "0"         # downsample blocks: bn3 + downsample-BN backward in one pass over g
     fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes
 
     def side_stream(self):

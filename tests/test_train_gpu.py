@@ -24,6 +24,59 @@ def nhwc(t):
 
 
 # ------------------------------------------------------------------------------------------------ primitives
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("mc", [(8 * 28 * 28, 512), (1000, 256), (37, 12), (16 * 56 * 56, 256), (301, 2048)], ids=str)
+def test_bn_bwd_pair_equals_two_separate_backwards(mc, dtype):
+    """Downsample block, out = relu(bn3(z3) + bnd(zd)) (reference resnet.py:227-233): the paired backward reads g and the sign
+    bits once for both BatchNorms and must reproduce the two separate passes bit for bit (and, in fp32, torch autograd)."""
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    m, c = mc
+    dt = 0 if dtype == torch.float32 else 1
+    gen = torch.Generator().manual_seed(m + c)
+    za, zb = torch.randn(m, c, generator=gen) * 1.5 + 0.3, torch.randn(m, c, generator=gen) * 0.7 - 0.2
+    ga, ba, gb, bb = (torch.rand(c, generator=gen) + 0.5 for _ in range(4))
+    g = torch.randn(m, c, generator=gen)
+    dev = "cuda"
+    zag, zbg, gg = za.to(dev, dtype), zb.to(dev, dtype), g.to(dev, dtype)
+    ws = torch.empty(2 * lib.mvf_bn_workspace_bytes(m, c), dtype=torch.uint8, device=dev)
+    st = {}
+    for k, z, gam, bet in (("a", zag, ga, ba), ("b", zbg, gb, bb)):
+        d = dict(gamma=gam.to(dev), beta=bet.to(dev), rm=torch.zeros(c, device=dev), rv=torch.ones(c, device=dev))
+        for n in ("mean", "invstd", "scale", "shift"):
+            d[n] = torch.empty(c, device=dev)
+        check(lib.mvf_bn_train_stats(P(z), m, c, P(d["gamma"]), P(d["beta"]), C.c_float(1e-5), C.c_float(0.1), P(d["rm"]), P(d["rv"]), P(d["mean"]), P(d["invstd"]),
+                                     P(d["scale"]), P(d["shift"]), P(ws), ws.numel(), dt, None))
+        st[k] = d
+    out, bits = torch.empty_like(zag), torch.empty(m, c // 4, dtype=torch.uint8, device=dev)
+    check(lib.mvf_bn_apply_bits(P(zag), m, c, P(st["a"]["scale"]), P(st["a"]["shift"]), P(zbg), P(st["b"]["scale"]), P(st["b"]["shift"]), 1, P(out), P(bits), dt, None))
+    sep = {}
+    for k, z in (("a", zag), ("b", zbg)):
+        d = st[k]
+        dg, db, dz = torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty_like(z)
+        check(lib.mvf_bn_bwd_reduce(P(gg), c, P(z), P(bits), m, c, P(d["mean"]), P(d["invstd"]), P(d["scale"]), P(d["shift"]), 4, None, P(dg), P(db), P(ws), ws.numel(), dt, None))
+        check(lib.mvf_bn_bwd_apply_masked(P(gg), c, P(z), P(bits), m, c, P(d["gamma"]), P(d["mean"]), P(d["invstd"]), P(d["scale"]), P(d["shift"]), P(dg), P(db), 4, P(dz), dt, None))
+        sep[k] = (dg, db, dz)
+    pa = [torch.empty(c, device=dev) for _ in range(4)]
+    dza, dzb = torch.full_like(zag, 7.0), torch.full_like(zbg, 7.0)
+    a, b = st["a"], st["b"]
+    check(lib.mvf_bn_bwd_pair(P(gg), c, P(zag), P(zbg), P(bits), m, c, P(a["gamma"]), P(a["mean"]), P(a["invstd"]), P(pa[0]), P(pa[1]),
+                              P(b["gamma"]), P(b["mean"]), P(b["invstd"]), P(pa[2]), P(pa[3]), P(dza), P(dzb), P(ws), ws.numel(), dt, None))
+    torch.cuda.synchronize()
+    assert torch.equal(pa[0], sep["a"][0]) and torch.equal(pa[1], sep["a"][1]) and torch.equal(pa[2], sep["b"][0]) and torch.equal(pa[3], sep["b"][1])
+    assert torch.equal(dza, sep["a"][2]) and torch.equal(dzb, sep["b"][2])
+    small = lib.mvf_bn_bwd_pair(P(gg), c, P(zag), P(zbg), P(bits), m, c, P(a["gamma"]), P(a["mean"]), P(a["invstd"]), P(pa[0]), P(pa[1]),
+                                P(b["gamma"]), P(b["mean"]), P(b["invstd"]), P(pa[2]), P(pa[3]), P(dza), P(dzb), P(ws), ws.numel() // 2 - 256, dt, None)
+    assert small == -3          # MVF_EWS
+    if dtype == torch.float32 and m <= 1000:
+        zat, zbt = za.clone().requires_grad_(True), zb.clone().requires_grad_(True)
+        gat, gbt = ga.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+        y = F.relu(F.batch_norm(zat, None, None, gat, ba, True, 0.1, 1e-5) + F.batch_norm(zbt, None, None, gbt, bb, True, 0.1, 1e-5))
+        y.backward(g)
+        assert rel_err(dza.cpu().numpy(), zat.grad.numpy()) < 5e-5 and rel_err(dzb.cpu().numpy(), zbt.grad.numpy()) < 5e-5
+        assert rel_err(pa[0].cpu().numpy(), gat.grad.numpy()) < 5e-5 and rel_err(pa[2].cpu().numpy(), gbt.grad.numpy()) < 5e-5
+
+
 @pytest.mark.parametrize("shape", [(4, 9, 7, 16), (8, 14, 14, 64), (2, 5, 5, 260)], ids=str)
 def test_bn_train_forward_backward_vs_oracle(shape):
     from mvfnet_amd import _lib
