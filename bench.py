@@ -221,6 +221,9 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         nb = esz * m * self.c * 3 + (m * self.c // 4 if mask_mode == 4 else 0)
         return (0.0, "bn bwd apply<%d> M%d C%d" % (mask_mode, m, self.c), nb)
 
+    def dbpr(self, out, b, g, g_pitch, za, zb, m, eng_, bits):          # bn3 + downsample BN -- reduce: g, z3, zd, bits; apply: the same + dz3, dzd
+        return (0.0, "bn bwd pair M%d C%d" % (m, self.c), esz * m * self.c * 8 + 2 * (m * self.c // 4))
+
     def dmvf(self, out, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits):
         m = d.nt * d.h * d.w
         nb = esz * m * d.cs * (3 if addend is not None else 2)          # slice read + slice write (+ the gated skip-connection slice)
@@ -229,6 +232,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
 
     undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb),
             tw.wrap(TE._TConv, "wgrad", dwgr), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
+            tb.wrap(TE._BN, "backward_pair", dbpr),
             tm.wrap(TE._TMvf, "launch_stencil", dmvf)]
     overlap = eng.overlap_wgrad
     eng.overlap_wgrad = False          # time every kernel alone on the launch stream (the timed steps overlap wgrad on a side stream)

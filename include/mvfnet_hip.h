@@ -137,15 +137,16 @@ int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const v
                                 const float* bias, const void* residual, const unsigned char* res_sign_bits, void* y,
                                 void* ws, size_t ws_bytes, void* stream);
 /* Stride-1 data gradient whose output da feeds the backward of a = ReLU(BN(z)): besides y = dgrad(dz) it accumulates that
- * BatchNorm's backward sums in the epilogue -- sums_part [mvf_conv2d_stats_rows(d)][cout][2] = per-tile column sums of gm and
+ * BatchNorm's backward sums in the epilogue -- sums_part, CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] = per-128-row column sums of gm and
  * gm * xhat with gm = y * [bn_scale*z + bn_shift > 0], xhat = (z - bn_mean) * bn_invstd (z: the forward conv output the BN
- * normalised, same shape as y).  mvf_bn_bwd_finalize turns them into dgamma / dbeta; no separate mvf_bn_bwd_reduce pass. */
+ * normalised, same shape as y).  mvf_bn_bwd_finalize (nblk = that row count) turns them into dgamma / dbeta; no separate
+ * mvf_bn_bwd_reduce pass.  (Channel-major: a channel's rows are contiguous, the finalize reads whole cache lines.) */
 int mvf_conv2d_nhwc_dgrad_bnsums(const mvf_conv_desc_t* d, const void* dz, const void* w_packed_dgrad, void* y, const void* bn_z,
                                  const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
                                  float* sums_part, void* ws, size_t ws_bytes, void* stream);
 int mvf_bn_bwd_finalize(const float* sums_part, int nblk, int c, float* dgamma, float* dbeta, void* stream);
 /* Training forward: plain conv (no bias / residual / ReLU) whose epilogue also accumulates the BatchNorm batch statistics of
- * the tensor it writes: stats_part [mvf_conv2d_stats_rows(d)][cout][2] = per-tile column sums of (y-K), (y-K)^2 with
+ * the tensor it writes: stats_part, CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] = per-128-row column sums of (y-K), (y-K)^2 with
  * K = stats_shift[cout] (pass the BN's running_mean; NULL = 0).  Feed stats_part to mvf_bn_train_finalize. */
 int mvf_conv2d_stats_rows(const mvf_conv_desc_t* d);
 int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, void* y,
@@ -201,7 +202,8 @@ size_t mvf_bn_workspace_bytes(long m, int c);
 int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
                        float* shift, void* ws, size_t ws_bytes, int dtype, void* stream);
-/* second half of mvf_bn_train_stats for partial sums produced by mvf_conv2d_nhwc_fwd_stats (K must be the same running_mean) */
+/* second half of mvf_bn_train_stats for the channel-major partial sums [c][nblk][2] produced by mvf_conv2d_nhwc_fwd_stats
+ * (nblk = mvf_conv2d_stats_rows(d); K must be the same running_mean) */
 int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                           float* scale, float* shift, void* stream);

@@ -59,7 +59,9 @@ struct ConvArgs {
     int pad_w;     // horizontal padding (pad = vertical)
     int w_kh0, w_kw0, w_ts, w_kwfull;   // weight tap (kh,kw) of this launch = full-pack tap (kh0 + kh*ts, kw0 + kw*ts)
     int o_s, o_ph, o_pw, o_hfull, o_wfull;   // o_s > 0: output pixel (oh,ow) lands at (oh*o_s+o_ph, ow*o_s+o_pw) of an o_hfull x o_wfull map
-    float* stats_part;         // optional [tiles_m][Cout][2]: per-tile column sums of (y - K), (y - K)^2 (BatchNorm batch statistics)
+    float* stats_part;         // optional, CHANNEL-MAJOR [Cout][stats_rows][2]: per-128-row column sums of (y - K), (y - K)^2 (BatchNorm batch
+                               // statistics); a channel's partial rows are contiguous, so the finalize kernel reads whole cache lines
+    int stats_rows;            // row extent of stats_part = mvf_conv2d_stats_rows(d)
     const float* stats_shift;  // K per output channel (the BN's old running mean; any K is exact, a close one avoids cancellation)
     // EPI 6 (data gradient whose output feeds a ReLU(BN(z)) backward): per-tile column sums of gm and gm * xhat into stats_part,
     // gm = y * [bn_scale*z + bn_shift > 0], xhat = (z - bn_mean) * bn_invstd; z has the output's shape
@@ -919,8 +921,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                             t1.x += p1.x; t1.y += p1.y; t1.z += p1.z; t1.w += p1.w;
                             t2.x += p2.x; t2.y += p2.y; t2.z += p2.z; t2.w += p2.w;
                         }
-                        float* p = a.stats_part + ((long)tm_i * a.Cout + c4) * 2;
-                        p[0] = t1.x; p[1] = t2.x; p[2] = t1.y; p[3] = t2.y; p[4] = t1.z; p[5] = t2.z; p[6] = t1.w; p[7] = t2.w;
+                        float2* p = reinterpret_cast<float2*>(a.stats_part) + (long)c4 * a.stats_rows + tm_i;
+                        p[0] = make_float2(t1.x, t2.x);
+                        p[a.stats_rows] = make_float2(t1.y, t2.y);
+                        p[2 * (long)a.stats_rows] = make_float2(t1.z, t2.z);
+                        p[3 * (long)a.stats_rows] = make_float2(t1.w, t2.w);
                     }
                 }
             }
@@ -1047,8 +1052,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     s1.x += p1.x; s1.y += p1.y; s1.z += p1.z; s1.w += p1.w;
                     s2.x += p2.x; s2.y += p2.y; s2.z += p2.z; s2.w += p2.w;
                 }
-                float* p = a.stats_part + ((long)pidx * a.Cout + col) * 2;
-                p[0] = s1.x; p[1] = s2.x; p[2] = s1.y; p[3] = s2.y; p[4] = s1.z; p[5] = s2.z; p[6] = s1.w; p[7] = s2.w;
+                float2* p = reinterpret_cast<float2*>(a.stats_part) + (long)col * a.stats_rows + pidx;
+                p[0] = make_float2(s1.x, s2.x);
+                p[a.stats_rows] = make_float2(s1.y, s2.y);
+                p[2 * (long)a.stats_rows] = make_float2(s1.z, s2.z);
+                p[3 * (long)a.stats_rows] = make_float2(s1.w, s2.w);
             }
             st1 = make_float4(0.f, 0.f, 0.f, 0.f);
             st2 = st1;
@@ -1646,6 +1654,7 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     (void)esz;
     a.pad_w = d->pad; a.w_kh0 = 0; a.w_kw0 = 0; a.w_ts = 1; a.w_kwfull = d->kw;
     a.stats_part = stats_part; a.stats_shift = stats_shift;
+    a.stats_rows = stats_part ? mvf_conv2d_stats_rows(d) : 0;
     if (mf) {
         a.mvf_coef = mf->coef; a.mvf_cs = mf->cs; a.mvf_T = mf->T; a.mvf_act = mf->act;
     }
@@ -1687,7 +1696,7 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
             c.M = d->n * c.Ho * c.Wo;
             c.nchunks = c.KH * c.KW * c.cpt;
             c.o_s = s_; c.o_ph = ph; c.o_pw = pw; c.o_hfull = d->ho; c.o_wfull = d->wo;
-            if (a.stats_part) c.stats_part = a.stats_part + part_rows * d->cout * 2;
+            if (a.stats_part) c.stats_part = a.stats_part + part_rows * 2;          // channel-major: this class's run of rows inside every channel
             part_rows += ((long)c.M + kBM - 1) / kBM;
             int rc = launch(c);
             if (rc) return rc;

@@ -172,53 +172,121 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const ET* z, long M,
     }
 }
 
-// partial sums [nblk][C][2] -> per-channel (s1, s2) in fp64; kFinCh channels x 64 block-lanes per workgroup, fixed order
+// partial sums [nblk][C][2] -> per-channel (s1, s2) in fp64, fixed order.  A workgroup owns kFinCh = 4 channels (C % 4 == 0); ALL 256
+// threads are row lanes, each reading the 32 contiguous bytes (4 channels x 2 sums) of its rows with U rows in flight: the loop is
+// pure L2 latency, and layer1's 3136-6272 partial rows are 2-4 trips of 2048 rows (12 trips of 512 with 64 row lanes x 4 channel
+// lanes and 8-byte loads: finalize kernels 9-12 us -> see DESIGN 4.2).  Then a butterfly over the wave and the 4 waves through LDS.
 constexpr int kFinCh = 4;
-__device__ __forceinline__ bool reduce_partials(const float* part, int C, int nblk, int& c, double& s1, double& s2) {
-    constexpr int CH = kFinCh, LN = 256 / kFinCh;        // channels per workgroup x block-lanes (256 threads)
-    constexpr int U = 8;                                 // loads in flight per lane: the loop is pure L2 latency
-    __shared__ double sh[2][LN][CH];
-    const int cl = threadIdx.x % CH, bl = threadIdx.x / CH;
-    c = blockIdx.x * CH + cl;
-    double a = 0.0, b = 0.0;
-    if (c < C) {
-        double aa[U], bb[U];
+__device__ __forceinline__ bool reduce_partials_at(const float* part, int C, int nblk, int blk, int& c, double& s1, double& s2) {
+    constexpr int CH = kFinCh, U = 4;
+    __shared__ double sh[4][2 * CH];
+    const int c0 = blk * CH, t = threadIdx.x;
+    double acc[2][2 * CH];
 #pragma unroll
-        for (int u = 0; u < U; ++u) aa[u] = bb[u] = 0.0;
-        int k = bl;
+    for (int j = 0; j < 2 * CH; ++j) acc[0][j] = acc[1][j] = 0.0;
+    int k = t;
+    for (; k + (U - 1) * 256 < nblk; k += U * 256) {
+        float4 v[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4* p = reinterpret_cast<const float4*>(part + ((long)(k + u * 256) * C + c0) * 2);
+            v[u][0] = p[0];
+            v[u][1] = p[1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double* a = acc[u & 1];
+            a[0] += v[u][0].x; a[1] += v[u][0].y; a[2] += v[u][0].z; a[3] += v[u][0].w;
+            a[4] += v[u][1].x; a[5] += v[u][1].y; a[6] += v[u][1].z; a[7] += v[u][1].w;
+        }
+    }
+    for (; k < nblk; k += 256) {
+        const float4* p = reinterpret_cast<const float4*>(part + ((long)k * C + c0) * 2);
+        const float4 v0 = p[0], v1 = p[1];
+        double* a = acc[0];
+        a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w;
+        a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+    }
+    double r[2 * CH];
+#pragma unroll
+    for (int j = 0; j < 2 * CH; ++j) {
+        r[j] = acc[0][j] + acc[1][j];
+        for (int off = 1; off < 64; off <<= 1) r[j] += __shfl_xor(r[j], off, 64);
+    }
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 2 * CH; ++j) sh[t >> 6][j] = r[j];
+    }
+    __syncthreads();
+    c = c0 + t;
+    if (t >= CH || c >= C) return false;
+    s1 = ((sh[0][2 * t] + sh[1][2 * t]) + (sh[2][2 * t] + sh[3][2 * t]));
+    s2 = ((sh[0][2 * t + 1] + sh[1][2 * t + 1]) + (sh[2][2 * t + 1] + sh[3][2 * t + 1]));
+    return true;
+}
+__device__ __forceinline__ bool reduce_partials(const float* part, int C, int nblk, int& c, double& s1, double& s2) {
+    return reduce_partials_at(part, C, nblk, blockIdx.x, c, s1, s2);
+}
+
+// CHANNEL-MAJOR partial sums [C][nblk][2] (what the conv epilogues write: mvf_conv2d_nhwc_fwd_stats / _dgrad_bnsums): a channel's
+// rows are contiguous, so the reads are whole cache lines (row-major: every 32-byte piece sits in its own 128-byte line, and
+// layer1's 6272 rows made a 16-workgroup finalize a 20-70 us kernel).  MODE 1: one workgroup per channel (256 row lanes, long row
+// counts); MODE 2: one WAVE per channel, 4 channels per workgroup.  Fixed order either way.
+template <int MODE>
+__device__ __forceinline__ bool reduce_partials_cm(const float* part, int C, int nblk, int& c, double& s1, double& s2) {
+    constexpr int U = 8;
+    constexpr int LN = MODE == 1 ? 256 : 64;
+    __shared__ double sh[4][2];
+    const int t = threadIdx.x, lane = MODE == 1 ? t : (t & 63);
+    c = MODE == 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + (t >> 6);
+    double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+    if (c < C) {
+        const float2* p = reinterpret_cast<const float2*>(part) + (long)c * nblk;
+        int k = lane;
         for (; k + (U - 1) * LN < nblk; k += U * LN) {
             float2 v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float2*>(part + ((long)(k + u * LN) * C + c) * 2);
+            for (int u = 0; u < U; ++u) v[u] = p[k + u * LN];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { aa[u] += v[u].x; bb[u] += v[u].y; }
+            for (int u = 0; u < U; u += 2) { a0 += v[u].x; b0 += v[u].y; a1 += v[u + 1].x; b1 += v[u + 1].y; }
         }
         for (; k < nblk; k += LN) {
-            const float2 v = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
-            aa[0] += v.x;
-            bb[0] += v.y;
+            const float2 v = p[k];
+            a0 += v.x;
+            b0 += v.y;
         }
-        a = ((aa[0] + aa[1]) + (aa[2] + aa[3])) + ((aa[4] + aa[5]) + (aa[6] + aa[7]));
-        b = ((bb[0] + bb[1]) + (bb[2] + bb[3])) + ((bb[4] + bb[5]) + (bb[6] + bb[7]));
     }
-    sh[0][bl][cl] = a;
-    sh[1][bl][cl] = b;
-    __syncthreads();
-    if (bl != 0 || c >= C) return false;
-    s1 = s2 = 0.0;
-    for (int k = 0; k < LN; ++k) {
-        s1 += sh[0][k][cl];
-        s2 += sh[1][k][cl];
+    double a = a0 + a1, b = b0 + b1;
+    for (int off = 1; off < 64; off <<= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
     }
-    return true;
+    if constexpr (MODE == 1) {
+        if ((t & 63) == 0) { sh[t >> 6][0] = a; sh[t >> 6][1] = b; }
+        __syncthreads();
+        if (t != 0 || c >= C) return false;
+        s1 = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+        s2 = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+        return true;
+    } else {
+        if ((t & 63) != 0 || c >= C) return false;
+        s1 = a;
+        s2 = b;
+        return true;
+    }
 }
 
+template <int MODE = 0>          // 0: row-major partials [nblk][C][2]; 1 / 2: channel-major [C][nblk][2] (reduce_partials_cm)
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(int C, int nblk, long M, const float* part, const float* gamma, const float* beta,
                                          float eps, float momentum, float* running_mean, float* running_var,
                                          float* save_mean, float* save_invstd, float* scale, float* shift) {
     int c;
     double s1, s2;
-    if (!reduce_partials(part, C, nblk, c, s1, s2)) return;
+    if constexpr (MODE == 0) {
+        if (!reduce_partials(part, C, nblk, c, s1, s2)) return;
+    } else {
+        if (!reduce_partials_cm<MODE>(part, C, nblk, c, s1, s2)) return;
+    }
     const double K = running_mean ? (double)running_mean[c] : 0.0;
     const double d = s1 / (double)M;
     const double mean = K + d;
@@ -372,10 +440,15 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const ET* g, in
     }
 }
 
+template <int MODE = 0>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nblk, const float* part, float* dgamma, float* dbeta) {
     int c;
     double s1, s2;
-    if (!reduce_partials(part, C, nblk, c, s1, s2)) return;
+    if constexpr (MODE == 0) {
+        if (!reduce_partials(part, C, nblk, c, s1, s2)) return;
+    } else {
+        if (!reduce_partials_cm<MODE>(part, C, nblk, c, s1, s2)) return;
+    }
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
 }
@@ -510,42 +583,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(int C, int nblk, 
     const bool second = (int)blockIdx.x >= gA;
     int c;
     double s1, s2;
-    // reduce_partials() derives the channel from blockIdx.x: re-base it for the second BatchNorm
-    constexpr int CH = kFinCh, LN = 256 / kFinCh, U = 8;
-    __shared__ double sh[2][LN][CH];
-    const float* part = second ? part_b : part_a;
-    const int cl = threadIdx.x % CH, bl = threadIdx.x / CH;
-    c = ((int)blockIdx.x - (second ? gA : 0)) * CH + cl;
-    double a = 0.0, b = 0.0;
-    if (c < C) {
-        double aa[U], bb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) aa[u] = bb[u] = 0.0;
-        int k = bl;
-        for (; k + (U - 1) * LN < nblk; k += U * LN) {
-            float2 v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float2*>(part + ((long)(k + u * LN) * C + c) * 2);
-#pragma unroll
-            for (int u = 0; u < U; ++u) { aa[u] += v[u].x; bb[u] += v[u].y; }
-        }
-        for (; k < nblk; k += LN) {
-            const float2 v = *reinterpret_cast<const float2*>(part + ((long)k * C + c) * 2);
-            aa[0] += v.x;
-            bb[0] += v.y;
-        }
-        a = ((aa[0] + aa[1]) + (aa[2] + aa[3])) + ((aa[4] + aa[5]) + (aa[6] + aa[7]));
-        b = ((bb[0] + bb[1]) + (bb[2] + bb[3])) + ((bb[4] + bb[5]) + (bb[6] + bb[7]));
-    }
-    sh[0][bl][cl] = a;
-    sh[1][bl][cl] = b;
-    __syncthreads();
-    if (bl != 0 || c >= C) return;
-    s1 = s2 = 0.0;
-    for (int k = 0; k < LN; ++k) {
-        s1 += sh[0][k][cl];
-        s2 += sh[1][k][cl];
-    }
+    if (!reduce_partials_at(second ? part_b : part_a, C, nblk, (int)blockIdx.x - (second ? gA : 0), c, s1, s2)) return;
     (second ? dbeta_b : dbeta_a)[c] = (float)s1;
     (second ? dgamma_b : dgamma_a)[c] = (float)s2;
 }
@@ -1000,6 +1038,7 @@ size_t mvf_bn_workspace_bytes(long m, int c) {
         }                                                                                     \
     } while (0)
 
+constexpr int kFinLongRows = 1024;       // channel-major partials: from this many rows on, a whole workgroup per channel
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const float* beta, float eps, float momentum,
@@ -1013,7 +1052,7 @@ int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const f
     const int gy = col_plan(m, c, (dtype != MVF_F32 && wide) ? 8 : 4).gy;
     MVF_BN_DISPATCH(bn_stats_kernel, wide, 2048, (const ET*)z, m, c, running_mean, p.cqb, p.rows, part);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, st, c, gy, m, part, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<0>, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, st, c, gy, m, part, gamma, beta, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd, scale, shift);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
@@ -1024,8 +1063,12 @@ int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const floa
                           float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                           float* scale, float* shift, void* stream) {
     MVF_REQUIRE(part && gamma && beta && save_mean && save_invstd && scale && shift && nblk > 0 && m > 0 && c > 0, MVF_EINVAL, "bn_train_finalize: bad argument");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, (hipStream_t)stream, c, nblk, m, part, gamma, beta, eps, momentum,
-                       running_mean, running_var, save_mean, save_invstd, scale, shift);
+    if (nblk >= kFinLongRows)
+        hipLaunchKernelGGL(bn_stats_finalize_kernel<1>, dim3(c), dim3(256), 0, (hipStream_t)stream, c, nblk, m, part, gamma, beta, eps, momentum,
+                           running_mean, running_var, save_mean, save_invstd, scale, shift);
+    else
+        hipLaunchKernelGGL(bn_stats_finalize_kernel<2>, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, c, nblk, m, part, gamma, beta, eps, momentum,
+                           running_mean, running_var, save_mean, save_invstd, scale, shift);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -1066,14 +1109,17 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
     else
         MVF_BN_DISPATCH(bn_bwd_reduce_kernel, wide, 2048, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (ET*)gm_out, p.cqb, p.rows, part);
     MVF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, st, c, gy, part, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, st, c, gy, part, dgamma, dbeta);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
 
 int mvf_bn_bwd_finalize(const float* sums_part, int nblk, int c, float* dgamma, float* dbeta, void* stream) {
     MVF_REQUIRE(sums_part && dgamma && dbeta && nblk > 0 && c > 0, MVF_EINVAL, "bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, (hipStream_t)stream, c, nblk, sums_part, dgamma, dbeta);
+    if (nblk >= kFinLongRows)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<1>, dim3(c), dim3(256), 0, (hipStream_t)stream, c, nblk, sums_part, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<2>, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, c, nblk, sums_part, dgamma, dbeta);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

@@ -650,7 +650,8 @@ static bool wg_big_shape(const mvf_conv_desc_t* d) {
 }
 static int wg_big_rows(const mvf_conv_desc_t* d) {
     const int M = d->n * d->ho * d->wo, K = d->kh * d->kw * d->cin;
-    return plan_split(M, (d->cout / 256) * (K / 256), 256);
+    static const int big_wgs = getenv("MVF_WGRAD_BIG_WGS") ? std::max(32, atoi(getenv("MVF_WGRAD_BIG_WGS"))) : 256;      // A/B switch
+    return plan_split(M, (d->cout / 256) * (K / 256), big_wgs);
 }
 
 size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
