@@ -203,7 +203,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * 2 + self.w.numel())
         return (fl, "dgrad M%d N%d K%d s%d +bn" % (n * h * w, self.cin, self.kh * self.kw * self.cout, self.stride), nbytes)
 
-    def dwgr(self, out, dz, x, n, h, w, ho, wo, eng_, x_pitch=None, x2=None, split_c=0):
+    def dwgr(self, out, dz, x, n, h, w, ho, wo, eng_, x_pitch=None, x2=None, split_c=0, on_main=False):
         k_alg = 147 if self.stem else self.kh * self.kw * self.cin
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * (4 if self.stem else self.cin)) + 4 * self.w.numel()
         return (2.0 * n * ho * wo * self.cout * k_alg, "wgrad M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)

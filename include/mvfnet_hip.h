@@ -246,6 +246,13 @@ int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const flo
                             unsigned char* argmax, int dtype, void* stream);
 int mvf_maxpool_bn_relu_bwd(const unsigned char* argmax, const void* g, int n, int h, int w, int c, void* ga, int dtype,
                             void* stream);
+/* The same scatter that also accumulates the backward sums of the BatchNorm under the pool (stem: pool(relu(bn(z))), reference
+ * resnet.py:461-466): gm = ga * [scale*z + shift > 0], sums of gm and gm * (z - mean) * invstd per channel into the channel-major
+ * partials sums_part [c][mvf_maxpool_bwd_sums_rows(n, h)][2]; mvf_bn_bwd_finalize turns them into dgamma / dbeta, so the
+ * BatchNorm backward only needs its apply pass (mask_mode 2 over ga).  Needs c/4 to divide 256. */
+int mvf_maxpool_bwd_sums_rows(int n, int h);
+int mvf_maxpool_bn_relu_bwd_sums(const unsigned char* argmax, const void* g, int n, int h, int w, int c, void* ga, const void* z, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, float* sums_part, int dtype, void* stream);
 /* head: avg-pool per frame -> new_fc -> mean over the clip's t frames -> cross-entropy (mean over clips).
  * pooled (clips*t, c), scores (clips, classes), dscores = dloss/dscores, loss_part (clips), loss (1): all fp32. */
 int mvf_head_train_fwd(const void* feat, int clips, int t, int hw, int c, const float* fc_w, const float* fc_b, int classes,

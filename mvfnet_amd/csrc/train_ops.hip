@@ -731,6 +731,87 @@ __global__ void maxpool_bn_bwd_rows_kernel(const unsigned char* amax, const ET* 
     }
 }
 
+// The row form that ALSO accumulates the backward sums of the BatchNorm under the pool (stem: pool(relu(bn(z)))): a workgroup walks
+// kPoolRB input rows; a thread's channel quad is the same for every position it visits (256 % (c/4) == 0), so it keeps the quad's
+// scale / shift / mean / invstd and two running sums in registers: gm = ga * [scale*z + shift > 0] (ga as STORED, i.e. rounded),
+// sum gm and sum gm * xhat.  One channel-major partial row per workgroup ([c][nblk][2], mvf_bn_bwd_finalize): the separate
+// reduce pass over ga and z (2 x 411 MB for the R50 stem at 32 x 8 frames) becomes one extra read of z here.
+constexpr int kPoolRB = 8;
+template <typename ET>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_rows_sums_kernel(const unsigned char* amax, const ET* g, int n, int h, int w, int c, int ho, int wo, ET* ga,
+                                                                       const ET* z, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                                                       float* part, int nblk) {
+    __shared__ float red[256 * 8];
+    const int c4 = c >> 2;
+    const int per = w * c4;
+    const int cq = threadIdx.x % c4;                   // fixed per thread: 256 % c4 == 0 (host-checked)
+    const float4 sc = *reinterpret_cast<const float4*>(scale + cq * 4), sh = *reinterpret_cast<const float4*>(shift + cq * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + cq * 4), rs = *reinterpret_cast<const float4*>(invstd + cq * 4);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int row_end = min(n * h, ((int)blockIdx.x + 1) * kPoolRB);
+    for (int row = blockIdx.x * kPoolRB; row < row_end; ++row) {
+        const int img = row / h, ih = row - img * h;
+        for (int i = threadIdx.x; i < per; i += 256) {
+            const int iw = i / c4;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            unsigned amv[4];
+            float4 gvv[4];
+            bool okv[4];
+            unsigned mev[4];
+            const long zi = ((long)row * w + iw) * c + cq * 4;
+            const float4 zv = ld4(z + zi);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int oh = (ih + (k >> 1)) >> 1, ow = (iw + (k & 1)) >> 1;
+                okv[k] = oh < ho && ow < wo && ((k >> 1) == 0 || (ih & 1)) && ((k & 1) == 0 || (iw & 1));
+                const int ohc = min(oh, ho - 1), owc = min(ow, wo - 1);
+                mev[k] = (unsigned)(ih - (oh * 2 - 1)) * 3u + (unsigned)(iw - (ow * 2 - 1));
+                const long oidx = (((long)img * ho + ohc) * wo + owc) * c + cq * 4;
+                amv[k] = *reinterpret_cast<const unsigned*>(amax + oidx);
+                gvv[k] = ld4(g + oidx);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned am = amv[k], me = mev[k];
+                if (okv[k] && (am & 255u) == me) acc[0] += gvv[k].x;
+                if (okv[k] && ((am >> 8) & 255u) == me) acc[1] += gvv[k].y;
+                if (okv[k] && ((am >> 16) & 255u) == me) acc[2] += gvv[k].z;
+                if (okv[k] && (am >> 24) == me) acc[3] += gvv[k].w;
+            }
+            st4(ga + zi, make_float4(acc[0], acc[1], acc[2], acc[3]));
+            if constexpr (sizeof(ET) == 2) {             // the sums see what the apply pass will read back
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = bf16_to_f32(f32_to_bf16(acc[j]));
+            }
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+            const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gm = (zz[j] * scv[j] + shv[j]) > 0.f ? acc[j] : 0.f;
+                s1[j] += gm;
+                s2[j] += gm * ((zz[j] - muv[j]) * rsv[j]);
+            }
+        }
+    }
+    // threads t, t + c4, t + 2*c4, ... share the channel quad: fixed-order sum through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[(2 * j) * 256 + threadIdx.x] = s1[j];
+        red[(2 * j + 1) * 256 + threadIdx.x] = s2[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < c4 * 4) {
+        const int q = threadIdx.x >> 2, j = threadIdx.x & 3;           // channel q*4 + j
+        float a = 0.f, b = 0.f;
+        for (int t = q; t < 256; t += c4) {
+            a += red[(2 * j) * 256 + t];
+            b += red[(2 * j + 1) * 256 + t];
+        }
+        reinterpret_cast<float2*>(part)[(long)(q * 4 + j) * nblk + blockIdx.x] = make_float2(a, b);
+    }
+}
+
 template <typename ET>
 __global__ void maxpool_bn_bwd_kernel(const unsigned char* amax, const ET* g, int n, int h, int w, int c, int ho, int wo, ET* ga) {
     const int c4 = c >> 2;
@@ -1208,6 +1289,24 @@ int mvf_maxpool_bn_relu_bwd(const unsigned char* argmax, const void* g, int n, i
         hipLaunchKernelGGL(maxpool_bn_bwd_kernel<float>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo, (float*)ga);
     else
         hipLaunchKernelGGL(maxpool_bn_bwd_kernel<bf16_t>, dim3(grid_for(total, 256 * 64)), dim3(256), 0, (hipStream_t)stream, argmax, (const bf16_t*)g, n, h, w, c, ho, wo, (bf16_t*)ga);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_maxpool_bwd_sums_rows(int n, int h) { return n > 0 && h > 0 ? (int)(((long)n * h + kPoolRB - 1) / kPoolRB) : 0; }
+
+int mvf_maxpool_bn_relu_bwd_sums(const unsigned char* argmax, const void* g, int n, int h, int w, int c, void* ga, const void* z, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, float* sums_part, int dtype, void* stream) {
+    MVF_REQUIRE(argmax && g && ga && z && mean && invstd && scale && shift && sums_part && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL,
+                "maxpool_bn_relu_bwd_sums: bad argument");
+    MVF_REQUIRE(256 % (c / 4) == 0 && (long)n * h < (1L << 31), MVF_EUNSUPPORTED, "maxpool_bn_relu_bwd_sums: needs c/4 to divide 256 (use the two-pass form)");
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1, nblk = mvf_maxpool_bwd_sums_rows(n, h);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(maxpool_bn_bwd_rows_sums_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo, (float*)ga,
+                           (const float*)z, mean, invstd, scale, shift, sums_part, nblk);
+    else
+        hipLaunchKernelGGL(maxpool_bn_bwd_rows_sums_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const bf16_t*)g, n, h, w, c, ho, wo, (bf16_t*)ga,
+                           (const bf16_t*)z, mean, invstd, scale, shift, sums_part, nblk);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

@@ -249,13 +249,13 @@ class _TConv(object):
             check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), _p(x), _p(x2), _p(self.wp), _p(z), _p(part), _p(shift), _p(ws), ws.numel(), _st()),
                   "conv fwd+stats")
 
-    def wgrad(self, dz, x, n, h, w, ho, wo, eng, x_pitch=None, x2=None, split_c=0):
+    def wgrad(self, dz, x, n, h, w, ho, wo, eng, x_pitch=None, x2=None, split_c=0, on_main=False):
         """Weight gradient; issued on the engine's side stream so it overlaps the data-gradient / BN chain (they are
         independent given dz) and fills the CUs the other chain's partial tile waves leave idle."""
         d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
         kwr, cinr, kwp, cinp = (self.kw, self.cin, 8, 4) if self.stem else (self.kw, self.cin, self.kw, self.cin)
         nbytes = lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d))
-        side = eng.side_stream()
+        side = None if on_main else eng.side_stream()
         if side is None:
             ws = eng.workspace(nbytes)
             check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(dz), _p(x), _p(x2), kwr, cinr, kwp, cinp, _p(self.dw), _p(ws), ws.numel(), _st()), "conv wgrad")
@@ -572,6 +572,8 @@ class _ParamStore(object):
             self._side = concurrent_stream(self.main_stream(), priority=self.side_priority)      # not every new stream gets its own hardware queue (streams.py)
         return self._side
 
+    fuse_stem_bwd = os.environ.get("MVF_FUSE_STEM_BWD", "1") != "0"
+    stem_wgrad_main = os.environ.get("MVF_STEM_WGRAD_MAIN", "1") != "0"
     side_priority = int(os.environ.get("MVF_SIDE_PRIORITY", "0"))       # HIP priority of the side stream (1 = below the launch stream)
 
     def main_stream(self):
@@ -945,9 +947,21 @@ class TrainEngine(_ParamStore):
                 self._launch_tail_allreduce()
         ho, wo = s["ho"], s["wo"]
         ga = self.buf("ga0", (nt * ho * wo, 64))
-        check(lib.mvf_maxpool_bn_relu_bwd(_p(s["amax"]), _p(g), nt, ho, wo, 64, _p(ga), self.dt, _st()), "maxpool bwd")
-        dz0 = self.stem_bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2)
-        self.stem.wgrad(dz0, s["xp"], nt, s["hp"], s["wp"], ho, wo, self)
+        if self.fuse_stem_bwd:      # the pool's scatter also produces the stem BatchNorm's backward sums (one read of z0 instead of a reduce pass)
+            bn = self.stem_bn
+            rows = lib.mvf_maxpool_bwd_sums_rows(nt, ho)
+            part = self.buf("stem_bnsums", (64, rows, 2), torch.float32)
+            check(lib.mvf_maxpool_bn_relu_bwd_sums(_p(s["amax"]), _p(g), nt, ho, wo, 64, _p(ga), _p(s["z0"]), _p(bn.mean), _p(bn.invstd), _p(bn.scale),
+                                                   _p(bn.shift), _p(part), self.dt, _st()), "maxpool bwd + bn sums")
+            check(lib.mvf_bn_bwd_finalize(_p(part), rows, 64, _p(bn.dgamma), _p(bn.dbeta), _st()), "bn bwd finalize")
+            dz0 = bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2, sums_done=True)
+        else:
+            check(lib.mvf_maxpool_bn_relu_bwd(_p(s["amax"]), _p(g), nt, ho, wo, 64, _p(ga), self.dt, _st()), "maxpool bwd")
+            dz0 = self.stem_bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2)
+        # the step's last weight gradient runs on the LAUNCH stream: nothing is left there to overlap it with, and the side stream
+        # still has layer1's weight gradients queued -- the two tails now run side by side (MVF_STEM_WGRAD_MAIN=0: side stream)
+        self.flush_side()
+        self.stem.wgrad(dz0, s["xp"], nt, s["hp"], s["wp"], ho, wo, self, on_main=self.stem_wgrad_main)
         self.join_side()
         if self.keep_io:
             self.io = dict(p0=self.buf("p0", (g.shape[0], 64)), g_p0=g, gfeat=self.buf("gfeat", tuple(s["feat_shape"])), nt=nt, b=b, t=t)

@@ -25,6 +25,49 @@ def nhwc(t):
 
 # ------------------------------------------------------------------------------------------------ primitives
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 14, 10, 64), (2, 9, 12, 8), (5, 21, 17, 32)], ids=str)
+def test_maxpool_bwd_with_bn_sums_equals_scatter_then_reduce(shape, dtype):
+    """Stem backward, pool(relu(bn(z))) (reference resnet.py:461-466): the scatter that also accumulates the BatchNorm's backward
+    sums writes the same ga bit for bit, and dgamma / dbeta equal the separate mvf_bn_bwd_reduce pass over (ga, z)."""
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    n, h, w, c = shape
+    dt = 0 if dtype == torch.float32 else 1
+    gen = torch.Generator().manual_seed(h * w + c)
+    dev = "cuda"
+    z = (torch.randn(n, h, w, c, generator=gen) * 1.3 + 0.2).to(dev, dtype)
+    m = n * h * w
+    gamma, beta = (torch.rand(c, generator=gen) + 0.5).to(dev), (torch.randn(c, generator=gen) * 0.3).to(dev)
+    mean, invstd, scale, shift = (torch.empty(c, device=dev) for _ in range(4))
+    rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    ws = torch.empty(lib.mvf_bn_workspace_bytes(m, c), dtype=torch.uint8, device=dev)
+    check(lib.mvf_bn_train_stats(P(z), m, c, P(gamma), P(beta), C.c_float(1e-5), C.c_float(0.1), P(rm), P(rv), P(mean), P(invstd), P(scale), P(shift),
+                                 P(ws), ws.numel(), dt, None))
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty(n, ho, wo, c, device=dev, dtype=dtype)
+    am = torch.empty(n, ho, wo, c, device=dev, dtype=torch.uint8)
+    check(lib.mvf_maxpool_bn_relu_fwd(P(z), n, h, w, c, P(scale), P(shift), P(out), P(am), dt, None))
+    g = torch.randn(n, ho, wo, c, generator=gen).to(dev, dtype)
+    ga_ref = torch.empty_like(z)
+    check(lib.mvf_maxpool_bn_relu_bwd(P(am), P(g), n, h, w, c, P(ga_ref), dt, None))
+    dg_ref, db_ref = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    check(lib.mvf_bn_bwd_reduce(P(ga_ref), c, P(z), None, m, c, P(mean), P(invstd), P(scale), P(shift), 2, None, P(dg_ref), P(db_ref), P(ws), ws.numel(), dt, None))
+    rows = lib.mvf_maxpool_bwd_sums_rows(n, h)
+    assert rows == (n * h + 7) // 8
+    part = torch.full((c, rows, 2), float("nan"), device=dev)
+    ga = torch.empty_like(z)
+    check(lib.mvf_maxpool_bn_relu_bwd_sums(P(am), P(g), n, h, w, c, P(ga), P(z), P(mean), P(invstd), P(scale), P(shift), P(part), dt, None))
+    dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    check(lib.mvf_bn_bwd_finalize(P(part), rows, c, P(dg), P(db), None))
+    torch.cuda.synchronize()
+    assert torch.equal(ga, ga_ref)
+    assert torch.isfinite(part).all()
+    assert rel_err(dg.cpu().numpy(), dg_ref.cpu().numpy()) < 2e-5 and rel_err(db.cpu().numpy(), db_ref.cpu().numpy()) < 2e-5
+    bad = lib.mvf_maxpool_bn_relu_bwd_sums(P(am), P(g), n, h, w, 12, P(ga), P(z), P(mean), P(invstd), P(scale), P(shift), P(part), dt, None)
+    assert bad == -5          # MVF_EUNSUPPORTED: 256 % (c/4) != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("mc", [(8 * 28 * 28, 512), (1000, 256), (37, 12), (16 * 56 * 56, 256), (301, 2048)], ids=str)
 def test_bn_bwd_pair_equals_two_separate_backwards(mc, dtype):
     """Downsample block, out = relu(bn3(z3) + bnd(zd)) (reference resnet.py:227-233): the paired backward reads g and the sign
