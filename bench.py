@@ -247,7 +247,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
             eng.backward()
             torch.cuda.synchronize()
             for k, t in timers:
-                tot[k] = [a + b for a, b in zip(tot[k], _summ(t.rec, per_layer and i == reps - 1 and k in ("igemm", "wgrad"), k, PEAK_TFLOPS[dtype]))]
+                tot[k] = [a + b for a, b in zip(tot[k], _summ(t.rec, per_layer and i == reps - 1, k, PEAK_TFLOPS[dtype]))]
     finally:
         for u in undo:
             u()

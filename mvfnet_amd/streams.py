@@ -27,34 +27,16 @@ def runs_beside(main, cand):
     return e_c.elapsed_time(e_end) > 0.2          # ms from the candidate's kernel to the end of the spin: > 0 only if it overtook
 
 
-_hip = None
-
-
-def _new_stream(priority):
-    """A new stream at a HIP priority: 0 = normal, -1 = high (both through torch's pool), 1 = low (torch's pool has no low
-    class, so the stream is created with hipStreamCreateWithPriority and wrapped; it lives as long as the process)."""
-    if priority <= 0:
-        return torch.cuda.Stream(priority=priority)
-    global _hip
-    import ctypes
-    if _hip is None:
-        _hip = ctypes.CDLL("libamdhip64.so")
-    h = ctypes.c_void_p()
-    if _hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority)) != 0:       # 1 = hipStreamNonBlocking
-        raise RuntimeError("hipStreamCreateWithPriority(%d) failed" % priority)
-    return torch.cuda.ExternalStream(h.value)
-
-
-def concurrent_stream(main=None, avoid=(), tries=12, priority=0):
+def concurrent_stream(main=None, avoid=(), tries=12):
     """A new stream that overlaps with `main` (and with every stream in `avoid`).  Falls back to the last candidate when none of
     `tries` does (a device with a single queue) -- correctness never depends on the overlap, only speed."""
     main = main or torch.cuda.current_stream()
     if not hasattr(torch.cuda, "_sleep"):          # no spin kernel to measure against: take the stream on faith
-        return _new_stream(priority)
+        return torch.cuda.Stream()
     cand = None
     keep = []                                     # rejected candidates stay alive until the search ends: a destroyed stream's
     for _ in range(tries):                        # queue slot would be handed straight to the next candidate
-        cand = _new_stream(priority)
+        cand = torch.cuda.Stream()
         try:
             if all(runs_beside(s, cand) for s in (main,) + tuple(avoid)):
                 return cand

@@ -569,12 +569,11 @@ class _ParamStore(object):
             return None
         if getattr(self, "_side", None) is None:
             from .streams import concurrent_stream
-            self._side = concurrent_stream(self.main_stream(), priority=self.side_priority)      # not every new stream gets its own hardware queue (streams.py)
+            self._side = concurrent_stream(self.main_stream())      # not every new stream gets its own hardware queue (streams.py)
         return self._side
 
     fuse_stem_bwd = os.environ.get("MVF_FUSE_STEM_BWD", "1") != "0"
     stem_wgrad_main = os.environ.get("MVF_STEM_WGRAD_MAIN", "1") != "0"
-    side_priority = int(os.environ.get("MVF_SIDE_PRIORITY", "0"))       # HIP priority of the side stream (1 = below the launch stream)
 
     def main_stream(self):
         ms = getattr(self, "_main", None)
