@@ -249,8 +249,14 @@ int mvf_maxpool_bn_relu_bwd(const unsigned char* argmax, const void* g, int n, i
 /* The same scatter that also accumulates the backward sums of the BatchNorm under the pool (stem: pool(relu(bn(z))), reference
  * resnet.py:461-466): gm = ga * [scale*z + shift > 0], sums of gm and gm * (z - mean) * invstd per channel into the channel-major
  * partials sums_part [c][mvf_maxpool_bwd_sums_rows(n, h)][2]; mvf_bn_bwd_finalize turns them into dgamma / dbeta, so the
- * BatchNorm backward only needs its apply pass (mask_mode 2 over ga).  Needs c/4 to divide 256. */
+ * BatchNorm backward only needs its apply pass (mask_mode 2 over ga).  Needs c/4 to divide 256.  ga may be NULL. */
 int mvf_maxpool_bwd_sums_rows(int n, int h);
+/* ... and the matching apply pass that re-gathers ga instead of reading it (pass ga = NULL to mvf_maxpool_bn_relu_bwd_sums then):
+ * dz = gamma*invstd * (gm - dbeta/M - xhat*dgamma/M), M = n*h*w, gm as above.  dgamma / dbeta: the finalized sums, or zeros for
+ * a BatchNorm in eval mode (no batch-statistics term). */
+int mvf_maxpool_bn_relu_bwd_apply(const unsigned char* argmax, const void* g, int n, int h, int w, int c, const void* z, const float* gamma,
+                                  const float* mean, const float* invstd, const float* scale, const float* shift, const float* dgamma,
+                                  const float* dbeta, void* dz, int dtype, void* stream);
 int mvf_maxpool_bn_relu_bwd_sums(const unsigned char* argmax, const void* g, int n, int h, int w, int c, void* ga, const void* z, const float* mean,
                                  const float* invstd, const float* scale, const float* shift, float* sums_part, int dtype, void* stream);
 /* head: avg-pool per frame -> new_fc -> mean over the clip's t frames -> cross-entropy (mean over clips).

@@ -120,6 +120,8 @@ def _load():
     lib.mvf_maxpool_bn_relu_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp]
     lib.mvf_maxpool_bwd_sums_rows.restype = i32
     lib.mvf_maxpool_bwd_sums_rows.argtypes = [i32, i32]
+    lib.mvf_maxpool_bn_relu_bwd_apply.restype = i32
+    lib.mvf_maxpool_bn_relu_bwd_apply.argtypes = [vp, vp, i32, i32, i32, i32, vp, fp, fp, fp, fp, fp, fp, fp, vp, i32, vp]
     lib.mvf_maxpool_bn_relu_bwd_sums.restype = i32
     lib.mvf_maxpool_bn_relu_bwd_sums.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, fp, fp, fp, fp, fp, i32, vp]
     lib.mvf_head_train_fwd.restype = i32

@@ -778,8 +778,8 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_rows_sums_kernel(const uns
                 if (okv[k] && ((am >> 16) & 255u) == me) acc[2] += gvv[k].z;
                 if (okv[k] && (am >> 24) == me) acc[3] += gvv[k].w;
             }
-            st4(ga + zi, make_float4(acc[0], acc[1], acc[2], acc[3]));
-            if constexpr (sizeof(ET) == 2) {             // the sums see what the apply pass will read back
+            if (ga) st4(ga + zi, make_float4(acc[0], acc[1], acc[2], acc[3]));
+            if constexpr (sizeof(ET) == 2) {             // the sums see what the apply pass will read back / re-gather (rounded to storage)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = bf16_to_f32(f32_to_bf16(acc[j]));
             }
@@ -809,6 +809,79 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_rows_sums_kernel(const uns
             b += red[(2 * j + 1) * 256 + t];
         }
         reinterpret_cast<float2*>(part)[(long)(q * 4 + j) * nblk + blockIdx.x] = make_float2(a, b);
+    }
+}
+
+// Second half of the stem backward without a materialised ga: dz = gamma*invstd * (gm - dbeta/M - xhat*dgamma/M) with gm = the SAME
+// gather as above (rounded to the storage type, as the sums saw it) masked by the recomputed ReLU.  Reads g / argmax (pooled map,
+// 1/4 of the pixels) and z, writes dz: the 2 x 411 MB round trip of ga through HBM (R50 stem, 32 x 8 frames) is gone.
+template <typename ET>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_rows_apply_kernel(const unsigned char* amax, const ET* g, int n, int h, int w, int c, int ho, int wo,
+                                                                        const ET* z, const float* gamma, const float* mean, const float* invstd,
+                                                                        const float* scale, const float* shift, const float* dgamma, const float* dbeta,
+                                                                        float inv_m, ET* dz) {
+    const int c4 = c >> 2;
+    const int per = w * c4;
+    const int cq = threadIdx.x % c4;
+    float av[4], d0[4], kx[4], muv[4], scv[4], shv[4];
+    {
+        const float4 ga_ = *reinterpret_cast<const float4*>(gamma + cq * 4), rs = *reinterpret_cast<const float4*>(invstd + cq * 4);
+        const float4 dg = *reinterpret_cast<const float4*>(dgamma + cq * 4), db = *reinterpret_cast<const float4*>(dbeta + cq * 4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + cq * 4);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + cq * 4), sh = *reinterpret_cast<const float4*>(shift + cq * 4);
+        const float gav[4] = {ga_.x, ga_.y, ga_.z, ga_.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w}, dgv[4] = {dg.x, dg.y, dg.z, dg.w}, dbv[4] = {db.x, db.y, db.z, db.w};
+        const float mu_[4] = {mu.x, mu.y, mu.z, mu.w}, sc_[4] = {sc.x, sc.y, sc.z, sc.w}, sh_[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            av[j] = gav[j] * rsv[j];
+            d0[j] = dbv[j] * inv_m;
+            kx[j] = rsv[j] * dgv[j] * inv_m;
+            muv[j] = mu_[j]; scv[j] = sc_[j]; shv[j] = sh_[j];
+        }
+    }
+    const int row_end = min(n * h, ((int)blockIdx.x + 1) * kPoolRB);
+    for (int row = blockIdx.x * kPoolRB; row < row_end; ++row) {
+        const int img = row / h, ih = row - img * h;
+        for (int i = threadIdx.x; i < per; i += 256) {
+            const int iw = i / c4;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            unsigned amv[4];
+            float4 gvv[4];
+            bool okv[4];
+            unsigned mev[4];
+            const long zi = ((long)row * w + iw) * c + cq * 4;
+            const float4 zv = ld4(z + zi);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int oh = (ih + (k >> 1)) >> 1, ow = (iw + (k & 1)) >> 1;
+                okv[k] = oh < ho && ow < wo && ((k >> 1) == 0 || (ih & 1)) && ((k & 1) == 0 || (iw & 1));
+                const int ohc = min(oh, ho - 1), owc = min(ow, wo - 1);
+                mev[k] = (unsigned)(ih - (oh * 2 - 1)) * 3u + (unsigned)(iw - (ow * 2 - 1));
+                const long oidx = (((long)img * ho + ohc) * wo + owc) * c + cq * 4;
+                amv[k] = *reinterpret_cast<const unsigned*>(amax + oidx);
+                gvv[k] = ld4(g + oidx);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned am = amv[k], me = mev[k];
+                if (okv[k] && (am & 255u) == me) acc[0] += gvv[k].x;
+                if (okv[k] && ((am >> 8) & 255u) == me) acc[1] += gvv[k].y;
+                if (okv[k] && ((am >> 16) & 255u) == me) acc[2] += gvv[k].z;
+                if (okv[k] && (am >> 24) == me) acc[3] += gvv[k].w;
+            }
+            if constexpr (sizeof(ET) == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = bf16_to_f32(f32_to_bf16(acc[j]));
+            }
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gm = (zz[j] * scv[j] + shv[j]) > 0.f ? acc[j] : 0.f;
+                o[j] = av[j] * (gm - d0[j] - (zz[j] - muv[j]) * kx[j]);
+            }
+            st4(dz + zi, make_float4(o[0], o[1], o[2], o[3]));
+        }
     }
 }
 
@@ -1297,8 +1370,8 @@ int mvf_maxpool_bwd_sums_rows(int n, int h) { return n > 0 && h > 0 ? (int)(((lo
 
 int mvf_maxpool_bn_relu_bwd_sums(const unsigned char* argmax, const void* g, int n, int h, int w, int c, void* ga, const void* z, const float* mean,
                                  const float* invstd, const float* scale, const float* shift, float* sums_part, int dtype, void* stream) {
-    MVF_REQUIRE(argmax && g && ga && z && mean && invstd && scale && shift && sums_part && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL,
-                "maxpool_bn_relu_bwd_sums: bad argument");
+    MVF_REQUIRE(argmax && g && z && mean && invstd && scale && shift && sums_part && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL,
+                "maxpool_bn_relu_bwd_sums: bad argument");             // ga may be NULL (mvf_maxpool_bn_relu_bwd_apply re-gathers it)
     MVF_REQUIRE(256 % (c / 4) == 0 && (long)n * h < (1L << 31), MVF_EUNSUPPORTED, "maxpool_bn_relu_bwd_sums: needs c/4 to divide 256 (use the two-pass form)");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1, nblk = mvf_maxpool_bwd_sums_rows(n, h);
     if (dtype == MVF_F32)
@@ -1307,6 +1380,24 @@ int mvf_maxpool_bn_relu_bwd_sums(const unsigned char* argmax, const void* g, int
     else
         hipLaunchKernelGGL(maxpool_bn_bwd_rows_sums_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const bf16_t*)g, n, h, w, c, ho, wo, (bf16_t*)ga,
                            (const bf16_t*)z, mean, invstd, scale, shift, sums_part, nblk);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+int mvf_maxpool_bn_relu_bwd_apply(const unsigned char* argmax, const void* g, int n, int h, int w, int c, const void* z, const float* gamma,
+                                  const float* mean, const float* invstd, const float* scale, const float* shift, const float* dgamma,
+                                  const float* dbeta, void* dz, int dtype, void* stream) {
+    MVF_REQUIRE(argmax && g && z && gamma && mean && invstd && scale && shift && dgamma && dbeta && dz && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0,
+                MVF_EINVAL, "maxpool_bn_relu_bwd_apply: bad argument");
+    MVF_REQUIRE(256 % (c / 4) == 0 && (long)n * h < (1L << 31), MVF_EUNSUPPORTED, "maxpool_bn_relu_bwd_apply: needs c/4 to divide 256 (use the two-pass form)");
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1, nblk = mvf_maxpool_bwd_sums_rows(n, h);
+    const float inv_m = 1.0f / (float)((long)n * h * w);
+    if (dtype == MVF_F32)
+        hipLaunchKernelGGL(maxpool_bn_bwd_rows_apply_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo,
+                           (const float*)z, gamma, mean, invstd, scale, shift, dgamma, dbeta, inv_m, (float*)dz);
+    else
+        hipLaunchKernelGGL(maxpool_bn_bwd_rows_apply_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const bf16_t*)g, n, h, w, c, ho, wo,
+                           (const bf16_t*)z, gamma, mean, invstd, scale, shift, dgamma, dbeta, inv_m, (bf16_t*)dz);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

@@ -572,7 +572,7 @@ class _ParamStore(object):
             self._side = concurrent_stream(self.main_stream())      # not every new stream gets its own hardware queue (streams.py)
         return self._side
 
-    fuse_stem_bwd = os.environ.get("MVF_FUSE_STEM_BWD", "1") != "0"
+    fuse_stem_bwd = int(os.environ.get("MVF_FUSE_STEM_BWD", "1"))        # 0: scatter, reduce, apply; 1: scatter + sums, apply (default); 2: gather + sums, gather + apply (no ga buffer; measured equal)
     stem_wgrad_main = os.environ.get("MVF_STEM_WGRAD_MAIN", "1") != "0"
 
     def main_stream(self):
@@ -945,15 +945,22 @@ class TrainEngine(_ParamStore):
             if i == self._tail_block:
                 self._launch_tail_allreduce()
         ho, wo = s["ho"], s["wo"]
-        ga = self.buf("ga0", (nt * ho * wo, 64))
+        ga = self.buf("ga0", (nt * ho * wo, 64)) if self.fuse_stem_bwd != 2 else None
         if self.fuse_stem_bwd:      # the pool's scatter also produces the stem BatchNorm's backward sums (one read of z0 instead of a reduce pass)
             bn = self.stem_bn
             rows = lib.mvf_maxpool_bwd_sums_rows(nt, ho)
             part = self.buf("stem_bnsums", (64, rows, 2), torch.float32)
-            check(lib.mvf_maxpool_bn_relu_bwd_sums(_p(s["amax"]), _p(g), nt, ho, wo, 64, _p(ga), _p(s["z0"]), _p(bn.mean), _p(bn.invstd), _p(bn.scale),
-                                                   _p(bn.shift), _p(part), self.dt, _st()), "maxpool bwd + bn sums")
+            regather = self.fuse_stem_bwd == 2      # ga is never written: the apply pass gathers it again from the pooled gradient
+            check(lib.mvf_maxpool_bn_relu_bwd_sums(_p(s["amax"]), _p(g), nt, ho, wo, 64, None if regather else _p(ga), _p(s["z0"]), _p(bn.mean), _p(bn.invstd),
+                                                   _p(bn.scale), _p(bn.shift), _p(part), self.dt, _st()), "maxpool bwd + bn sums")
             check(lib.mvf_bn_bwd_finalize(_p(part), rows, 64, _p(bn.dgamma), _p(bn.dbeta), _st()), "bn bwd finalize")
-            dz0 = bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2, sums_done=True)
+            if regather:
+                dz0 = self.buf((id(bn), "dz"), s["z0"].shape, s["z0"].dtype)
+                sg, sb = (bn._zero, bn._zero) if bn.frozen else (bn.dgamma, bn.dbeta)
+                check(lib.mvf_maxpool_bn_relu_bwd_apply(_p(s["amax"]), _p(g), nt, ho, wo, 64, _p(s["z0"]), _p(bn.gamma), _p(bn.mean), _p(bn.invstd), _p(bn.scale),
+                                                        _p(bn.shift), _p(sg), _p(sb), _p(dz0), self.dt, _st()), "maxpool bwd + bn apply")
+            else:
+                dz0 = bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2, sums_done=True)
         else:
             check(lib.mvf_maxpool_bn_relu_bwd(_p(s["amax"]), _p(g), nt, ho, wo, 64, _p(ga), self.dt, _st()), "maxpool bwd")
             dz0 = self.stem_bn.backward(ga, 64, s["z0"], nt * ho * wo, self, 2)

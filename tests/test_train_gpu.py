@@ -65,6 +65,15 @@ def test_maxpool_bwd_with_bn_sums_equals_scatter_then_reduce(shape, dtype):
     assert rel_err(dg.cpu().numpy(), dg_ref.cpu().numpy()) < 2e-5 and rel_err(db.cpu().numpy(), db_ref.cpu().numpy()) < 2e-5
     bad = lib.mvf_maxpool_bn_relu_bwd_sums(P(am), P(g), n, h, w, 12, P(ga), P(z), P(mean), P(invstd), P(scale), P(shift), P(part), dt, None)
     assert bad == -5          # MVF_EUNSUPPORTED: 256 % (c/4) != 0
+    # without a materialised ga: same sums, and the apply pass that gathers again equals the masked apply over the stored ga
+    part2 = torch.full((c, rows, 2), float("nan"), device=dev)
+    check(lib.mvf_maxpool_bn_relu_bwd_sums(P(am), P(g), n, h, w, c, None, P(z), P(mean), P(invstd), P(scale), P(shift), P(part2), dt, None))
+    assert torch.equal(part2, part)
+    dz_ref, dz = torch.empty_like(z), torch.empty_like(z)
+    check(lib.mvf_bn_bwd_apply_masked(P(ga_ref), c, P(z), None, m, c, P(gamma), P(mean), P(invstd), P(scale), P(shift), P(dg), P(db), 2, P(dz_ref), dt, None))
+    check(lib.mvf_maxpool_bn_relu_bwd_apply(P(am), P(g), n, h, w, c, P(z), P(gamma), P(mean), P(invstd), P(scale), P(shift), P(dg), P(db), P(dz), dt, None))
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz_ref)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
