@@ -433,9 +433,14 @@ class _TBlock(object):
         # data-gradient GEMM that shares its dz has been queued on the main stream, so it starts when the main stream
         # moves on to the (HBM-bound) BatchNorm-backward kernels of the next layer -- MFMA work under memory work --
         # instead of fighting the data-gradient GEMM for the matrix cores.
-        dzd = None
+        dzd = resid_aux = aux = None
         if self.cd is not None and eng.pair_bn_bwd and not (self.b3.frozen or self.bd.frozen):
             dz3, dzd = _BN.backward_pair(self.b3, self.bd, g, self.c3.cout, s["z3"], s["zd"], m2, eng, bits)
+            aux = eng.aux_stream()
+            if aux is not None:      # the downsample branch's data gradient runs beside the conv3 -> conv2 -> conv1 chain (joined before conv1's)
+                aux.wait_stream(eng.main_stream())
+                with _on_stream(aux):
+                    resid_aux = self.cd.dgrad(dzd, nt, ho, wo, h, w)
         else:
             dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 4, ymask=bits)
         fuse = eng.fuse_bn_bwd_sums
@@ -462,7 +467,11 @@ class _TBlock(object):
         if self.cd is not None:
             if dzd is None:
                 dzd = self.bd.backward(g, self.cd.cout, s["zd"], m2, eng, 4, ymask=bits)
-            resid, rbits = self.cd.dgrad(dzd, nt, ho, wo, h, w), None
+            if resid_aux is not None:
+                eng.main_stream().wait_stream(aux)
+                resid, rbits = resid_aux, None
+            else:
+                resid, rbits = self.cd.dgrad(dzd, nt, ho, wo, h, w), None
             self.cd.wgrad(dzd, s["x"], nt, h, w, ho, wo, eng, x_pitch=c)
             del dzd
         if self.mvf is None:
@@ -574,6 +583,18 @@ class _ParamStore(object):
 
     fuse_stem_bwd = int(os.environ.get("MVF_FUSE_STEM_BWD", "1"))        # 0: scatter, reduce, apply; 1: scatter + sums, apply (default); 2: gather + sums, gather + apply (no ga buffer; measured equal)
     stem_wgrad_main = os.environ.get("MVF_STEM_WGRAD_MAIN", "1") != "0"
+
+    overlap_downsample_bwd = os.environ.get("MVF_AUX_DOWNSAMPLE_BWD", "0") != "0"      # opt-in: measured 21.46 vs 21.51 ms (noise level), and a fourth stream beside RCCL's
+
+    def aux_stream(self):
+        """A third stream (beside the launch and the weight-gradient streams) for the downsample branch's data gradient."""
+        if not (self.overlap_wgrad and self.overlap_downsample_bwd):
+            return None
+        if getattr(self, "_aux", None) is None:
+            from .streams import concurrent_stream
+            side = self.side_stream()
+            self._aux = concurrent_stream(self.main_stream(), avoid=[side] if side is not None else [])
+        return self._aux
 
     def main_stream(self):
         ms = getattr(self, "_main", None)
@@ -1001,7 +1022,7 @@ class TrainEngine(_ParamStore):
         # when the collective is, and the optimizer orders itself behind `comm`.
         if getattr(self, "_comm", None) is None:
             from .streams import concurrent_stream
-            self._comm = concurrent_stream(self.main_stream(), avoid=[side])
+            self._comm = concurrent_stream(self.main_stream(), avoid=[side] + ([self._aux] if getattr(self, "_aux", None) is not None else []))
         comm = self._comm
         comm.wait_stream(side)                 # weight-gradient GEMMs / tap gradients of layer3, layer4, head
         comm.wait_stream(self.main_stream())   # BatchNorm / head gradients
