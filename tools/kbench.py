@@ -50,6 +50,8 @@ def bench_bn(dt=1):
             if tag == "final":
                 t = timeit(lambda: check(lib.mvf_bn_apply_bits(P(z), m, cc, P(scale), P(shift), P(r), None, None, 1, P(out), P(bits), dt, None)))
                 print("%-7s %-5s apply+res+bits  %8.1f us  %6.2f TB/s" % (name, tag, t, (3 * nb + m * cc // 4) / t / 1e6))
+                t = timeit(lambda: check(lib.mvf_bn_apply_bits(P(z), m, cc, P(scale), P(shift), P(r), None, None, 1, P(out), None, dt, None)))
+                print("%-7s %-5s apply+res        %8.1f us  %6.2f TB/s   (no sign bits)" % (name, tag, t, 3 * nb / t / 1e6))
                 t = timeit(lambda: check(lib.mvf_bn_bwd_reduce(P(g), cc, P(z), P(bits), m, cc, P(mean), P(invstd), P(scale), P(shift), 4, None, P(dg), P(db), P(ws), ws.numel(), dt, None)))
                 print("%-7s %-5s bwd_reduce<4>   %8.1f us  %6.2f TB/s" % (name, tag, t, (2 * nb + m * cc // 4) / t / 1e6))
                 t = timeit(lambda: check(lib.mvf_bn_bwd_apply_masked(P(g), cc, P(z), P(bits), m, cc, P(gamma), P(mean), P(invstd), P(scale), P(shift), P(dg), P(db), 4, P(dz), dt, None)))
