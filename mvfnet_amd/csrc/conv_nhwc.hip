@@ -591,10 +591,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     if constexpr (GLDS == 1) {
         // one buffer: DMA, wait, compute; the overlap comes from the other workgroups of the CU (32 KB of LDS each)
         for (int kc = 0; kc < nseg; ++kc) {
+#ifdef MVF_CONV_ABLATE
+            if (!(a.prio & 4)) load_chunk(s0, 0);          // ablation: bit 2 = no loads, bit 1 = no MFMAs
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!(a.prio & 2)) compute(0);
+#else
             load_chunk(s0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             compute(0);
+#endif
             __syncthreads();
         }
     } else if constexpr (GLDS == 3) {
@@ -880,7 +887,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
                 u32x4 pk;
                 pk.x = lo.x; pk.y = lo.y; pk.z = hi.x; pk.w = hi.y;
+#ifdef MVF_CONV_ABLATE
+                if (!(a.prio & 32))                        // ablation: bit 5 = no output stores, bit 6 = no statistics
+#endif
                 __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, off, 0, 0);
+#ifdef MVF_CONV_ABLATE
+                if (a.prio & 64) continue;
+#endif
                 if constexpr (EPI == 1 || e_bnb) {
                     float v[8];
                     unpack8(pk, v);
@@ -903,6 +916,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     }
                 }
             }
+#ifdef MVF_CONV_ABLATE
+            if (a.prio & 64) return;
+#endif
             if constexpr (EPI == 1 || e_bnb) {               // column sums over the RPP8 row-threads, fixed order, one writer per column
                 __syncthreads();
                 float4* red = reinterpret_cast<float4*>(smem);

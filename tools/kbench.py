@@ -2,6 +2,7 @@
 """Micro-benchmarks of single C-ABI kernels at the R50 8x8 x 32-clip (C3) tensor sizes: HIP-event timing, algorithmic GB/s.
 
     python tools/kbench.py bn        # BatchNorm streaming kernels (apply / backward reduce / backward apply) per stage
+    python tools/kbench.py conv [substring]     # single implicit-GEMM launches (forward + statistics, data gradients) per stage
 """
 import ctypes as C
 import os
@@ -27,6 +28,51 @@ def timeit(fn, reps=20, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3      # us
+
+
+def bench_conv(dt=1, only=None):
+    """Single conv launches at the C3 shapes: (name, pixels M as n x h x w, cin, cout, k, kind); kind: 'stats' = forward + BN statistics
+    (EPI 1), 'plain' = plain data gradient (EPI 2), 'res' = data gradient + gated residual (EPI 3), 'bnb' = data gradient + BN sums (EPI 6)."""
+    from mvfnet_amd._lib import ConvDesc
+    tdt = torch.bfloat16 if dt else torch.float32
+    esz = 2 if dt else 4
+    dev = "cuda"
+    shapes = [("l1.c3 fwd", 56, 64, 256, 1, "stats"), ("l1.c1 fwd", 56, 256, 64, 1, "stats"), ("l1.c1 dgrad", 56, 64, 256, 1, "res"),
+              ("l1.c3 dgrad", 56, 256, 64, 1, "bnb"), ("l2.c3 fwd", 28, 128, 512, 1, "stats"), ("l2.c1 dgrad", 28, 128, 512, 1, "res"),
+              ("l3.c3 fwd", 14, 256, 1024, 1, "stats"), ("l3.c1 fwd", 14, 1024, 256, 1, "stats"), ("l3.c1 dgrad", 14, 256, 1024, 1, "res"),
+              ("l3.c3 dgrad", 14, 1024, 256, 1, "bnb"), ("l3.c2 fwd", 14, 256, 256, 3, "stats"), ("l3.c2 dgrad", 14, 256, 256, 3, "bnb"),
+              ("l4.c3 fwd", 7, 512, 2048, 1, "stats"), ("l2.c2 fwd", 28, 128, 128, 3, "stats"), ("l1.c2 fwd", 56, 64, 64, 3, "stats")]
+    n = 256
+    for name, hw, cin, cout, k, kind in shapes:
+        if only and only not in name:
+            continue
+        m = n * hw * hw
+        d = ConvDesc(n, hw, hw, cin, cout, k, k, 1, k // 2, hw, hw, cin, dt, 0, 0, 0, 0, 0)
+        x = torch.randn(m, cin, device=dev).to(tdt)
+        wp = (torch.randn(cout, k * k * cin, device=dev) * 0.05).to(tdt)
+        y = torch.empty(m, cout, device=dev, dtype=tdt)
+        ws = torch.empty(lib.mvf_conv2d_workspace_bytes(None), dtype=torch.uint8, device=dev)
+        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        part = torch.empty(cout, rows, 2, device=dev)
+        shift = torch.zeros(cout, device=dev)
+        nbytes = esz * (m * cin + m * cout + cout * k * k * cin)
+        if kind == "stats":
+            fn = lambda: check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(x), None, P(wp), P(y), P(part), P(shift), P(ws), ws.numel(), None))  # noqa: E731
+        elif kind == "plain":
+            fn = lambda: check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(x), None, P(wp), None, None, P(y), P(ws), ws.numel(), None))  # noqa: E731
+        elif kind == "res":
+            res = torch.randn(m, cout, device=dev).to(tdt)
+            bits = torch.randint(0, 16, (m, cout // 4), device=dev, dtype=torch.uint8)
+            nbytes += esz * m * cout + m * cout // 4
+            fn = lambda: check(lib.mvf_conv2d_nhwc_fwd_resmask(C.byref(d), P(x), None, P(wp), None, P(res), P(bits), P(y), P(ws), ws.numel(), None))  # noqa: E731
+        else:
+            z = torch.randn(m, cout, device=dev).to(tdt)
+            v = [torch.rand(cout, device=dev) + 0.5 for _ in range(4)]
+            nbytes += esz * m * cout
+            fn = lambda: check(lib.mvf_conv2d_nhwc_dgrad_bnsums(C.byref(d), P(x), P(wp), P(y), P(z), P(v[0]), P(v[1]), P(v[2]), P(v[3]), P(part), P(ws), ws.numel(), None))  # noqa: E731
+        t = timeit(fn, reps=30, warm=5)
+        fl = 2.0 * m * cout * k * k * cin
+        print("%-12s %-5s M%-7d K%-5d N%-5d %8.1f us  %6.1f TF/s  %5.2f TB/s" % (name, kind, m, k * k * cin, cout, t, fl / t / 1e6, nbytes / t / 1e6))
 
 
 def bench_bn(dt=1):
@@ -68,3 +114,5 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "bn"
     if what == "bn":
         bench_bn(1)
+    elif what == "conv":
+        bench_conv(1, sys.argv[2] if len(sys.argv) > 2 else None)
