@@ -1112,11 +1112,11 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
 }
 
 // LDS-DMA staged variant for the long-K (matrix-core bound) launches
-template <typename ET, int WM, int WN, int TM, int TN, int EPI, int NB, bool MVFL = false>
+template <typename ET, int WM, int WN, int TM, int TN, int EPI, int NB, bool MVFL = false, bool PW = false>
 __global__ __launch_bounds__(kThreads, (NB == 1 && !MVFL) ? 4 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
-    conv_tile<ET, WM, WN, TM, TN, false, false, false, EPI, false, NB, MVFL>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+    conv_tile<ET, WM, WN, TM, TN, false, false, false, EPI, PW, NB, MVFL>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
 // The long-K tile: 256 x 128 outputs per workgroup of 8 waves (4 x 2, 64 x 64 each), three 48 KB LDS-DMA buffers = one
@@ -1202,19 +1202,24 @@ int launch_glds(int nb, int tiles, hipStream_t st, const ConvArgs& a) {
             return MVF_OK;
         }
     }
+    // pointwise launches (1x1 taps, no padding, no split operand) take the loader specialisation PW: no tap masks, no second-operand
+    // offsets and, at stride 1, no division in the per-tile set-up (MVF_CONV_EPI bit 1, as for the register-staged kernel)
+    static const int epi_spec = getenv("MVF_CONV_EPI") ? atoi(getenv("MVF_CONV_EPI")) : 3;
+    const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
     if (nb == 1) {
-        auto k = conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 1>;
         constexpr int lds = kGldsLds<BM, BN, 1>();
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds, st, a);
+        if (pw) hipLaunchKernelGGL((conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 1, false, true>), dim3(tiles), dim3(kThreads), lds, st, a);
+        else hipLaunchKernelGGL((conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 1>), dim3(tiles), dim3(kThreads), lds, st, a);
     } else {
-        auto k = conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 2>;
         constexpr int lds = kGldsLds<BM, BN, 2>();
         static bool attr = false;
         if (!attr) {
-            MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            MVF_HIP_OK(hipFuncSetAttribute((const void*)(conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            MVF_HIP_OK(hipFuncSetAttribute((const void*)(conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr = true;
         }
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds, st, a);
+        if (pw) hipLaunchKernelGGL((conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 2, false, true>), dim3(tiles), dim3(kThreads), lds, st, a);
+        else hipLaunchKernelGGL((conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 2>), dim3(tiles), dim3(kThreads), lds, st, a);
     }
     return MVF_OK;
 }
