@@ -879,10 +879,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 f[4] = __uint_as_float(t.z << 16); f[5] = __uint_as_float(t.z & 0xffff0000u);
                 f[6] = __uint_as_float(t.w << 16); f[7] = __uint_as_float(t.w & 0xffff0000u);
             };
+            // FULL: the tile lies inside M x Cout (a uniform test, true for every tile but the ragged last ones): the per-element
+            // "row in range" selects of the statistics disappear (1 of 3.5 VALU instructions per element)
+            auto rows_pass = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
             for (int ps = 0; ps < NPS8; ++ps) {
                 const unsigned off = offs8[ps];
-                const bool ok = off != kOOB;
+                const bool ok = FULL || off != kOOB;
                 const char* src = smem + (r08 + ps * RPP8) * CPB + cq8 * 16;
                 const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
                 u32x4 pk;
@@ -916,6 +920,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     }
                 }
             }
+            };
+            if (m0 + BM <= a.M && n0 + BN <= a.Cout) rows_pass(std::true_type());
+            else rows_pass(std::false_type());
 #ifdef MVF_CONV_ABLATE
             if (a.prio & 64) return;
 #endif
