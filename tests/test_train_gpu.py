@@ -859,6 +859,37 @@ def test_side_stream_overlap_is_bit_identical_to_single_stream(dtype):
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_engine_switch_variants_reproduce_the_default_step(dtype):
+    """The backward variants behind the engine's A/B switches compute the same step: the downsample data gradient on a third stream, the
+    stem backward without a materialised scatter (MVF_FUSE_STEM_BWD=2) and the unpaired bn3 / downsample-BN backward are BIT-identical to
+    the default over three optimizer steps; the stem backward with a separate reduce pass (mode 0) sums in another order (one step, 1e-5)."""
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 96, 96)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+
+    def run(steps=3, **attrs):
+        torch.manual_seed(0)
+        m = _model(50, 4, dropout=0.5)
+        eng = m.train_engine(dtype=dtype)
+        for k, v in attrs.items():
+            assert hasattr(eng, k)
+            setattr(eng, k, v)
+        losses = [float(eng.train_step(imgs, labels)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        return losses, eng.flat_params.clone()
+
+    base = run()
+    for attrs in (dict(overlap_downsample_bwd=True), dict(fuse_stem_bwd=2), dict(pair_bn_bwd=False), dict(stem_wgrad_main=False)):
+        got = run(**attrs)
+        assert got[0] == base[0], attrs
+        assert torch.equal(got[1], base[1]), attrs
+    # one step only: the 2-clip batch-statistics network amplifies last-bit differences by orders of magnitude per step
+    got, ref = run(steps=1, fuse_stem_bwd=0), run(steps=1)
+    tol = 1e-5 if dtype == torch.float32 else 1e-3          # bf16: the stem's dz is re-rounded from sums that differ in the last bits
+    assert got[0] == ref[0]
+    assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < tol
+
+
 def test_two_bucket_gradient_exchange_matches_flat_allreduce_single_rank():
     """One rank, RCCL process group, exchange forced: the engine launches the tail bucket (layer3 + layer4 + head) from the
     side stream while backward is still running and the head bucket after it -- parameters after two steps must be bit-identical
