@@ -145,7 +145,7 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
 // SOURCE side: position p of row r holds the 16-byte unit p ^ ((r >> 1) & 7), and the operand fetch applies the same XOR.
 // Out-of-range buffer offsets DMA zeros (tools/probes/glds_probe.hip), so padding taps stay branch-free.
 template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0, bool PW = false, int GLDS = 0,
-          bool MVFL = false, bool ILV = false>
+          bool MVFL = false, bool ILV = false, bool HALFK = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -567,6 +567,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             // (the order is pinned: left alone, the machine scheduler folds the two sets back into one and waits per k-step)
             fetch(0, fa0, fb0);
             fetch(1, fa1, fb1);
+            if constexpr (HALFK) {                 // the chunk's upper 64 bytes are zero padding: two k-steps instead of four
+                mma(fa0, fb0);
+                mma(fa1, fb1);
+                if (a.prio & 1) __builtin_amdgcn_s_setprio(0);
+                return;
+            }
             __builtin_amdgcn_sched_barrier(0);
             mma(fa0, fb0, ilv_more ? 0 : -1);
             __builtin_amdgcn_sched_barrier(0);
@@ -1119,11 +1125,14 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
 }
 
 // LDS-DMA staged variant for the long-K (matrix-core bound) launches
-template <typename ET, int WM, int WN, int TM, int TN, int EPI, int NB, bool MVFL = false, bool PW = false>
+// HALFK: a K chunk is 128 bytes per row; when the packed input channels of a tap fill only half of it (the bf16 stem: 8 pixels x 4
+// channels = 64 bytes) the two upper k-steps would multiply zeros and are not issued: half the MFMAs and operand reads of that conv
+// (a compile-time variant: the same test as a run-time branch inside the pinned MFMA / fetch schedule cost every conv launch 4x).
+template <typename ET, int WM, int WN, int TM, int TN, int EPI, int NB, bool MVFL = false, bool PW = false, bool HALFK = false>
 __global__ __launch_bounds__(kThreads, (NB == 1 && !MVFL) ? 4 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
-    conv_tile<ET, WM, WN, TM, TN, false, false, false, EPI, PW, NB, MVFL>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+    conv_tile<ET, WM, WN, TM, TN, false, false, false, EPI, PW, NB, MVFL, false, HALFK>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
 // The long-K tile: 256 x 128 outputs per workgroup of 8 waves (4 x 2, 64 x 64 each), three 48 KB LDS-DMA buffers = one
@@ -1215,6 +1224,12 @@ int launch_glds(int nb, int tiles, hipStream_t st, const ConvArgs& a) {
     const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
     if (nb == 1) {
         constexpr int lds = kGldsLds<BM, BN, 1>();
+        if constexpr (BN == 64 && sizeof(ET) == 2 && (EPI == 1 || EPI == 4)) {       // the stem (training: + statistics; inference: bias + ReLU)
+            if (!pw && (size_t)a.Cin * sizeof(ET) <= 64 && a.split_c == 0) {
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 1, false, false, true>), dim3(tiles), dim3(kThreads), lds, st, a);
+                return MVF_OK;
+            }
+        }
         if (pw) hipLaunchKernelGGL((conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 1, false, true>), dim3(tiles), dim3(kThreads), lds, st, a);
         else hipLaunchKernelGGL((conv_igemm_glds_kernel<ET, WM, WN, TM, TN, EPI, 1>), dim3(tiles), dim3(kThreads), lds, st, a);
     } else {
