@@ -920,16 +920,20 @@ class TrainEngine(_ParamStore):
         # head + loss
         lab = labels.reshape(-1).to(device=imgs.device, dtype=torch.int64).contiguous()
         mask = None
-        if self.dropout > 0.0:
-            keep = 1.0 - self.dropout
-            mask = (torch.rand(nt, cc, device=imgs.device) < keep).float().div_(keep)
+        if self.dropout > 0.0:      # nn.Dropout over the pooled [frames, channels] features (reference tsn_clshead.py: self.dropout(x)): the SAME draw --
+            cache = self.__dict__.setdefault("_drop_ones", {})         # F.dropout of a ones tensor of that shape -- in one launch
+            ones = cache.get((nt, cc))
+            if ones is None:
+                ones = cache[(nt, cc)] = torch.ones(nt, cc, device=imgs.device, dtype=torch.float32)
+            mask = torch.nn.functional.dropout(ones, self.dropout, True)
         dev = imgs.device
         f32 = torch.float32
         pooled = self.buf("pooled", (nt, cc), f32)
         scores = self.buf("scores", (b, self.num_classes), f32)
         dscores = self.buf("dscores", (b, self.num_classes), f32)
         loss_part = self.buf("loss_part", (b,), f32)
-        loss = self.buf("loss", (1,), f32)
+        loss = torch.empty(1, device=dev, dtype=f32)      # a fresh tensor per step: the caller keeps it (a persistent buffer + clone() went
+                                                          # through hipMemcpyAsync: a blit on another queue = ~70 us of idle launch stream per step)
         check(lib.mvf_head_train_fwd(_p(xcur), b, t, hc * wc, cc, _p(self.fc_w), _p(self.fc_b), self.num_classes, _p(lab), _p(mask), _p(pooled),
                                      _p(scores), _p(dscores), _p(loss_part), _p(loss), self.dt, _st()), "head fwd")
         self.saved.update(pooled=pooled, dscores=dscores, mask=mask, hw=hc * wc, c=cc, feat_shape=xcur.shape, scores=scores)
@@ -942,7 +946,7 @@ class TrainEngine(_ParamStore):
                     self._nbt_inc[key] = torch.tensor([int(k) for k in key] or [0], dtype=torch.int64, device=self.device)
                 self._nbt_flat += self._nbt_inc[key]
             self._nbt_touched = False
-        return loss.clone()                      # `loss` itself is a persistent buffer that the next step overwrites
+        return loss
 
     def backward(self, exchange=False):
         """exchange=True (train_step): this engine also owns the data-parallel gradient exchange and may start it during
