@@ -1369,6 +1369,11 @@ int sk_slots() {
     return slots;
 }
 
+float sk_min_us() {          // stream-K when cutting the partial tile wave saves more than this (MVF_SK_MIN_US; the fix-up costs ~60 us)
+    static const float v = getenv("MVF_SK_MIN_US") ? (float)atof(getenv("MVF_SK_MIN_US")) : 60.0f;
+    return v;
+}
+
 size_t sk_ws_bytes() { return (size_t)sk_slots() * (128 * 128 * sizeof(float)) + 4096; }
 
 template <typename ET, int WM, int WN, int TM, int TN>
@@ -1417,7 +1422,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         const int full0 = tiles / slots * slots, tail0 = tiles - full0;
         const float wave_us0 = a.nchunks * (sizeof(ET) == 4 ? 3.9f : 1.0f);
         sk_wins = skh.ws && skh.ws_bytes >= sk_ws_bytes() && tail0 > 0 && (long)tail0 * a.nchunks >= slots &&
-                  (1.0f - (float)tail0 / slots) * wave_us0 > 60.0f;
+                  (1.0f - (float)tail0 / slots) * wave_us0 > sk_min_us();
     }
     if (a.mvf_coef) {                            // MVF fused into this pointwise conv's A loader (inference epilogue: bias + ReLU)
         MVF_REQUIRE(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.o_s <= 0 && a.bias && a.relu &&
@@ -1545,7 +1550,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
     // saves (1 - tail/slots) of that and costs ~60 us (memset + launch + 64 KB partial round trip per workgroup)
     const float wave_us = a.nchunks * (sizeof(ET) == 4 ? 3.9f : 1.0f);
     const bool use_sk = skh.ws && skh.ws_bytes >= sk_ws_bytes() && tail > 0 && (long)tail * a.nchunks >= slots &&
-                        (1.0f - (float)tail / slots) * wave_us > 60.0f;
+                        (1.0f - (float)tail / slots) * wave_us > sk_min_us();
     if (!use_sk) {
         const bool pf2 = g_pf2_mode == 2 || (g_pf2_mode == 1 && sizeof(ET) == 2);
         hipLaunchKernelGGL(pf2 ? kern_pf : kern, dim3(tiles), dim3(kThreads), lds, st, a);
