@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  -- FIRST: torch bundles its own libamdhip64; ours must resolve to that same runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvfnet_hip.so")
+LIB_PATH = os.environ.get("MVF_LIB_PATH") or os.path.join(_HERE, "libmvfnet_hip.so")      # (override: tooling only, e.g. timing-ablation builds)
 
 MVF_F32, MVF_BF16 = 0, 1
 MVF_NCHW, MVF_NHWC = 0, 1

@@ -151,6 +151,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(BM == kBM || (BM == 2 * kBM && GLDS >= 2), "BM is 128 (256 for the 8-wave LDS-DMA tiles)");
     static_assert(WM * WN == 4 || (WM * WN == 8 && GLDS >= 2), "4 waves (8 for the LDS-DMA experiments)");
+    // P4 = the four-phase ping-pong main loop (see the loop itself): 2 x 4 waves of 128 x 64 outputs on a 256 x 256 tile
+    constexpr bool P4 = GLDS == 4;
+    static_assert(!P4 || (WM == 2 && WN == 4 && TM == 4 && TN == 2 && sizeof(ET) == 2 && !MVFL && !ILV && !HALFK), "the four-phase loop is written for the bf16 256 x 256 tile");
     constexpr int NT = WM * WN * 64;        // threads per workgroup
     constexpr int RP = NT / 8;              // rows per loader pass (8 lanes x 16 B per row)
     constexpr int ESZ = TT<ET>::ESZ, UE = TT<ET>::UE, CE = TT<ET>::CE;
@@ -163,9 +166,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     static_assert(!GLDS || (!GEN && !PF2 && !LOWK), "the LDS-DMA loop is its own variant");
     static_assert(!MVFL || (((LOWK && PW) || GLDS == 1 || GLDS == 2) && !GEN), "the fused MVF loader: single-buffer register-staged pointwise kernel or the 4-wave LDS-DMA kernels");
     static_assert(!ILV || (GLDS == 2 && !MVFL), "interleaved DMA issue: the two-buffer LDS-DMA loop");
-    constexpr int NBUF = GLDS ? GLDS : (LOWK ? 1 : 2);
+    constexpr int NBUF = P4 ? 2 : (GLDS ? GLDS : (LOWK ? 1 : 2));
     constexpr int PITCH = GLDS ? 128 : kPitch;         // LDS-DMA rows are unpadded (lane-linear destination)
-    constexpr int kSmem = GLDS ? kGldsLds<BM, BN, GLDS ? GLDS : 1>() : (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch);
+    constexpr int kSmem = GLDS ? kGldsLds<BM, BN, GLDS ? NBUF : 1>() : (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch);
     char* As = smem;                                   // [NBUF][BM][PITCH]
     char* Bs = smem + NBUF * BM * PITCH;               // [NBUF][BN][PITCH]
 
@@ -175,6 +178,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = tid >> 3;                         // loader: row-in-32, 16-B unit within the 128-B chunk
     const int q = GLDS ? ((tid & 7) ^ ((lrow >> 1) & 7)) : (tid & 7);     // LDS-DMA: the unit that belongs at position tid & 7
+    // loader row i of this thread.  P4 stages HALF tiles (128 rows = the rows one phase's operand reads touch, in every wave's sub-tile):
+    // i = 2 * half + n, wave instruction n of a half covers 8 consecutive rows -- A half h = rows {wm' * 128 + h * 64 + r, r < 64}
+    // (fragment rows 2h, 2h + 1 of both wave rows), B half h = rows {wn' * 64 + h * 32 + r, r < 32} (fragment h of the four wave columns).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto a_row0 = [&](int i) { return P4 ? (wave_u >> 2) * 128 + (i >> 1) * 64 + (wave_u & 3) * 16 + (i & 1) * 8 : wave_u * 8 + RP * i; };
+    auto b_row0 = [&](int i) { return P4 ? (wave_u >> 1) * 64 + (i >> 1) * 32 + (wave_u & 1) * 16 + (i & 1) * 8 : wave_u * 8 + RP * i; };
+    auto a_row = [&](int i) { return P4 ? a_row0(i) + (lane >> 3) : lrow + RP * i; };
+    auto b_row = [&](int i) { return P4 ? b_row0(i) + (lane >> 3) : lrow + RP * i; };
+    auto q_of = [&](int row) { return P4 ? ((tid & 7) ^ ((row >> 1) & 7)) : q; };     // (the other variants' rows differ by multiples of 16)
 
     // ---- per-thread loader state (rows are fixed for the whole K loop) ----
     struct Stage {                       // one K chunk of this thread's loader rows, in registers
@@ -249,7 +261,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         }
 #pragma unroll
         for (int i = 0; i < A_ROWS_PT; ++i) {
-            const int m = m0 + lrow + RP * i;
+            const int m = m0 + a_row(i);
+            const int q = q_of(a_row(i));
             if constexpr (PW) {
                 if (a.stride == 1) {             // pointwise stride 1: input pixel == output pixel, no division at all
                     a_off[i] = m < a.M ? (unsigned)((m - img0 * hw_o) * a.xps + q * UE) * ESZ : kOOB;
@@ -280,8 +293,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS_PT; ++i) {
-            const int co = n0 + lrow + RP * i;
-            b_off[i] = co < a.Cout ? (unsigned)((long)co * a.wK + q * UE) * ESZ : kOOB;
+            const int co = n0 + b_row(i);
+            b_off[i] = co < a.Cout ? (unsigned)((long)co * a.wK + q_of(b_row(i)) * UE) * ESZ : kOOB;
         }
     }
 
@@ -629,6 +642,149 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             bnext = bnext == 2 ? 0 : bnext + 1;
         }
         __syncthreads();
+    } else if constexpr (GLDS == 4) {
+        // ---- four-phase ping-pong loop (tools/probes/gemm8p_probe.hip VAR 3: the matrix pipe issues 99 % of the loop's cycles) ----------------
+        // The 8 waves are two groups (wave rows wm = 0 / 1: one wave of each on every SIMD) running ONE BARRIER APART: while a group issues the
+        // 16 MFMAs of a phase, the other issues its 12 operand reads and 4 LDS-DMA pieces for its next phase, then they swap -- every s_barrier
+        // is a role switch.  A chunk is two phases per group:
+        //   X(k): read A fragments {0,1} + B fragment 0 of chunk k      -> C[0..1][0..1] += ...   stage B0(k+1), then A1(k+1)
+        //   Y(k): read A fragments {2,3} of chunk k + B fragment 1 of k+1 -> C[2..3][0..1] += ... stage B1(k+2), then A0(k+2)
+        // (B fragment 1 of chunk k was read one phase early, in Y(k-1): 12 reads in every phase).  Half tiles are staged in the order they die;
+        // every phase waits vmcnt(6), i.e. three half tiles stay in flight across the barrier: the activations get two phases of lead, the
+        // weights (L2 resident) one.  Hazards (cdna_hip_programming.md section 5, "Read a staged buffer one phase AFTER the wait ..."):
+        //  RAW  a half tile is read one phase after the counted wait that retired it, with that phase's first barrier in between -- by both groups;
+        //  WAR  the A slots are restaged ONE phase after their last read: those 8 reads are issued first and retired (lgkmcnt(4)) before the
+        //       reading phase's first barrier; the B slots are restaged two phases after their last read.
+        // The MFMA builtin touches no memory, so neither s_barrier nor a "memory" clobber orders it and sched_barrier(0) does not bind the
+        // sinking passes: the accumulators are made opaque (empty asm, "+v") on both sides of every MFMA block.
+        // Chunks past the segment's end are staged with out-of-range offsets (the DMA writes zeros into dead slots), so the counted waits
+        // need no tail variants.
+        struct Cur { int cc, kw, kh, left; };              // position of a chunk in the K walk; left = chunks of the segment from it on
+        auto cur_next = [&](Cur c) {
+            if (++c.cc == a.cpt) {
+                c.cc = 0;
+                if (++c.kw == a.KW) { c.kw = 0; ++c.kh; }
+            }
+            --c.left;
+            return c;
+        };
+        const unsigned lds_a = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)As);
+        const unsigned lds_b = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)Bs);
+        auto stage_a = [&](int h, int buf, const Cur& c) {
+            const bool live = c.left > 0;
+            const bool from2 = (a.split_c > 0) && (c.cc * CE < a.split_c);
+            const int ps = from2 ? a.x2ps : a.xps;
+            const unsigned toff = (unsigned)((c.kh * a.W + c.kw) * ps + c.cc * CE) * ESZ;       // wave-uniform
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int i = 2 * h + n;
+                unsigned voff;
+                if constexpr (PW) {
+                    voff = live ? a_off[i] + (unsigned)(c.cc * CE) * ESZ : kOOB;          // kOOB + small stays out of range
+                } else {
+                    const bool ok = live && ((hmask[i] >> c.kh) & (wmask[i] >> c.kw) & 1u) != 0u;
+                    voff = ok ? (from2 ? a_off2[i] : a_off[i]) + toff : kOOB;
+                }
+                glds16((PW || !from2) ? gs_x : gs_x2, lds_a + (unsigned)((buf * BM + a_row0(i)) * PITCH), voff);
+            }
+        };
+        auto stage_b = [&](int h, int buf, const Cur& c) {
+            const unsigned koff = (unsigned)(((a.w_kh0 + c.kh * a.w_ts) * a.w_kwfull + (a.w_kw0 + c.kw * a.w_ts)) * a.Cin + c.cc * CE) * ESZ;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int i = 2 * h + n;
+                glds16(gs_w, lds_b + (unsigned)((buf * BN + b_row0(i)) * PITCH), c.left > 0 ? b_off[i] + koff : kOOB);
+            }
+        };
+        const char* a_base = As + (wm * 128 + (lane & 31)) * PITCH;
+        const char* b_base = Bs + (wn * 64 + (lane & 31)) * PITCH;
+        int ko[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ko[ks] = ((2 * ks + (lane >> 5)) ^ fsw) << 4;
+        auto fetch_a = [&](int buf, int i, uint4 (&f)[4]) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const uint4*>(a_base + (buf * BM + i * 32) * PITCH + ko[ks]);
+        };
+        auto fetch_b = [&](int buf, int j, uint4 (&f)[4]) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const uint4*>(b_base + (buf * BN + j * 32) * PITCH + ko[ks]);
+        };
+        auto mma1 = [&](f32x16& d, const uint4& fa, const uint4& fb) {
+            bf16x8 av, bv;
+            __builtin_memcpy(&av, &fa, 16);
+            __builtin_memcpy(&bv, &fb, 16);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, d, 0, 0, 0);          // D^T: see the epilogue
+        };
+#define MVF_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
+        // prologue: chunk 0 whole + B1 / A0 of chunk 1 in the steady-state issue order; chunk 0's A0, B0, B1 have landed after the wait
+        Cur c1 = {cc, kw, kh, nseg};                       // the chunk X stages for (k + 1) ...
+        stage_b(1, 0, c1); stage_a(0, 0, c1); stage_b(0, 0, c1); stage_a(1, 0, c1);
+        c1 = cur_next(c1);
+        stage_b(1, 1, c1); stage_a(0, 1, c1);
+        Cur c2 = cur_next(c1);                             // ... and the one Y stages for (k + 2)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        uint4 fa[2][4], fb0[4], fb1a[4], fb1b[4];
+        fetch_b(0, 1, fb1a);
+        if (wm == 1) __builtin_amdgcn_s_barrier();         // the second group runs one barrier behind the first
+        auto phase_x = [&](int buf, uint4 (&cur)[4]) {
+            fetch_a(buf, 0, fa[0]);
+            fetch_a(buf, 1, fa[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_b(buf, 0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_b(0, buf ^ 1, c1);
+            stage_a(1, buf ^ 1, c1);
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MVF_PIN2(acc[0][0], acc[1][0]); MVF_PIN2(acc[0][1], acc[1][1]);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                mma1(acc[0][0], fa[0][ks], fb0[ks]); mma1(acc[1][0], fa[1][ks], fb0[ks]);
+                mma1(acc[0][1], fa[0][ks], cur[ks]); mma1(acc[1][1], fa[1][ks], cur[ks]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            MVF_PIN2(acc[0][0], acc[1][0]); MVF_PIN2(acc[0][1], acc[1][1]);
+            __builtin_amdgcn_s_barrier();
+        };
+        auto phase_y = [&](int buf, uint4 (&cur)[4], uint4 (&nxt)[4]) {
+            fetch_a(buf, 2, fa[0]);
+            fetch_a(buf, 3, fa[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_b(buf ^ 1, 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_b(1, buf, c2);
+            stage_a(0, buf, c2);
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MVF_PIN2(acc[2][0], acc[3][0]); MVF_PIN2(acc[2][1], acc[3][1]);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                mma1(acc[2][0], fa[0][ks], fb0[ks]); mma1(acc[3][0], fa[1][ks], fb0[ks]);
+                mma1(acc[2][1], fa[0][ks], cur[ks]); mma1(acc[3][1], fa[1][ks], cur[ks]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            MVF_PIN2(acc[2][0], acc[3][0]); MVF_PIN2(acc[2][1], acc[3][1]);
+            __builtin_amdgcn_s_barrier();
+            c1 = c2;
+            c2 = cur_next(c2);
+        };
+        for (int kc = 0; kc < nseg; kc += 2) {
+            phase_x(0, fb1a);
+            phase_y(0, fb1a, fb1b);
+            if (kc + 1 < nseg) {
+                phase_x(1, fb1b);
+                phase_y(1, fb1b, fb1a);
+            }
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();         // the groups meet again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs of the tail must not land in the epilogue's C tile
+        __syncthreads();
+#undef MVF_PIN2
     } else if constexpr (GLDS >= 2) {
         // GLDS buffers: chunk kc+GLDS-1 is in flight while chunk kc is multiplied; one barrier per chunk
         if (nseg > 0) load_chunk(s0, 0);
@@ -1186,6 +1342,39 @@ int launch_big2(hipStream_t st, const ConvArgs& a0) {
     return MVF_OK;
 }
 
+// The 256 x 256 tile on the four-phase ping-pong loop (conv_tile GLDS = 4): 8 waves as 2 x 4 (128 x 64 outputs each), two 64 KB LDS-DMA
+// buffers staged by half tiles, three half tiles in flight across every barrier.  bf16 only.
+template <typename ET, int EPI, bool PW>
+__global__ __launch_bounds__(512) void conv_igemm_p4_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<ET, 2, 4, 4, 2, false, false, false, EPI, PW, 4>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+template <typename ET, int EPI>
+int launch_p4(hipStream_t st, const ConvArgs& a0) {
+    if constexpr (sizeof(ET) != 2) {
+        return MVF_EUNSUPPORTED;
+    } else {
+        ConvArgs a = a0;
+        a.tiles_m = (a.M + 255) / 256;
+        a.tiles_n = (a.Cout + 255) / 256;
+        constexpr int lds = kGldsLds<256, 256, 2>();
+        auto k0 = conv_igemm_p4_kernel<ET, EPI, false>;
+        auto k1 = conv_igemm_p4_kernel<ET, EPI, true>;
+        static bool attr = false;
+        if (!attr) {
+            MVF_HIP_OK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            MVF_HIP_OK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr = true;
+        }
+        const bool pw = a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
+        if (pw) hipLaunchKernelGGL(k1, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL(k0, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+        return MVF_OK;
+    }
+}
+
 template <typename ET, int EPI>
 int launch_big(hipStream_t st, const ConvArgs& a0) {
     ConvArgs a = a0;
@@ -1471,6 +1660,20 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
             static const bool force2 = getenv("MVF_CONV_BIG2_FORCE") != nullptr;      // tests: every eligible shape, whatever its tile count
             if (force2 || (t2 >= cus / 2 && (double)t2 / (double)(rounds * cus) >= 0.75)) {       // the last round at least 3/4 full
                 int rc;
+                // the four-phase ping-pong loop carries the same tile (MVF_CONV_P4=0 -> the two-barrier loop); whole K chunks only
+                static const int p4_on = getenv("MVF_CONV_P4") ? atoi(getenv("MVF_CONV_P4")) : 1;
+                if (p4_on && a.Cin % 64 == 0 && (a.split_c % 64) == 0) {
+                    if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_p4<ET, 1>(st, a);
+                    else if (bnsum_epi) rc = launch_p4<ET, 6>(st, a);
+                    else if (train_like && !a.stats_part && !a.res) rc = launch_p4<ET, 2>(st, a);
+                    else if (train_like && !a.stats_part && a.res) rc = launch_p4<ET, 3>(st, a);
+                    else if (infer_like && !a.res) rc = launch_p4<ET, 4>(st, a);
+                    else if (infer_like && a.res) rc = launch_p4<ET, 5>(st, a);
+                    else rc = launch_p4<ET, 0>(st, a);
+                    if (rc != MVF_OK) return rc;
+                    MVF_LAUNCH_CHECK();
+                    return MVF_OK;
+                }
                 if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_big2<ET, 1>(st, a);
                 else if (bnsum_epi) rc = launch_big2<ET, 6>(st, a);
                 else if (train_like && !a.stats_part && !a.res) rc = launch_big2<ET, 2>(st, a);

@@ -27,6 +27,17 @@ def three_crop_offsets(img_h, img_w, crop_h, crop_w):
     return [(0, 2 * hs), (4 * ws, 2 * hs), (2 * ws, 2 * hs)]
 
 
+def three_crop_windows(n_frames, img_h, img_w, crop_h, crop_w):
+    """Window rows (y0, x0, flip) for ThreeCrop's oversampled group: crop-major, frame-minor, never mirrored (augmentations.py:512-530)."""
+    return [(y0, x0, 0) for (x0, y0) in three_crop_offsets(img_h, img_w, crop_h, crop_w) for _ in range(n_frames)]
+
+
+def flip_flag(flip_ratio, rng=None):
+    """Flip's per-sample decision (augmentations.py:217): ONE `rand()` draw, mirrored when it is below flip_ratio."""
+    import numpy as np
+    return bool((rng if rng is not None else np.random).rand() < flip_ratio)
+
+
 class FramePipeline(object):
     """Normalize(mean, std, to_rgb, div_255) + a crop size; per-frame windows (y0, x0, flip) select crop position and mirroring."""
 

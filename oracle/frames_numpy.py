@@ -11,8 +11,12 @@ Follows, step by step:
   * stacking  codes/datasets/pipelines/formating.py:146-160: per frame HWC -> CHW, np.stack over frames
 
 PARITY STATUS: FormatShape is pinned by a golden vector from the reference's own class (tests/golden/make_frames_golden.py).
-The crop / flip / normalise steps call mmcv 0.4.3 and cv2, neither of which is installed in the build container, so their
-restatement here is from the pinned versions' documented behaviour: **parity unpinned** for those three steps."""
+[r3] The crop / flip DECISIONS -- ThreeCrop's three boxes and their order, the crop-major / frame-minor order of the oversampled
+group, CenterCrop's box, Flip's `np.random.rand() < flip_ratio` draw -- are the reference's own code and are pinned by
+tests/golden/crops_cases.npz, recorded from those classes through logging stand-ins for `mmcv.imcrop` / `mmcv.imflip`
+(tests/golden/make_crops_golden.py; tests/test_frames_cpu.py).  What stays **parity unpinned** is third-party pixel arithmetic only:
+`mmcv.imcrop` / `imflip` themselves (mmcv 0.4.3: a slice, a reversed view) and cv2's cvtColor / subtract / multiply inside Normalize
+(restated from their documented fp32 behaviour) -- neither library is installed in the build container."""
 import numpy as np
 
 
@@ -26,6 +30,22 @@ def three_crop_offsets(img_h, img_w, crop_h, crop_w):
         return [(0, 0), (0, 2 * s), (0, s)]
     ws, hs = (img_w - crop_w) // 4, (img_h - crop_h) // 4
     return [(0, 2 * hs), (4 * ws, 2 * hs), (2 * ws, 2 * hs)]
+
+
+def three_crop_windows(n_frames, img_h, img_w, crop_h, crop_w):
+    """(3 * n_frames, 3) rows (y0, x0, flip = 0) in the order of ThreeCrop's returned img_group (augmentations.py:512-530: for every
+    offset all frames, the flipped copies are built and dropped)."""
+    return np.array([(y0, x0, 0) for (x0, y0) in three_crop_offsets(img_h, img_w, crop_h, crop_w) for _ in range(n_frames)], dtype=np.int32)
+
+
+def center_crop_offset(img_h, img_w, crop_h, crop_w):
+    """(x0, y0) of CenterCrop (augmentations.py:447-452)."""
+    return (img_w - crop_w) // 2, (img_h - crop_h) // 2
+
+
+def flip_decision(draw, flip_ratio):
+    """Flip.__call__ (augmentations.py:217): one uniform draw per sample, mirrored when it is below the ratio."""
+    return bool(draw < flip_ratio)
 
 
 def imnormalize(img_u8_hwc, mean, std, to_rgb, div_255=False):

@@ -25,6 +25,14 @@ CONV_CASES = [
     (3, 2, 33, 32, 96, 3, 1, 1),        # two-row maps, Wo not a power of two, every tap masked somewhere
     (2, 5, 5, 64, 128, 5, 1, 2),        # 5x5 kernel (25 taps in the kh / kw bit masks)
     (1, 40, 3, 64, 64, 3, 2, 1),        # tall thin map, stride 2
+    # [r3] shapes the 256 x 256 tiles take when forced (Cout % 256 == 0, whole 64-channel K chunks): 3x3 with 18 / 9 (odd) / 27 chunks,
+    # ragged M, stride 2, and a single-chunk K (the four-phase loop's prologue alone stages more than that)
+    (2, 14, 14, 128, 256, 3, 1, 1),
+    (3, 9, 11, 64, 256, 3, 2, 1),
+    (1, 14, 14, 192, 256, 3, 1, 1),
+    (2, 7, 7, 64, 512, 3, 1, 1),
+    (5, 6, 6, 64, 256, 1, 1, 0),
+    (2, 16, 16, 128, 256, 1, 1, 0),
 ]
 
 
@@ -72,10 +80,11 @@ def test_conv_igemm_vs_oracle(case, dtype, epi):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_conv_split_a_operand(dtype):
-    """1x1 conv reading channels [0,Cs) from the compact MVF slice buffer and the rest from x."""
+@pytest.mark.parametrize("shape", [(2, 7, 7, 256, 128, 64), (3, 9, 7, 512, 256, 128), (2, 6, 6, 256, 256, 64)], ids=str)
+def test_conv_split_a_operand(dtype, shape):
+    """1x1 conv reading channels [0,Cs) from the compact MVF slice buffer and the rest from x ([r3] also at Cout = 256: the 256 x 256 tiles)."""
     g = torch.Generator().manual_seed(7)
-    n, h, w, cin, cout, cs = 2, 7, 7, 256, 128, 64
+    n, h, w, cin, cout, cs = shape
     x = torch.randn(n, h, w, cin, generator=g)
     sl = torch.randn(n, h, w, cs, generator=g)
     wgt = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
@@ -175,9 +184,10 @@ def test_conv_streamk_tail_matches_plain_launch_and_oracle(case, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["MVF_CONV_GLDS=0", "MVF_CONV_GLDS=1,1", "MVF_CONV_GLDS=1,2", "MVF_CONV_BIG=1", "MVF_CONV_BIG2=1,MVF_CONV_BIG2_FORCE=1"],
+@pytest.mark.parametrize("env", ["MVF_CONV_GLDS=0", "MVF_CONV_GLDS=1,1", "MVF_CONV_GLDS=1,2", "MVF_CONV_BIG=1", "MVF_CONV_BIG2=1,MVF_CONV_BIG2_FORCE=1",
+                                 "MVF_CONV_BIG2=1,MVF_CONV_BIG2_FORCE=1,MVF_CONV_P4=0"],
                          ids=["register_staged_only", "lds_dma_1buf_everywhere", "lds_dma_2buf_everywhere", "tile_256x128_everywhere",
-                              "tile_256x256_everywhere"])
+                              "tile_256x256_four_phase_everywhere", "tile_256x256_two_barrier_everywhere"])
 def test_conv_kernel_variants_forced_by_env(env):
     """The loader variant is a per-process policy (environment, read once), so each forced policy re-runs this file's oracle
     comparisons in a child process: register staging only, the LDS-DMA loop with one and two buffers for EVERY launch (the

@@ -1,4 +1,5 @@
-"""Input-pipeline oracle (oracle/frames_numpy.py): FormatShape against the reference's own output, crop offsets by formula."""
+"""Input-pipeline oracle (oracle/frames_numpy.py): FormatShape against the reference's own output; [r3] the crop / flip decisions against
+what the reference's ThreeCrop / CenterCrop / Flip handed to (recording stand-ins of) mmcv.imcrop / imflip (tests/golden/make_crops_golden.py)."""
 import os
 
 import numpy as np
@@ -37,3 +38,74 @@ def test_normalize_is_two_rounded_fp32_steps():
     for k in range(3):                           # to_rgb: output channel k reads input channel 2-k (equal here), uses mean[k]
         want = np.float32(np.float32(np.float32(u8[0, :, :, 2 - k]) - m32[k]) * np.float32(1.0 / np.float64(s32[k])))
         assert np.array_equal(out[0, k], want)
+
+
+# ------------------------------------------------------------------------------------------------ [r3] crop / flip decisions vs the reference's classes
+GC = np.load(os.path.join(os.path.dirname(__file__), "golden", "crops_cases.npz"))
+
+
+def _three_cases():
+    return sorted({k.split("/")[1] for k in GC.files if k.startswith("three_crop/")})
+
+
+def test_three_crop_boxes_and_group_order_match_the_reference():
+    from mvfnet_amd import preprocess as P
+    assert len(_three_cases()) == 8
+    for case in _three_cases():
+        hw, crop = case.split("_")
+        h, w = (int(v) for v in hw.split("x"))
+        cw, ch = (int(v) for v in crop.split("x"))
+        boxes, ret = GC["three_crop/%s/boxes" % case], GC["three_crop/%s/returned" % case]
+        n = boxes.shape[0] // 3
+        for mod in (F, P):
+            offs = mod.three_crop_offsets(h, w, ch, cw)
+            # the boxes the reference hands to mmcv.imcrop, call by call: [x0, y0, x0 + w - 1, y0 + h - 1], every offset for all frames
+            want = np.array([[x0, y0, x0 + cw - 1, y0 + ch - 1] for (x0, y0) in offs for _ in range(n)])
+            assert np.array_equal(boxes, want), (case, mod.__name__)
+            win = np.asarray(mod.three_crop_windows(n, h, w, ch, cw))
+            # what comes back, image by image: frame index (frame-minor), top-left corner, crop size
+            assert np.array_equal(ret[:, 0], np.tile(np.arange(n), 3)), case
+            assert np.array_equal(ret[:, 1:3], win[:, :2]) and not win[:, 2].any(), (case, mod.__name__)
+            assert np.array_equal(ret[:, 3:], np.tile([ch, cw], (3 * n, 1)))
+        assert tuple(GC["three_crop/%s/img_shape" % case]) == (ch, cw, 3)
+        # the oracle's crop semantics on marked frames = the windows above (frames_to_nchw slices [y0:y0+h, x0:x0+w])
+        marks = np.zeros((n, h, w, 3), dtype=np.uint8)
+        marks[..., 1] = (np.arange(h) % 251)[None, :, None]
+        marks[..., 2] = (np.arange(w) % 241)[None, None, :]
+        win = F.three_crop_windows(n, h, w, ch, cw)
+        out = F.frames_to_nchw(np.concatenate([marks] * 3), win, ch, cw, [0, 0, 0], [1, 1, 1], to_rgb=False)
+        assert np.array_equal(out[:, 1, 0, 0], ret[:, 1] % 251) and np.array_equal(out[:, 2, 0, 0], ret[:, 2] % 241)
+
+
+def test_center_crop_box_matches_the_reference():
+    import torch
+    from mvfnet_amd.preprocess import FramePipeline
+    cases = sorted({k.split("/")[1] for k in GC.files if k.startswith("center_crop/")})
+    assert len(cases) == 3
+    for case in cases:
+        hw, crop = case.split("_")
+        h, w = (int(v) for v in hw.split("x"))
+        cw, ch = (int(v) for v in crop.split("x"))
+        box = GC["center_crop/%s/box" % case]
+        assert np.array_equal(GC["center_crop/%s/logged" % case], np.tile(box, (2, 1)))
+        x0, y0 = F.center_crop_offset(h, w, ch, cw)
+        assert box.tolist() == [x0, y0, x0 + cw - 1, y0 + ch - 1]
+        assert np.array_equal(GC["center_crop/%s/returned" % case][:, 1:], np.tile([y0, x0, ch, cw], (2, 1)))
+        row = FramePipeline(crop_size=(cw, ch)).center_window(2, h, w, device="cpu")      # cfg order (w, h), as the reference's crop_size
+        assert row.tolist() == [[y0, x0, 0]] * 2 and row.dtype == torch.int32
+
+
+def test_flip_decision_is_one_draw_below_the_ratio():
+    from mvfnet_amd.preprocess import flip_flag
+    seen = set()
+    for seed in range(8):
+        for ratio in (0.5, 0.0, 1.0):
+            tag = "flip/seed%d_ratio%g" % (seed, ratio)
+            flag = int(GC[tag + "/flag"])
+            assert int(GC[tag + "/calls"]) == 2 * flag                   # both frames mirrored, or none
+            assert int(GC[tag + "/first_col"]) == (5 if flag else 0)
+            draw = np.random.RandomState(seed).rand()                   # = np.random.seed(seed); np.random.rand()
+            assert F.flip_decision(draw, ratio) == bool(flag), tag
+            assert flip_flag(ratio, np.random.RandomState(seed)) == bool(flag), tag
+            seen.add((ratio, flag))
+    assert {(0.5, 0), (0.5, 1), (0.0, 0), (1.0, 1)} <= seen
