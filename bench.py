@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--eager-seconds", type=float, default=150.0, help="wall-clock bound per eager comparator run")
     ap.add_argument("--streams", type=int, default=2, help="infer: independent clip-group launch chains (HIP streams)")
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch timing table to stderr")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default 1-GPU train run only: skip the short runs of BASELINE.json's other configurations (configs[1] fp32 inference, "
+                         "configs[3] R101 16x4 bf16 train, configs[4] 30-clip video) that are appended as `other_configs` AFTER the timed region")
+    ap.add_argument("--other-seconds", type=float, default=150.0, help="wall-clock bound for each of those runs")
     return ap.parse_args()
 
 
@@ -458,6 +462,35 @@ def verify_replicas(dist, eng, step, world):
     return out
 
 
+def other_configs(seconds):
+    """BASELINE.json's other single-GPU configurations, each as a short run of THIS script in a child process (after the headline's timed
+    region; same JSON contract, 5 timed steps): so that the driver's record carries them, not only the builder's notes."""
+    import subprocess
+    runs = {"C2 configs[1]: R50 8x8, 32 clips, fp32, forward only": ["--mode", "infer", "--dtype", "f32"],
+            "C4 configs[3]: R101 16x4, 16 clips/GPU, bf16 train step": ["--mode", "train", "--dtype", "bf16", "--depth", "101", "--frames", "16", "--clips", "16"],
+            "C5 configs[4]: R50 8x8, one video = 10 clips x 3 crops of 256^2, fcn_testing, fp32": ["--mode", "video", "--dtype", "f32"],
+            "C5 in bf16": ["--mode", "video", "--dtype", "bf16"]}
+    out = {}
+    for name, flags in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-eager-compare", "--no-other-configs"] + flags
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=seconds, env=dict(os.environ, BENCH_CHILD="1"))
+            line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            d = json.loads(line[-1])
+            rf = d.get("roofline", {})
+            out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"],
+                         "model_tflops": d.get("model_tflops"), "conv_ms_per_step": rf.get("ms_per_step"), "conv_hbm_frac": rf.get("hbm_frac"),
+                         "conv_mfma_frac": rf.get("mfma_frac")}
+            if "videos_per_s" in d:
+                out[name]["videos_per_s"] = d["videos_per_s"]
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "timed out after %.0f s" % seconds}
+    return out
+
+
 def main():
     global T_FRAMES, SIZE, VIDEO
     args = parse()
@@ -568,6 +601,8 @@ def main():
                 # (the engine's buffers stay allocated: 288 GB of HBM hold both; the timed region is long over)
                 eager = eager_comparators(args.depth, args.clips, T_FRAMES, SIZE, args.eager_seconds, value, args.dtype)
             res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds, args.mode, args.clips, eager)
+        if world == 1 and train and args.depth == 50 and T_FRAMES == 8 and args.clips == 32 and not args.no_other_configs:
+            res["other_configs"] = other_configs(args.other_seconds)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

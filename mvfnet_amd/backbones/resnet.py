@@ -59,8 +59,55 @@ class Bottleneck(nn.Module):
     norm3 = property(lambda self: self.bn3)
 
     def forward(self, x):
-        raise RuntimeError("mvfnet_amd Bottleneck is executed by its ResNet's engine (fused HIP kernels), not called "
-                           "block by block")
+        """Stand-alone block (reference resnet.py:208-244): (N*T, C, H, W) CUDA tensor -> (N*T, 4 * planes, H/s, W/s) through the HIP block
+        kernels (`train_engine.BlockTrainer`: conv + BatchNorm (batch statistics when the BatchNorm is in training mode, folded running
+        statistics in eval mode) + ReLU + MVF + residual), as ONE autograd node whose backward is the HIP backward of the block.  Inside a
+        ResNet / Recognizer2D the blocks are not called one by one: the whole stack runs as one fused launch sequence (ResNet.engine(),
+        Recognizer2D.forward_train).  Storage type = x.dtype (float32, or bfloat16 storage with fp32 accumulation / statistics / gradients)."""
+        if not x.is_cuda:
+            raise RuntimeError("mvfnet_amd Bottleneck runs on MI355X tensors only; no CPU fallback (tests use oracle/)")
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("Bottleneck.forward: float32 or bfloat16 input, got %s" % x.dtype)
+        tr = getattr(self, "_trainer", None)
+        if tr is None or tr.tdtype != x.dtype:
+            from ..train_engine import BlockTrainer
+            tr = BlockTrainer(self, dtype=x.dtype)
+            object.__setattr__(self, "_trainer", tr)
+        return _BlockFn.apply(tr, x, *list(self.parameters()))
+
+    def invalidate_engine(self):
+        object.__setattr__(self, "_trainer", None)
+
+    def _apply(self, fn, *a, **k):
+        object.__setattr__(self, "_trainer", None)      # the trainer's flat buffers alias the OLD parameter storage
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        object.__setattr__(self, "_trainer", None)
+        return super().load_state_dict(*a, **k)
+
+
+class _BlockFn(torch.autograd.Function):
+    """One bottleneck as an autograd node: forward / backward = the HIP block kernels (BlockTrainer keeps ONE forward's activations)."""
+
+    @staticmethod
+    def forward(ctx, tr, x, *params):
+        ctx.tr = tr
+        y = tr.forward(x.detach())
+        tr.forward_token = getattr(tr, "forward_token", 0) + 1
+        ctx.token = tr.forward_token
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        tr = ctx.tr
+        if ctx.token != getattr(tr, "forward_token", 0):
+            raise RuntimeError("Bottleneck: backward() of an output whose activations are gone (the block keeps one forward)")
+        dx = tr.backward(gy.contiguous())
+        grads = []
+        for p in tr.model.parameters():
+            grads.append(tr.grad_of(p).clone() if p.requires_grad else None)
+        return (None, dx.to(gy.dtype)) + tuple(grads)
 
 
 def make_res_layer(block, inplanes, planes, blocks, stride=1, dilation=1, style="pytorch", norm_cfg=None,

@@ -85,22 +85,26 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
 
 
 # ---- optimizer state: torch.optim.SGD's state_dict layout (what the reference's checkpoints hold, checkpoint.py:262-263) ---------
-def sgd_state_dict(momentum_bufs, lr, momentum, weight_decay, nesterov=True, dampening=0.0, multipliers=None):
+def sgd_state_dict(momentum_bufs, lr, momentum, weight_decay, nesterov=True, dampening=0.0, multipliers=None, initial_lr=None):
     """{'state': {i: {'momentum_buffer': t}}, 'param_groups': [...]} over n parameters in model.parameters() order;
     momentum_bufs[i] is None for a parameter that has not been stepped (torch creates the buffer at the first step).  One param
     group -- or, with `multipliers` = [(lr_mult, decay_mult)] per parameter, ONE GROUP PER PARAMETER as the reference's paramwise
     build_optimizer makes them (codes/core/train.py:131-153), so torch's load_state_dict finds the group structure it expects.
-    Keys of a group = torch.optim.SGD's (older torch ignores the newer ones on load)."""
+    Keys of a group = torch.optim.SGD's (older torch ignores the newer ones on load).  `lr` is the CURRENT (scheduled) rate;
+    `initial_lr` (the schedule's base rate, x lr_mult per group) is stored beside it as mmcv's LrUpdaterHook does
+    (`group.setdefault('initial_lr', group['lr'])` at before_run): without it a checkpoint written after warm-up or an lr step
+    would resume under the reference's runner with the decayed rate as its base."""
     n = len(momentum_bufs)
     state = {i: {"momentum_buffer": b} for i, b in enumerate(momentum_bufs) if b is not None}
+    base = lr if initial_lr is None else initial_lr
 
-    def group(ids, lr_, wd_):
-        return dict(lr=lr_, momentum=momentum, dampening=dampening, weight_decay=wd_, nesterov=bool(nesterov), maximize=False,
+    def group(ids, lr_, wd_, base_):
+        return dict(lr=lr_, initial_lr=base_, momentum=momentum, dampening=dampening, weight_decay=wd_, nesterov=bool(nesterov), maximize=False,
                     foreach=None, differentiable=False, fused=None, params=ids)
 
     if multipliers is None:
-        return {"state": state, "param_groups": [group(list(range(n)), lr, weight_decay)]}
-    return {"state": state, "param_groups": [group([i], lr * a, weight_decay * b) for i, (a, b) in enumerate(multipliers)]}
+        return {"state": state, "param_groups": [group(list(range(n)), lr, weight_decay, base)]}
+    return {"state": state, "param_groups": [group([i], lr * a, weight_decay * b, base * a) for i, (a, b) in enumerate(multipliers)]}
 
 
 def sgd_momentum_buffers(opt_state, n_params):

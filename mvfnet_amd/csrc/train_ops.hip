@@ -1212,7 +1212,8 @@ int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const f
     return MVF_OK;
 }
 
-// finalize from partial sums produced elsewhere (the conv epilogue: mvf_conv2d_nhwc_fwd_stats), layout [nblk][c][2]
+// finalize from partial sums produced elsewhere (the conv epilogue: mvf_conv2d_nhwc_fwd_stats), CHANNEL-MAJOR layout [c][nblk][2]: a channel's
+// nblk partial pairs are contiguous (row-major [nblk][c][2] partials would be summed into the wrong channels -- silently)
 int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                           float* scale, float* shift, void* stream) {

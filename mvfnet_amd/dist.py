@@ -118,14 +118,38 @@ class MMDistributedDataParallel(torch.nn.Module):
         return self.module(*inputs, **kwargs)
 
 
+def _engine_backed_iter(optimizer, loss, grad_clip, exchange):
+    """The hook sequence for `build_optimizer`'s EngineSGD (the reference's _dist_train pairing, train.py:159-196): its step() updates
+    from the engine's FLAT gradient buffer, which `loss.backward()` has just filled -- the parameters' .grad are autograd's copies, so
+    an all-reduce or clip_grad_norm_ on them would never reach the update.  The exchange (/ world), the global L2 clip and the
+    update therefore all run inside the engine on the flat buffer: one collective, one fused kernel.  Returns the pre-clip norm,
+    as clip_grad_norm_ does."""
+    if grad_clip is not None and grad_clip.get("norm_type", 2) != 2:
+        raise NotImplementedError("grad_clip norm_type %r: the fused clip is the L2 norm" % grad_clip.get("norm_type"))
+    optimizer.zero_grad()
+    loss.backward()
+    eng = optimizer.engine
+    keep_clip, keep_x = eng.max_norm, eng.exchange_enabled
+    eng.max_norm = grad_clip.get("max_norm") if grad_clip is not None else None
+    eng.exchange_enabled = bool(exchange)
+    try:
+        norm = optimizer.step()
+    finally:
+        eng.max_norm, eng.exchange_enabled = keep_clip, keep_x
+    return norm[0] if grad_clip is not None and norm is not None else None
+
+
 class DistOptimizerHook(object):
     """after_train_iter of the reference hook (dist_utils.py:52-67): zero_grad -> backward -> all-reduce / world ->
-    clip_grad_norm_ -> optimizer.step(), for any torch optimizer; `loss` comes from Recognizer2D.forward_train."""
+    clip_grad_norm_ -> optimizer.step(), for any torch optimizer; `loss` comes from Recognizer2D.forward_train.  With the
+    engine-backed optimizer of `runner.build_optimizer` the same sequence runs on the engine's flat gradient buffer."""
 
     def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1):
         self.grad_clip, self.coalesce, self.bucket_size_mb = grad_clip, coalesce, bucket_size_mb
 
     def after_train_iter(self, model, optimizer, loss):
+        if hasattr(optimizer, "engine"):
+            return _engine_backed_iter(optimizer, loss, self.grad_clip, True)
         optimizer.zero_grad()
         loss.backward()
         allreduce_grads(model.parameters(), self.coalesce, self.bucket_size_mb)
@@ -160,6 +184,8 @@ class Fp16OptimizerHook(DistOptimizerHook):
         return model
 
     def after_train_iter(self, model, optimizer, loss):
+        if hasattr(optimizer, "engine"):
+            return _engine_backed_iter(optimizer, loss, self.grad_clip, self.distributed)
         optimizer.zero_grad()
         loss.backward()
         if self.distributed:

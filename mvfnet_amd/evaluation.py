@@ -102,3 +102,40 @@ class EvalTopKAccuracyHook(object):
         out["epoch"] = runner.epoch
         self.history.append(out)
         return out
+
+
+class DistEvalTopKAccuracyHook(EvalTopKAccuracyHook):
+    """The reference's hook signature (eval_hooks.py:17-104): `DistEvalTopKAccuracyHook(dataset, interval=1, k=(1,), dist=True)`.
+    `dataset`: anything with `__len__`, `__getitem__(i) -> dict(img_group=tensor, ...)` and `video_infos[i]['label']` (the reference's
+    RawFramesDataset / VideoDataset in test_mode; building one from a config dict needs the dataset classes, which are out of scope
+    here -- pass the object).  Every rank scores items `rank::world` one by one, as DistEvalHook.after_train_epoch does
+    (collate([data], samples_per_gpu=1) = a batch dimension of one), the rows are gathered on rank 0 and top-k accuracy is logged."""
+
+    def __init__(self, dataset, interval=1, k=(1,), dist=True):
+        if isinstance(dataset, dict):
+            raise TypeError("DistEvalTopKAccuracyHook: a dataset CONFIG dict needs the reference's dataset classes (out of scope here); "
+                            "pass the Dataset object")
+        if not (hasattr(dataset, "__getitem__") and hasattr(dataset, "__len__")):
+            raise TypeError("dataset must be a Dataset object or a dict, not {}".format(type(dataset)))      # the reference's message
+        self.dataset, self.dist = dataset, dist
+        labels = [dataset.video_infos[i]["label"] for i in range(len(dataset))]
+        super().__init__(_RankShare(dataset, dist), labels, interval, k)
+
+
+class _RankShare(object):
+    """items rank::world of a dataset as batches of one (what the reference's hook feeds the model)."""
+
+    def __init__(self, dataset, dist=True):
+        self.dataset, self.dist = dataset, dist
+
+    def __iter__(self):
+        import torch
+        from .dist import get_dist_info
+        rank, world = get_dist_info() if self.dist else (0, 1)
+        for idx in range(rank, len(self.dataset), world):
+            data = self.dataset[idx]
+            img = data["img_group"]
+            img = img if isinstance(img, torch.Tensor) else torch.as_tensor(np.asarray(img))
+            out = {k: v for k, v in data.items() if k not in ("img_group", "label")}
+            out["img_group"] = img.unsqueeze(0).cuda(non_blocking=True)
+            yield out

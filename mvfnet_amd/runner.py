@@ -59,10 +59,15 @@ def _cfg_get(cfg, key, default=None):
 def step_lr(base_lr, epoch, it, steps=(90, 130), gamma=0.1, warmup="linear", warmup_iters=25070, warmup_ratio=0.01):
     """lr at (epoch, global iteration) -- mmcv LrUpdaterHook 'step' policy + linear warm-up."""
     lr = base_lr * (gamma ** sum(1 for s in steps if epoch >= s))
-    if warmup == "linear" and it < warmup_iters:
-        k = (1 - it / float(warmup_iters)) * (1 - warmup_ratio)
-        lr = lr * (1 - k)
-    return lr
+    if warmup is None or it >= warmup_iters:
+        return lr
+    if warmup == "linear":
+        return lr * (1 - (1 - it / float(warmup_iters)) * (1 - warmup_ratio))
+    if warmup == "constant":
+        return lr * warmup_ratio
+    if warmup == "exp":
+        return lr * warmup_ratio ** (1 - it / float(warmup_iters))
+    raise NotImplementedError("lr_config warmup %r (mmcv LrUpdaterHook knows None, 'constant', 'linear', 'exp')" % (warmup,))
 
 
 def parse_losses(losses):
@@ -118,6 +123,7 @@ class EngineSGD(object):
         if dtype is not None:
             opt["dtype"] = dtype
         self.model, self.engine = model, model.train_engine(**opt)
+        self.grad_clip = None           # dict(max_norm=..., norm_type=2), set by train_network / the optimizer hooks (dist.py)
         self.engine.max_norm = None
         self.engine.nesterov = bool(nesterov)
         self.engine.set_param_options(paramwise)
@@ -134,6 +140,7 @@ class EngineSGD(object):
 
     def state_dict(self):
         self.engine.lr = self.param_groups[0]["lr"]
+        self.engine.initial_lr = self.param_groups[0].get("initial_lr", self.engine.lr)
         return self.engine.optimizer_state_dict()
 
     def load_state_dict(self, sd):
@@ -232,9 +239,11 @@ class DevicePrefetcher(object):
             yield cur
 
 
-def build_dataloader(dataset, videos_per_gpu, workers_per_gpu=0, dist_mode=False, shuffle=True):
+def build_dataloader(dataset, videos_per_gpu, workers_per_gpu=0, dist_mode=False, shuffle=True, drop_last=False, pin_memory=False):
     """A torch DataLoader over `dataset` (items: dict(img_group=tensor, label=tensor)): DistributedSampler (rank::world, as the
-    reference's sampler.py:62-78 deals videos) when distributed.  Datasets / decode pipelines themselves are out of scope."""
+    reference's sampler.py:62-78 deals videos) when distributed.  Like the reference's build_dataloader (datasets/builder.py) the
+    last, partial batch of an epoch is kept (drop_last=False: the engine's buffers are keyed by shape) -- the iteration count that
+    drives the warm-up is the reference's.  Datasets / decode pipelines themselves are out of scope."""
     if isinstance(dataset, (torch.utils.data.DataLoader, list, tuple)) or not hasattr(dataset, "__getitem__"):
         return dataset                                     # already a loader / a list or iterable of ready batches
     sampler = None
@@ -242,7 +251,7 @@ def build_dataloader(dataset, videos_per_gpu, workers_per_gpu=0, dist_mode=False
         rank, world = get_dist_info()
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, world, rank, shuffle=shuffle)
     return torch.utils.data.DataLoader(dataset, batch_size=videos_per_gpu, sampler=sampler, shuffle=(shuffle and sampler is None),
-                                       num_workers=workers_per_gpu, pin_memory=False, drop_last=True)
+                                       num_workers=workers_per_gpu, pin_memory=pin_memory, drop_last=drop_last)
 
 
 # ------------------------------------------------------------------------------------------------ runner
@@ -266,6 +275,7 @@ class Runner(object):
             self.engine = model.train_engine(**opt)
         self.optimizer = optimizer
         self.engine.max_norm = max_norm
+        self.engine.initial_lr = lr          # the schedule's base rate: checkpoints carry it beside the current one (mmcv's 'initial_lr')
         self.base_lr, self.lr_steps, self.lr_gamma = lr, tuple(lr_steps), lr_gamma
         self.warmup, self.warmup_iters, self.warmup_ratio = warmup, warmup_iters, warmup_ratio
         self.ckpt_interval, self.log_interval, self.log = ckpt_interval, log_interval, logger
@@ -331,14 +341,29 @@ class Runner(object):
         return ckpt
 
 
+def as_config(cfg):
+    """A plain dict, this package's Config, an mmcv Config (what the reference's train_recognizer.py passes: the settings live in
+    `_cfg_dict`, `vars()` of it shows only _cfg_dict / _filename / _text) or any attribute namespace -> Config."""
+    if isinstance(cfg, Config):
+        return cfg
+    if isinstance(cfg, dict):
+        return Config(cfg)
+    if hasattr(cfg, "_cfg_dict"):
+        d = cfg._cfg_dict
+        return Config(d.to_dict() if hasattr(d, "to_dict") else dict(d))
+    if hasattr(cfg, "to_dict"):
+        return Config(cfg.to_dict())
+    return Config({k: v for k, v in vars(cfg).items() if not k.startswith("_")})
+
+
 def train_network(model, dataset, cfg, distributed=False, validate=False, logger=None):
     """reference train.py:63-76 + _dist_train / _non_dist_train :159-252: loaders, model on the GPU (parameters broadcast from
     rank 0 when distributed), optimizer from cfg.optimizer, grad clip from cfg.optimizer_config, lr schedule from cfg.lr_config,
     checkpoints from cfg.checkpoint_config, logging interval from cfg.log_config, optional fp16 section, resume_from /
     load_from, then run cfg.total_epochs.  `dataset`: a torch Dataset of dict(img_group, label) items, a ready loader, or an
-    iterable of batches (or a list whose first entry is the training one).  `validate` registers cfg's eval hook when the
-    caller provides one under cfg.eval_hook (datasets are out of scope here)."""
-    cfg = cfg if isinstance(cfg, Config) else Config(cfg if isinstance(cfg, dict) else dict(vars(cfg)))
+    iterable of batches (or a list whose first entry is the training one).  `validate` registers the reference's
+    DistEvalTopKAccuracyHook(cfg.data.val, interval=cfg.eval_interval, k=(1, 5)) for a Dataset OBJECT under cfg.data.val."""
+    cfg = as_config(cfg)
     log = (logger.info if logger is not None and hasattr(logger, "info") else (logger or print))
     is_list_of_sets = isinstance(dataset, (list, tuple)) and dataset and not isinstance(dataset[0], dict)     # (a list of dicts = ready batches)
     datasets = dataset if is_list_of_sets else [dataset]
@@ -367,8 +392,19 @@ def train_network(model, dataset, cfg, distributed=False, validate=False, logger
                     log_interval=_cfg_get(lg, "interval", 0) or 0, logger=log, optimizer=optimizer)
     if clip and _cfg_get(clip, "norm_type", 2) != 2:
         raise NotImplementedError("grad_clip norm_type %r: the fused clip is the L2 norm" % _cfg_get(clip, "norm_type"))
-    if validate and cfg.get("eval_hook") is not None:
-        runner.register_hook(cfg.get("eval_hook"))
+    if validate:
+        # reference train.py:192-196: DistEvalTopKAccuracyHook(cfg.data.val, interval=cfg.eval_interval, k=(1, 5)).  Here cfg.data.val
+        # must be the Dataset OBJECT (items dict(img_group=...), video_infos[i]['label']) -- the dataset classes a config dict would
+        # name are out of scope; a ready hook under cfg.eval_hook is taken as is.
+        if cfg.get("eval_hook") is not None:
+            runner.register_hook(cfg.get("eval_hook"))
+        else:
+            val = _cfg_get(data, "val")
+            if val is None or isinstance(val, dict):
+                raise NotImplementedError("validate=True: put the validation Dataset object under cfg.data.val (or a hook under cfg.eval_hook); "
+                                          "building datasets from a config dict is out of scope")
+            from .evaluation import DistEvalTopKAccuracyHook
+            runner.register_hook(DistEvalTopKAccuracyHook(val, interval=cfg.get("eval_interval", 1), k=(1, 5), dist=distributed))
     if cfg.get("resume_from"):
         runner.resume(cfg.get("resume_from"))
     elif cfg.get("load_from"):

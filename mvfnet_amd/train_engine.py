@@ -724,7 +724,8 @@ class _ParamStore(object):
             stepped = self.steps > 0 and first >= off and p.requires_grad
             bufs.append(self.flat_mom[first:first + p.numel()].view(p.shape).detach().cpu().clone() if stepped else None)
         mult = [self.param_options.get(id(p), (1.0, 1.0)) for p in params] if self.param_options else None
-        return sgd_state_dict(bufs, self.lr, self.momentum, self.weight_decay, self.nesterov, multipliers=mult)
+        return sgd_state_dict(bufs, self.lr, self.momentum, self.weight_decay, self.nesterov, multipliers=mult,
+                              initial_lr=getattr(self, "initial_lr", None))
 
     def load_optimizer_state_dict(self, opt):
         """Accepts torch.optim.SGD's state_dict (the reference's checkpoints) or round 1's {'momentum_buffer': flat, 'steps': n}."""

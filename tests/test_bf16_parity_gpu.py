@@ -177,6 +177,76 @@ def test_bf16_train_step_end_to_end_within_the_emulations_own_sensitivity():
     assert np.median(d_eng) < 1.5 * np.median(d_self) + 1e-2 and d_eng.max() < 1.5 * d_self.max() + 1e-2
 
 
+@pytest.mark.parametrize("clips,t,size,norm_eval", [(8, 8, 64, True), (16, 4, 64, False), (8, 8, 64, False)],
+                         ids=["8clips_t8_frozen_stats", "16clips_t4_batch_stats", "8clips_t8_batch_stats"])
+def test_bf16_train_step_end_to_end_eight_and_more_clips(clips, t, size, norm_eval):
+    """[r3] One bf16 train step of the whole R50 network with >= 8 clips against the bf16-storage emulation (forward AND backward rounding
+    points): loss, every stage output, every parameter gradient.
+      * frozen statistics (norm_eval, the reference's `norm_eval=True` training mode, resnet.py:496-505): the network is well-conditioned and
+        the comparison has REAL tolerances -- loss 2e-3, stages 2e-2, gradients median 5e-2.
+      * batch statistics: more clips do NOT make this synthetic-weight network well-conditioned -- measured with 16 x 4 and 8 x 8 frames of
+        64^2 the emulation differs from ITSELF under a 1e-6 input jitter by 25 % at layer4 and O(1) in the gradients (128+ samples per
+        channel in every BatchNorm; the amplifier is 16 random-weight residual blocks after discontinuous bf16 rounding, not the sample
+        count).  There the engine is required to sit inside that self-distance, stage by stage and in the gradient statistics; the
+        well-posed bf16 evidence for batch statistics is the per-block teacher-forced test above."""
+    import mvfnet_amd
+    from oracle import net_torch
+    import torch.nn.functional as F
+    depth = 50
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    cfg = mvfnet_amd.mvfnet_config(depth, t, dropout_ratio=0.0)
+    cfg["backbone"]["norm_eval"] = bool(norm_eval)
+    m = mvfnet_amd.build_recognizer(cfg, None, dict(average_clips=None))
+    vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in m.state_dict()}, strict=True)
+    m = m.cuda().train()
+    sd_cpu = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    imgs_np, labels_np = synth.synth_clip_batch(clips, t, size, size, seed=clips), synth.synth_labels(clips, seed=clips)
+    imgs = torch.from_numpy(imgs_np)
+
+    def emulate(x):
+        if not norm_eval:
+            return _emulated_train_step(sd_cpu, x, labels_np, depth, t)
+        sd = {k: v.clone() for k, v in sd_cpu.items()}
+        leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+        stages = {}
+        with bf16_storage_oracle(backward=True):
+            f = net_torch.backbone(x.reshape((-1, 3) + x.shape[3:]), sd, depth, t, training=False, stages=stages)
+            loss = F.cross_entropy(net_torch.head(f, sd, t, training=True), torch.from_numpy(labels_np).squeeze(1))
+            loss.backward()
+        return float(loss.detach()), {k: v.detach().numpy() for k, v in stages.items()}, {k: v.grad.numpy() for k, v in leaves.items() if v.grad is not None}
+
+    ref_loss, ref_stages, ref_grads = emulate(imgs)
+    jit_loss, jit_stages, jit_grads = emulate(imgs * (1.0 + 1e-6 * torch.randn(imgs.shape, generator=torch.Generator().manual_seed(1))))
+    eng = m.train_engine(dtype=torch.bfloat16)
+    stages = {}
+    loss = float(eng.forward(imgs.cuda(), torch.from_numpy(labels_np).cuda(), stages=stages))
+    eng.backward()
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    rep = {}
+    for k, v in stages.items():
+        got = v.float().cpu().permute(0, 3, 1, 2).contiguous().numpy()
+        rep[k] = (rel_l2(got, ref_stages[k]), rel_l2(jit_stages[k], ref_stages[k]))
+    d_eng = np.array([rel_l2(eng.grad_of(params[k]).cpu().numpy(), g) for k, g in ref_grads.items()])
+    d_self = np.array([rel_l2(jit_grads[k], g) for k, g in ref_grads.items()])
+    print("bf16 end-to-end R50 T=%d x %d clips of %d^2, %s statistics: loss eng %.5f emu %.5f (jittered emu %.5f); stages (eng / self) %s; grads eng median %.2e "
+          "p90 %.2e max %.2e | self median %.2e max %.2e" % (t, clips, size, "frozen" if norm_eval else "batch", loss, ref_loss, jit_loss,
+                                                            {k: "%.1e/%.1e" % v for k, v in rep.items()}, np.median(d_eng), np.percentile(d_eng, 90), d_eng.max(),
+                                                            np.median(d_self), d_self.max()))
+    assert len(d_eng) == len(ref_grads) and np.isfinite(d_eng).all()
+    if norm_eval:
+        assert abs(loss - ref_loss) < 2e-3 * abs(ref_loss), (loss, ref_loss)
+        for k, (d, _) in rep.items():
+            assert d < 2e-2, (k, d)
+        assert np.median(d_eng) < 5e-2 and np.percentile(d_eng, 90) < 0.15, (np.median(d_eng), np.percentile(d_eng, 90))
+    else:
+        assert abs(loss - ref_loss) < 2 * abs(jit_loss - ref_loss) + 5e-3 * abs(ref_loss), (loss, ref_loss, jit_loss)
+        for k, (d, ds) in rep.items():
+            assert d < 1.5 * ds + 1e-3, (k, d, ds)
+        assert np.median(d_eng) < 1.5 * np.median(d_self) + 1e-2 and d_eng.max() < 1.5 * d_self.max() + 1e-2
+
+
 @pytest.mark.parametrize("name", sorted(BLOCK_CASES))
 def test_bf16_bottleneck_block_matches_bf16_storage_emulation(name):
     """One bottleneck (with and without MVF / stride / downsample, the golden block shapes) in bf16 storage: forward, dx and every
@@ -239,18 +309,21 @@ def _grad_norms(eng, m):
     return torch.stack([eng.grad_of(p).double().norm() for p in m.parameters()]).cpu().numpy()
 
 
-def test_c3_full_size_bf16_train_step_properties():
-    """BASELINE configs[2] at its full size (32 clips x 8 x 3 x 224^2, bf16 train step): size-independent properties.
+@pytest.mark.parametrize("cfg", [(50, 8, 32), (101, 16, 16)], ids=["C3_r50_8x8_32clips", "C4_r101_16x4_16clips"])
+def test_full_size_bf16_train_step_properties(cfg):
+    """BASELINE configs[2] (R50, 32 clips x 8 x 3 x 224^2) and [r3] configs[3] (R101, 16 clips x 16 x 3 x 224^2: 33 bottlenecks, 26 MVF
+    modules with the long temporal view) at their FULL sizes, bf16 train step: size-independent properties.
     (a) bit-reproducible: the same batch twice gives the same loss bits and the same flat gradient (no atomics anywhere);
     (b) clip-permutation invariance: batch-statistics BatchNorm, the MVF (never mixes clips) and the mean CE loss are invariant
         under a permutation of the clips (with their labels), so loss and every parameter-gradient norm agree up to summation
         order amplified by the bf16 stores;
     (c) every gradient finite, the clipped SGD step lowers the loss on the same batch."""
-    m = _model(50, 8).train()
+    depth, T, clips = cfg
+    m = _model(depth, T).train()
     eng = m.train_engine(dtype=torch.bfloat16)
     gen = torch.Generator(device="cuda").manual_seed(1234)
-    imgs = torch.randn(32, 8, 3, 224, 224, device="cuda", generator=gen)
-    labels = torch.randint(0, 400, (32, 1), device="cuda", generator=gen)
+    imgs = torch.randn(clips, T, 3, 224, 224, device="cuda", generator=gen)
+    labels = torch.randint(0, 400, (clips, 1), device="cuda", generator=gen)
     p0 = eng.flat_params.clone()
     bufs0 = [b.clone() for b in m.buffers()]
 
@@ -268,14 +341,15 @@ def test_c3_full_size_bf16_train_step_properties():
     eng.backward()
     assert torch.equal(l1, l2) and torch.equal(g1, eng.flat_grads)
     restore()
-    perm = torch.randperm(32, device="cuda", generator=gen)
+    perm = torch.randperm(clips, device="cuda", generator=gen)
     l3 = eng.forward(imgs[perm].contiguous(), labels[perm].contiguous()).clone()
     eng.backward()
     n3 = _grad_norms(eng, m)
     rel = np.abs(n3 - n1) / np.maximum(n1, 1e-12)
-    print("C3 permutation: loss %.6f vs %.6f, grad-norm rel diff median %.2e max %.2e" % (float(l1), float(l3), np.median(rel), rel.max()))
+    print("R%d T=%d x %d clips, permutation: loss %.6f vs %.6f, grad-norm rel diff median %.2e max %.2e" % (depth, T, clips, float(l1), float(l3), np.median(rel), rel.max()))
     assert abs(float(l3) - float(l1)) < 1e-3 * abs(float(l1))               # measured 3e-5
-    assert np.median(rel) < 2e-2 and rel.max() < 0.25                       # measured: median 6e-3, max 0.11 (a re-ordered sum re-diverges to the bf16 floor)
+    # measured C3: median 6e-3, max 0.11 (a re-ordered sum re-diverges to the bf16 floor); the 33-block R101 amplifies that further
+    assert np.median(rel) < (2e-2 if depth == 50 else 5e-2) and rel.max() < (0.25 if depth == 50 else 0.5)
     eng.step()
     l4 = eng.forward(imgs[perm].contiguous(), labels[perm].contiguous())
     assert float(l4) < float(l3)

@@ -74,3 +74,83 @@ def test_two_rank_train_steps_keep_replicas_bit_identical_and_buckets_equal_flat
         assert l0 != l1                                           # different clips per rank: the losses differ
         assert all(x == x for x in l0 + l1)
     assert a[0][2][0] == b[0][2][0]                               # two-bucket overlapped exchange == single collective, bit for bit
+
+
+# ------------------------------------------------------------------------------------------------ [r3] oracle semantics of the exchange
+def _worker_oracle(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import numpy as np
+    import mvfnet_amd
+    from mvfnet_amd import synth
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0), None, dict(average_clips=None))
+    sd = m.state_dict()
+    vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in sd}, strict=True)
+    m = m.cuda().train()
+    eng = m.train_engine(dtype=torch.float32, lr=0.0, momentum=0.0, weight_decay=0.0, max_norm=None)
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64, seed=10 + rank)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2, seed=10 + rank)).cuda()
+    eng.forward(imgs, labels)
+    eng.backward(exchange=False)
+    local = {k: eng.grad_of(p).cpu().numpy().copy() for k, p in m.named_parameters()}
+    eng.step()                                   # all-reduce (sum) of the flat gradient; / world is folded into the (lr = 0) update
+    torch.cuda.synchronize()
+    summed = {k: eng.grad_of(p).cpu().numpy().copy() for k, p in m.named_parameters()}
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **{"local/" + k: v for k, v in local.items()}, **{"sum/" + k: v for k, v in summed.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_exchanged_gradient_is_the_mean_of_the_oracles_per_rank_gradients(tmp_path):
+    """reference dist_utils.py:15-49 with per-GPU BatchNorm (SyncBN is commented out in the reference): the gradient a rank applies is
+    sum_r grad_r / world, grad_r = the gradient of rank r's OWN clips under rank r's OWN batch statistics.  Two real ranks (fp32
+    engine) with different clips: what the engine holds after the exchange, / world, against the mean of the CPU oracle's two
+    per-rank gradients -- and, to make sure the comparison can fail, against either single-rank gradient."""
+    import numpy as np
+    from helpers import rel_l2
+    import mvfnet_amd
+    from mvfnet_amd import synth
+    from oracle import net_torch
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_oracle, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    got = [np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(2)]
+    m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0), None, dict(average_clips=None))
+    sd0 = m.state_dict()
+    vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd0.items()})
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    oracle = []
+    for r in range(2):
+        sd = {k: torch.from_numpy(vals["r50/" + k]).clone() for k in sd0}
+        leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+        imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64, seed=10 + r))
+        labels = torch.from_numpy(synth.synth_labels(2, seed=10 + r))
+        net_torch.forward_train(imgs, labels, sd, 50).backward()
+        oracle.append({k: v.grad.numpy() for k, v in leaves.items()})
+    names = [k for k, _ in m.named_parameters()]
+    assert all(np.array_equal(got[0]["sum/" + k], got[1]["sum/" + k]) for k in names)            # both ranks hold the same summed gradient
+    flat = lambda d, pre="": np.concatenate([d[pre + k].ravel() for k in names])                # noqa: E731
+    mean_eng = flat(got[0], "sum/") / 2.0
+    mean_orc = (flat(oracle[0]) + flat(oracle[1])) / 2.0
+    # the engine's own per-rank gradients against the oracle's (the size of a legitimate fp32 difference on this 2-clip network) ...
+    d_local = [rel_l2(flat(got[r], "local/"), flat(oracle[r])) for r in range(2)]
+    # ... the exchanged mean, and the same mean against a SINGLE rank's gradient (must be far away)
+    d_mean = rel_l2(mean_eng, mean_orc)
+    d_wrong = min(rel_l2(mean_eng, flat(oracle[r])) for r in range(2))
+    per = np.array([rel_l2(got[0]["sum/" + k] / 2.0, (oracle[0][k] + oracle[1][k]) / 2.0) for k in names])
+    print("DDP oracle check: local grads vs oracle %.2e / %.2e; exchanged mean vs oracle mean %.2e (per parameter median %.2e max %.2e); vs a single rank's %.2e"
+          % (d_local[0], d_local[1], d_mean, np.median(per), per.max(), d_wrong))
+    assert np.array_equal(flat(got[0], "sum/"), flat(got[0], "local/") + flat(got[1], "local/")) or rel_l2(flat(got[0], "sum/"), flat(got[0], "local/") + flat(got[1], "local/")) < 1e-6
+    # measured: each rank's own gradient is 2.06e-2 from the oracle's (fp32 summation order through 53 batch-statistics BatchNorms on 2 clips:
+    # the oracle itself moves by that much between fp32 and fp64, DESIGN.md section 2), the exchanged mean 2.06e-2, a single rank's 0.68
+    assert d_mean < 1.25 * max(d_local) + 1e-3 and d_mean < 4e-2, (d_mean, d_local)
+    assert np.median(per) < 4e-2 and per.max() < 8e-2, (np.median(per), per.max())
+    assert d_wrong > 10 * d_mean

@@ -142,3 +142,75 @@ def test_device_prefetcher_passes_host_batches_through_without_a_gpu():
     batches = [dict(img_group=torch.full((2, 3), float(i)), label=torch.tensor([i, i])) for i in range(3)]
     out = list(DevicePrefetcher(batches, device="cpu"))
     assert len(out) == 3 and all(torch.equal(a["img_group"], b["img_group"]) for a, b in zip(out, batches))
+
+
+# ------------------------------------------------------------------------------------------------ [r3] advisor items of round 2
+def test_step_lr_warmup_kinds_and_unknown_kind_is_refused():
+    """mmcv LrUpdaterHook.get_warmup_lr: constant = ratio, linear (above), exp = ratio ** (1 - it / iters); anything else raises
+    instead of silently training without a warm-up."""
+    from mvfnet_amd.runner import step_lr
+    assert abs(step_lr(0.1, 0, 5, warmup="constant", warmup_iters=10, warmup_ratio=0.25) - 0.025) < 1e-12
+    assert abs(step_lr(0.1, 0, 5, warmup="exp", warmup_iters=10, warmup_ratio=0.25) - 0.1 * 0.25 ** 0.5) < 1e-12
+    assert abs(step_lr(0.1, 0, 10, warmup="exp", warmup_iters=10, warmup_ratio=0.25) - 0.1) < 1e-12
+    assert step_lr(0.1, 0, 3, warmup=None, warmup_iters=10) == 0.1
+    with pytest.raises(NotImplementedError):
+        step_lr(0.1, 0, 3, warmup="cosine", warmup_iters=10)
+
+
+def test_optimizer_state_carries_initial_lr_beside_the_scheduled_lr():
+    """A checkpoint written after warm-up / an lr step must resume under the reference's runner with the BASE rate as `initial_lr`
+    (mmcv's LrUpdaterHook keeps an existing key: setdefault), per group x lr_mult under paramwise options."""
+    from mvfnet_amd.checkpoint import sgd_state_dict
+    bufs = [torch.zeros(3), None, torch.ones(2)]
+    sd = sgd_state_dict(bufs, lr=0.0015, momentum=0.9, weight_decay=1e-4, initial_lr=0.015)
+    g = sd["param_groups"][0]
+    assert g["lr"] == 0.0015 and g["initial_lr"] == 0.015
+    sd2 = sgd_state_dict(bufs, lr=0.0015, momentum=0.9, weight_decay=1e-4, initial_lr=0.015, multipliers=[(1, 1), (2, 0), (1, 0.5)])
+    assert [g["initial_lr"] for g in sd2["param_groups"]] == [0.015, 0.03, 0.015]
+    assert [g["lr"] for g in sd2["param_groups"]] == [0.0015, 0.003, 0.0015]
+    assert sgd_state_dict(bufs, 0.01, 0.9, 0.0)["param_groups"][0]["initial_lr"] == 0.01          # no schedule known: the current rate
+    # torch.optim.SGD takes the dict (extra key kept in the group, as mmcv finds it)
+    ps = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(2))]
+    opt = torch.optim.SGD(ps, lr=1.0, momentum=0.9)
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]["initial_lr"] == 0.015 and opt.param_groups[0]["lr"] == 0.0015
+    opt.param_groups[0].setdefault("initial_lr", opt.param_groups[0]["lr"])                     # LrUpdaterHook.before_run
+    assert opt.param_groups[0]["initial_lr"] == 0.015
+
+
+def test_as_config_reads_an_mmcv_style_config_object():
+    from mvfnet_amd.runner import as_config
+
+    class ConfigDict(dict):                     # mmcv's ConfigDict: a dict with attribute access
+        def to_dict(self):
+            return dict(self)
+
+    class MmcvConfig(object):                   # mmcv.Config keeps everything behind _cfg_dict; vars() shows only these three names
+        def __init__(self, d):
+            self._cfg_dict, self._filename, self._text = ConfigDict(d), "x.py", "..."
+
+        def __getattr__(self, k):
+            return self._cfg_dict[k]
+
+    c = as_config(MmcvConfig(dict(optimizer=dict(type="SGD", lr=0.1), total_epochs=3)))
+    assert c.optimizer["lr"] == 0.1 and c.get("total_epochs") == 3 and c.get("_filename") is None
+    import types
+    c2 = as_config(types.SimpleNamespace(optimizer=dict(type="SGD", lr=0.2), total_epochs=1))
+    assert c2.optimizer["lr"] == 0.2
+    assert as_config(dict(a=1)).get("a") == 1
+
+
+def test_build_dataloader_keeps_the_last_partial_batch_like_the_reference():
+    from mvfnet_amd.runner import build_dataloader
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return dict(img_group=torch.zeros(2), label=torch.tensor([i]))
+
+    sizes = [len(b["label"]) for b in build_dataloader(DS(), 2, shuffle=False)]
+    assert sizes == [2, 2, 1]                                              # drop_last=False: 3 iterations per epoch, as the reference counts them
+    assert [len(b["label"]) for b in build_dataloader(DS(), 8, shuffle=False)] == [5]      # a dataset smaller than the batch still trains
+    assert [len(b["label"]) for b in build_dataloader(DS(), 2, shuffle=False, drop_last=True)] == [2, 2]

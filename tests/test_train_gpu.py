@@ -1211,3 +1211,116 @@ def test_eight_step_training_trajectory_vs_oracle_norm_eval():
     l16 = [float(e16.train_step(imgs.cuda(), labels.cuda())) for _ in range(8)]
     for a, b in zip(l16, ref_losses):
         assert abs(a - b) < 5e-2 * abs(b) + 2e-2, (l16, ref_losses)
+
+
+# ------------------------------------------------------------------------------------------------ round 3
+def test_optimizer_hooks_with_the_engine_backed_optimizer_keep_the_gradient_clip():
+    """[r3, advisor] The reference's _dist_train pairing -- build_optimizer(model, cfg.optimizer) + DistOptimizerHook(grad_clip) (train.py:
+    159-196, dist_utils.py:52-67) -- with build_optimizer's EngineSGD: the clip must reach the update (it acted on autograd's copies of the
+    gradients and was silently dropped).  With a max_norm far below the gradient norm, the hook path must equal the fused
+    train_step(max_norm) bit for bit, differ from an un-clipped step, and return the pre-clip norm like clip_grad_norm_."""
+    from mvfnet_amd.dist import DistOptimizerHook, Fp16OptimizerHook
+    from mvfnet_amd.runner import build_optimizer
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64, seed=9)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2, seed=9)).cuda()
+    ocfg = dict(type="SGD", lr=0.015, momentum=0.9, weight_decay=1e-4, nesterov=True)
+
+    def run(kind, max_norm):
+        m = _model(50, 4)
+        m.train()
+        if kind == "fused":
+            eng = m.train_engine(lr=0.015, momentum=0.9, weight_decay=1e-4, max_norm=max_norm)
+            eng.dropout = 0.0
+            for _ in range(2):
+                eng.train_step(imgs, labels)
+            return eng.flat_params.clone(), float(eng.norm_out[0])
+        m.cls_head.dropout = None
+        hook = (DistOptimizerHook if kind == "hook" else Fp16OptimizerHook)(grad_clip=None if max_norm is None else dict(max_norm=max_norm, norm_type=2))
+        opt = build_optimizer(m, ocfg)
+        total = None
+        for _ in range(2):
+            out = m(imgs, labels, return_loss=True)
+            total = hook.after_train_iter(m, opt, out["loss_cls"])
+        assert opt.engine.max_norm is None                    # the hook leaves the optimizer as it found it
+        return opt.engine.flat_params.clone(), (None if total is None else float(total))
+
+    p_fused, n_fused = run("fused", 0.05)
+    p_hook, n_hook = run("hook", 0.05)
+    p_free, n_free = run("hook", None)
+    assert n_fused > 1.0                                      # the clip is active: the norm is far above max_norm
+    assert torch.equal(p_hook, p_fused) and n_hook == n_fused
+    assert n_free is None and not torch.equal(p_free, p_fused)
+    with pytest.raises(NotImplementedError):
+        m = _model(50, 4)
+        out = m(imgs, labels, return_loss=True)
+        DistOptimizerHook(grad_clip=dict(max_norm=1.0, norm_type=1)).after_train_iter(m, build_optimizer(m, ocfg), out["loss_cls"])
+
+
+@pytest.mark.parametrize("name", sorted(BLOCK_CASES))
+def test_standalone_bottleneck_forward_is_an_autograd_node_over_the_hip_block(name):
+    """[r3] reference resnet.py:208-244: `block(x)` on its own.  Output, input gradient, every parameter gradient (through autograd:
+    y.backward(dy)) and the running statistics against the reference's own run of the block (tests/golden/block_cases.npz)."""
+    N, T, Cin, planes, H, W, stride = BLOCK_CASES[name]
+    g = golden("block_cases.npz")
+    blk = _block(name)
+    x = torch.from_numpy(synth.synth_tensor("block_x/" + name, (N * T, Cin, H, W))).cuda().requires_grad_(True)
+    y = blk(x)
+    assert y.requires_grad and rel_err(y.detach().cpu().numpy(), g[name + "/train/y"]) < 1e-5
+    y.backward(torch.from_numpy(synth.synth_tensor("block_dy/" + name, tuple(y.shape))).cuda())
+    assert rel_err(x.grad.cpu().numpy(), g[name + "/train/dx"]) < 1e-4
+    for pn, p in blk.named_parameters():
+        assert p.grad is not None and rel_err(p.grad.cpu().numpy(), g[name + "/train/grad/" + pn]) < 2e-4, pn
+    for bn_, b in blk.named_buffers():
+        ref = g[name + "/train/buf/" + bn_]
+        assert (int(b) == int(ref)) if ref.dtype.kind == "i" else (rel_err(b.cpu().numpy(), ref) < 1e-5), bn_
+    # eval mode (folded running statistics) on a FRESH block against the reference's eval run (the train forward above has updated the
+    # running statistics of `blk`, as it must); a second backward of the first output is refused
+    with torch.no_grad():
+        ye = _block(name).eval()(x.detach())
+    assert rel_err(ye.cpu().numpy(), g[name + "/eval/y"]) < 1e-4
+    with pytest.raises(RuntimeError):
+        y.backward(torch.ones_like(y))
+    with pytest.raises(RuntimeError):
+        blk(x.detach().cpu())
+
+
+def test_dist_eval_hook_with_the_references_signature_and_validate_registration(tmp_path):
+    """[r3] eval_hooks.py:86-104 / train.py:192-196: DistEvalTopKAccuracyHook(dataset, interval, k, dist) scores dataset[i] one by one in eval
+    mode and reads the labels from dataset.video_infos; train_network(validate=True) registers it for a Dataset object under cfg.data.val."""
+    from mvfnet_amd.evaluation import DistEvalTopKAccuracyHook, top_k_accuracy
+    from mvfnet_amd.runner import Config, train_network
+
+    class Val(object):
+        def __init__(self, n):
+            self.video_infos = [dict(label=int(l)) for l in synth.synth_labels(n, seed=3).ravel()]
+
+        def __len__(self):
+            return len(self.video_infos)
+
+        def __getitem__(self, i):
+            return dict(img_group=torch.from_numpy(synth.synth_clip_batch(1, 4, 64, 64, seed=40 + i)[0]), label=torch.tensor([self.video_infos[i]["label"]]))
+
+    val = Val(5)
+    m = _model(50, 4)
+    with pytest.raises(TypeError):
+        DistEvalTopKAccuracyHook(dict(type="RawFramesDataset"))
+    hook = DistEvalTopKAccuracyHook(val, interval=1, k=(1, 5), dist=False)
+
+    class R(object):
+        epoch, model = 1, m
+    out = hook.after_train_epoch(R())
+    m.eval()
+    rows = [m(val[i]["img_group"].unsqueeze(0).cuda(), None, return_loss=False).squeeze() for i in range(5)]
+    want = top_k_accuracy(rows, [v["label"] for v in val.video_infos], k=(1, 5))
+    assert out["top1 acc"] == float(want[0]) and out["top5 acc"] == float(want[1]) and m.training is False
+    batches = [dict(img_group=torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64, seed=i)), label=torch.from_numpy(synth.synth_labels(2, seed=i))) for i in range(2)]
+    cfg = Config(optimizer=dict(type="SGD", lr=0.001, momentum=0.9, weight_decay=1e-4, nesterov=True), optimizer_config=dict(grad_clip=dict(max_norm=40, norm_type=2)),
+                 lr_config=dict(policy="step", step=[90]), checkpoint_config=dict(interval=0), log_config=dict(interval=0), total_epochs=2, eval_interval=2,
+                 work_dir=str(tmp_path), data=dict(videos_per_gpu=2, workers_per_gpu=0, val=val))
+    logs = []
+    run = train_network(_model(50, 4), batches, cfg, distributed=False, validate=True, logger=logs.append)
+    assert len(run.hooks) == 1 and isinstance(run.hooks[0], DistEvalTopKAccuracyHook)
+    assert len(run.hooks[0].history) == 1 and run.hooks[0].history[0]["epoch"] == 2                 # eval_interval = 2: after the second epoch only
+    assert any("Epoch(val) [2]" in l and "top1 acc" in l for l in logs)
+    with pytest.raises(NotImplementedError):
+        train_network(_model(50, 4), batches, Config(dict(cfg, data=dict(videos_per_gpu=2, val=dict(type="RawFramesDataset")))), validate=True)
