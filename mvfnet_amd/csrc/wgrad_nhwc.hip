@@ -29,21 +29,36 @@ struct WgArgs {
     float* part;
     int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, xps, split_c, x2ps;
     int M, K, rows_per_split, tiles_k;
-    int tiles, nsplit;   // output tiles and pixel splits; the 1-D grid is 8 * ceil(nsplit / 8) * tiles (see wg_map)
+    int tiles, nsplit;   // output tiles and pixel splits; the 1-D grid is nsplit * tiles (see wg_map)
     unsigned fd_hw_mul, fd_hw_shr, fd_w_mul, fd_w_shr;   // magic numbers for n / (Ho*Wo) and n / Wo, n < 2^31 (bf16 kernel)
+    int xcd_rr;          // wg_map: 1 = splits round-robin over the XCDs (nsplit % 8 == 0), 0 = contiguous balanced ranges
+    int abl;             // -DMVF_WGRAD_ABLATE builds only (timing ablation, wrong results): 1 no main loop, 2 no partial-slab stores
 };
 
 // n / d for 0 <= n < 2^31 with host-made magic: l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, q = (mulhi(n, mul) + n) >> l
 __device__ __forceinline__ int wg_fd_div(int n, unsigned mul, unsigned shr) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shr); }
-// Workgroup -> (output tile, pixel split).  All tiles of one split read the SAME dz / x rows, so they are placed on the same
-// XCD (consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2): split s lives on XCD s % 8 and its tiles
-// are consecutive there.  With the plain (tile, split) grid every XCD re-fetched every row: 2-4x the algorithmic HBM reads
-// (rocprofv3 FETCH_SIZE, profiles/r01_pmc_summary_bf16_train.json before/after).
-__device__ __forceinline__ bool wg_map(const int tiles, const int nsplit, int& tile, int& split) {
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int sl = idx / tiles;
-    tile = idx - sl * tiles;
-    split = sl * 8 + xcd;
+// Workgroup -> (output tile, pixel split).  All tiles of one split read the SAME dz / x rows, so they should share an XCD (each has its own
+// L2; consecutive workgroup ids round-robin over the 8 XCDs): with the plain (tile, split) grid every XCD re-fetched every row, 2-4x the
+// algorithmic HBM reads (rocprofv3 FETCH_SIZE, profiles/r01_pmc_summary_bf16_train.json before/after).
+// [r3] The split-major list of (split, tile) pairs is cut into 8 CONTIGUOUS, equally long ranges, one per XCD (the bijective remap of the
+// conv kernels).  Rounds 1-2 pinned split s to XCD s % 8: with 28 splits x 9 tiles of the 256 x 256 plan that is 36 workgroups on XCDs 0-3
+// (32 CUs each: a second, nearly empty round -- twice the launch's time) and 27 on XCDs 4-7; 252 workgroups are 31-32 per XCD in one round.
+// A split that straddles two ranges is fetched by two L2s (at most 7 of them).
+// When the number of splits is a multiple of 8 the round-robin form (split s on XCD s % 8, grid = nsplit * tiles as well) is just as
+// balanced and keeps the 8 XCDs streaming one compact window of pixels instead of 8 distant ones -- measured 10 % faster on the
+// HBM-bound layer1 launches (M = 802816, K = 64: 4.2 vs 3.8 TB/s) -- so the host picks it there (WgArgs::xcd_rr).
+__device__ __forceinline__ bool wg_map(const int tiles, const int nsplit, int& tile, int& split, const int rr = 0) {
+    const int nwg = (int)gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (rr) {                                          // nsplit % 8 == 0: XCD x owns splits x, x + 8, ...
+        const int sl = idx / tiles;
+        tile = idx - sl * tiles;
+        split = sl * 8 + xcd;
+        return split < nsplit;
+    }
+    const int q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    split = id / tiles;
+    tile = id - split * tiles;
     return split < nsplit;
 }
 inline void wg_fd_make(unsigned d, unsigned& mul, unsigned& shr) {
@@ -69,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgArgs a) {
     __shared__ __attribute__((aligned(16))) float Ds[2][BMR][BCO];
     __shared__ __attribute__((aligned(16))) float Xs[2][BMR][BK];
     int wg_tile, wg_split;
-    if (!wg_map(a.tiles, a.nsplit, wg_tile, wg_split)) return;
+    if (!wg_map(a.tiles, a.nsplit, wg_tile, wg_split, a.xcd_rr)) return;
     const int tile_k = wg_tile % a.tiles_k, tile_co = wg_tile / a.tiles_k;
     const int co0 = tile_co * BCO, k0 = tile_k * BK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(WMG * 128) void wgrad_bf16_kernel(WgArgs a) {
     char* Ds = smem16;                                              // [2][BMR16][PA]
     char* Xs = smem16 + 2 * BMR16 * PA;                             // [2][BMR16][PB]
     int wg_tile, wg_split;
-    if (!wg_map(a.tiles, a.nsplit, wg_tile, wg_split)) return;
+    if (!wg_map(a.tiles, a.nsplit, wg_tile, wg_split, a.xcd_rr)) return;
     const int tile_k = wg_tile % a.tiles_k, tile_co = wg_tile / a.tiles_k;
     const int co0 = tile_co * BCO, k0 = tile_k * BK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -451,6 +466,264 @@ __global__ __launch_bounds__(WMG * 128) void wgrad_bf16_kernel(WgArgs a) {
     }
 }
 
+// ---- the 256 x 256 weight-gradient tile on the four-phase ping-pong loop (conv_nhwc.hip, conv_tile GLDS = 4; probe: tools/probes/gemm8p_probe.hip) ----
+// Same machine as the conv kernel with the roles A := im2col(X) columns (4 fragments of 32 per wave), B := dZ columns (2 fragments per wave):
+// 8 waves = 4 (co) x 2 (k), two groups (waves 0-3 / 4-7: one wave of each per SIMD) one barrier apart; a chunk = 64 pixels = 4 MFMA k-steps.
+//   X(c): read x fragments {0,1} + dz fragment 0 of chunk c       -> acc[0..1][0..1]     stage dz-half 0 (c+1), then x-half 1 (c+1)
+//   Y(c): read x fragments {2,3} of chunk c + dz fragment 1 of c+1 -> acc[0..1][2..3]     stage dz-half 1 (c+2), then x-half 0 (c+2)
+// every phase: 24 transpose reads, 4 LDS-DMA pieces, vmcnt(6) (three half tiles in flight), the 16 x reads retired before the first barrier.
+// LDS image: the contraction index (pixel) is the ROW here, so a half tile is a COLUMN range; to keep a wave's DMA footprint (1 KB)
+// contiguous the operand tiles are stored as column blocks [block of 64 channels][64 pixels][128 B] (8 KB each, 4 per operand per buffer),
+// rows XOR-swizzled on the source side as in wgrad_bf16_kernel (swz16<8>).  Fragment -> column mapping (any bijection works, the
+// partial-slab store applies the same one): x fragment j of wave column wn = columns (j >> 1) * 128 + wn * 64 + (j & 1) * 32 (x-half h =
+// columns [128 h, 128 h + 128)); dz fragment i of wave row wm = channels i * 128 + wm * 32 (dz-half i = channels [128 i, 128 i + 128)).
+__global__ __launch_bounds__(512) void wgrad_bf16_p4_kernel(WgArgs a) {
+    constexpr int kRows = BMR16;                       // 64 pixels per chunk
+    constexpr int kBlk = kRows * 128;                  // one column block: [64 pixels][64 channels] = 8 KB
+    constexpr int kBuf = 8 * kBlk;                     // x blocks 0-3, dz blocks 0-3
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    int wg_tile, wg_split;
+    if (!wg_map(a.tiles, a.nsplit, wg_tile, wg_split, a.xcd_rr)) return;
+    const int tile_k = wg_tile % a.tiles_k, tile_co = wg_tile / a.tiles_k;
+    const int co0 = tile_co * 256, k0 = tile_k * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    const int m_begin = wg_split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nchunks = (m_end - m_begin + kRows - 1) / kRows;
+    constexpr unsigned kOOB = 0x80000000u;
+    const int hw_o = a.Ho * a.Wo;
+    const bf16_t* dzp = reinterpret_cast<const bf16_t*>(a.dz);
+    const i32x4 gs_dz = rsrc_words(dzp + (long)m_begin * a.Cout, (unsigned)min((long)(m_end - m_begin) * a.Cout * 2, 0x7ffffff0L));
+    const bool x2u = a.split_c > 0 && (k0 % a.Cin) < a.split_c;            // uniform per workgroup (host: split_c % 256 == 0, cin % 256 == 0)
+    const int ps = x2u ? a.x2ps : a.xps;
+    const i32x4 gs_x = rsrc_words(x2u ? a.x2 : a.x, (unsigned)min((long)a.N * a.H * a.W * ps * 2, 0x7ffffff0L));
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)smem16);
+    // DMA piece n (0 / 1) of a half: instruction q = 2 wave + n of 16: column block (q >> 3) of the half, pixel rows (q & 7) * 8 .. + 8
+    const int drow = lane >> 3;                        // row within the 8-row piece
+    int prow[2], prow0[2], pblk[2], punit[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int q = wave * 2 + n;
+        pblk[n] = q >> 3;
+        prow0[n] = (q & 7) * 8;                         // wave-uniform: the LDS-DMA destination base must be a scalar
+        prow[n] = prow0[n] + drow;
+        punit[n] = (lane & 7) ^ swz16<8>(prow[n]);      // the source unit that belongs at LDS position lane & 7 of this row
+    }
+    // dz piece n of half h, chunk c: byte offset = (row within the split) * Cout * 2 + column; rows past the split's end are past the
+    // descriptor's range (zeros), so are all rows of a chunk past the last one
+    unsigned dz_col[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) dz_col[n] = (unsigned)(prow[n] * a.Cout + co0 + pblk[n] * 64 + punit[n] * 8) * 2u;
+    const unsigned dz_chunk = (unsigned)(kRows * a.Cout) * 2u;
+    auto stage_dz = [&](int h, int buf, int c) {       // channels [co0 + 128 h, + 128) of the chunk's 64 pixels
+#ifdef MVF_WGRAD_ABLATE
+        if ((a.abl & 32) && c >= 2) return;
+#endif
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            glds16(gs_dz, lds0 + (unsigned)(buf * kBuf + (4 + h * 2 + pblk[n]) * kBlk + prow0[n] * 128),
+                   c < nchunks ? dz_col[n] + (unsigned)c * dz_chunk + (unsigned)h * 256u : kOOB);
+    };
+    // x piece n of half h: its 64-column block lies inside ONE tap (host: cin % 64 == 0) -> tap and channel offset are per-thread constants;
+    // the pixel decomposition (two magic divisions per row) is done ONCE per chunk for the thread's two rows, by x_offsets(), which the
+    // loop calls inside the MFMA block of a phase: beside the wave's own matrix instructions VALU issue is nearly free, while in the
+    // load segment (the partner wave holds the matrix pipe at raised priority) every VALU instruction is on the critical path.
+    int x_kh[2][2], x_kw[2][2];
+    unsigned x_cofs[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int kcol = k0 + h * 128 + pblk[n] * 64;
+            const int tap = kcol / a.Cin, ci = kcol - tap * a.Cin + punit[n] * 8;
+            x_kh[h][n] = tap / a.KW;
+            x_kw[h][n] = tap - x_kh[h][n] * a.KW;
+            x_cofs[h][n] = (unsigned)((x_kh[h][n] * a.W + x_kw[h][n]) * ps + ci) * 2u;
+        }
+    unsigned xo[2][2];                                 // [half][piece] byte offsets of the chunk prepared last (out of range = zeros)
+    // x_step(q, c), q = 0..15: the q-th slice (about five VALU instructions) of chunk c's offset arithmetic -- rows n = q >> 3, stages
+    // q & 7 -- so that phase X can issue one slice behind each of its 16 matrix instructions (left to itself the scheduler puts all
+    // ~75 instructions behind the last MFMA, where they delay the barrier; sched_group_barrier pipelines were not honoured here)
+    int t_m[2], t_img[2], t_rem[2], t_oh[2], t_ih0[2], t_iw0[2], t_live[2];
+    unsigned t_q[2], t_base[2];
+    auto x_step = [&](int q, int c) {
+        const int n = q >> 3;
+        // (every slice ends by making its result opaque: otherwise the sinking passes move the whole chain down to its use, the DMA
+        // statements of the NEXT phase's load segment -- exactly where it must not be)
+#define MVF_KEEP(v) asm volatile("" : "+v"(v))
+        switch (q & 7) {
+        case 0: t_m[n] = m_begin + c * kRows + prow[n]; t_q[n] = __umulhi((unsigned)t_m[n], a.fd_hw_mul); MVF_KEEP(t_q[n]); break;
+        case 1: t_img[n] = (int)((t_q[n] + (unsigned)t_m[n]) >> a.fd_hw_shr); t_rem[n] = t_m[n] - t_img[n] * hw_o; MVF_KEEP(t_rem[n]); break;
+        case 2: t_oh[n] = (int)((__umulhi((unsigned)t_rem[n], a.fd_w_mul) + (unsigned)t_rem[n]) >> a.fd_w_shr); MVF_KEEP(t_oh[n]); break;
+        case 3: t_ih0[n] = t_oh[n] * a.stride - a.pad; t_iw0[n] = (t_rem[n] - t_oh[n] * a.Wo) * a.stride - a.pad; MVF_KEEP(t_ih0[n]); MVF_KEEP(t_iw0[n]); break;
+        case 4: t_base[n] = (unsigned)(((t_img[n] * a.H + t_ih0[n]) * a.W + t_iw0[n]) * ps) * 2u; MVF_KEEP(t_base[n]); break;       // (may wrap for a padded corner; valid taps land in range)
+        case 5: t_live[n] = (c < nchunks && t_m[n] < m_end) ? 1 : 0; MVF_KEEP(t_live[n]); break;
+        case 6: xo[0][n] = (t_live[n] && (unsigned)(t_ih0[n] + x_kh[0][n]) < (unsigned)a.H && (unsigned)(t_iw0[n] + x_kw[0][n]) < (unsigned)a.W) ? t_base[n] + x_cofs[0][n] : kOOB; MVF_KEEP(xo[0][n]); break;
+        default: xo[1][n] = (t_live[n] && (unsigned)(t_ih0[n] + x_kh[1][n]) < (unsigned)a.H && (unsigned)(t_iw0[n] + x_kw[1][n]) < (unsigned)a.W) ? t_base[n] + x_cofs[1][n] : kOOB; MVF_KEEP(xo[1][n]); break;
+        }
+#undef MVF_KEEP
+    };
+    auto x_offsets = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x_step(q, c);
+    };
+    auto stage_x = [&](int h, int buf) {               // im2col columns [k0 + 128 h, + 128) of the chunk x_offsets() prepared
+#ifdef MVF_WGRAD_ABLATE
+        if (a.abl & 32) return;
+#endif
+#pragma unroll
+        for (int n = 0; n < 2; ++n) glds16(gs_x, lds0 + (unsigned)(buf * kBuf + (h * 2 + pblk[n]) * kBlk + prow0[n] * 128), xo[h][n]);
+    };
+    // transpose reads (wgrad_bf16_kernel): 16-lane group g supplies pixel rows (i >> 2) + 8 (g >> 1), channel quad 16 (g & 1) + 4 (i & 3)
+    const int tg = lane >> 4, ti = lane & 15;
+    const int trow = (ti >> 2) + 8 * (tg >> 1);
+    const int tunit = 2 * (tg & 1) + ((ti & 3) >> 1), thalf = ti & 1;
+    // fragment = 32 channels = units [4 f, 4 f + 4) of a 128-byte row, f = 0 / 1
+    const int tofs0 = trow * 128 + (((0 * 4 + tunit) ^ swz16<8>(trow)) * 16) + thalf * 8;
+    const int tofs1 = trow * 128 + (((1 * 4 + tunit) ^ swz16<8>(trow)) * 16) + thalf * 8;
+    auto gather = [&](const char* p) {
+        typedef short v4s __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s* lds_v4s;
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p + 4 * 128));
+        bf16x8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return v;
+    };
+    // x fragment j: half j >> 1, block wn of the half, row half j & 1;  dz fragment i: half i, block wm >> 1 of the half, row half wm & 1
+    auto fetch_x = [&](int buf, int j, bf16x8_t (&f)[4]) {
+#ifdef MVF_WGRAD_ABLATE
+        if (a.abl & 16) { for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(f[ks])); return; }
+#endif
+        const char* p = smem16 + buf * kBuf + ((j >> 1) * 2 + wn) * kBlk + ((j & 1) ? tofs1 : tofs0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) f[ks] = gather(p + ks * 16 * 128);
+    };
+    const int dofs = (wm & 1) ? tofs1 : tofs0;
+    auto fetch_dz = [&](int buf, int i, bf16x8_t (&f)[4]) {
+#ifdef MVF_WGRAD_ABLATE
+        if (a.abl & 16) { for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(f[ks])); return; }
+#endif
+        const char* p = smem16 + buf * kBuf + (4 + i * 2 + (wm >> 1)) * kBlk + dofs;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) f[ks] = gather(p + ks * 16 * 128);
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#define MVF_PIN2(x, y) asm volatile("" : "+v"(x), "+v"(y))
+#ifdef MVF_WGRAD_ABLATE
+#define MVF_WG_PRIO(v) do { if (!(a.abl & 4)) __builtin_amdgcn_s_setprio(v); } while (0)
+#else
+#define MVF_WG_PRIO(v) __builtin_amdgcn_s_setprio(v)
+#endif
+    // prologue in the steady-state issue order: chunk 0 whole, then dz-half 1 and x-half 0 of chunk 1
+    x_offsets(0);
+    stage_dz(1, 0, 0); stage_x(0, 0); stage_dz(0, 0, 0); stage_x(1, 0);
+    x_offsets(1);                                      // its half 1 is staged by X(0)
+    stage_dz(1, 1, 1); stage_x(0, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8_t fx[2][4] = {}, fd0[4] = {}, fd1a[4] = {}, fd1b[4] = {};
+    fetch_dz(0, 1, fd1a);
+    if (grp == 1) __builtin_amdgcn_s_barrier();        // the second group runs one barrier behind the first
+    auto phase_x = [&](int c, int buf, bf16x8_t (&d1)[4]) {
+        fetch_x(buf, 0, fx[0]);
+        fetch_x(buf, 1, fx[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_dz(buf, 0, fd0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_dz(0, buf ^ 1, c + 1);
+        stage_x(1, buf ^ 1);                               // x-half 1 of chunk c + 1 (offsets from the previous X phase's MFMA block)
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(8)" ::: "memory");        // x reads (16, issued first) retired: their slot is restaged next phase
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MVF_PIN2(acc[0][0], acc[0][1]); MVF_PIN2(acc[1][0], acc[1][1]);
+        MVF_WG_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                   // one slice of chunk c + 2's offset arithmetic behind every matrix instruction
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd0[ks], fx[0][ks], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); x_step(4 * ks + 0, c + 2); __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd0[ks], fx[1][ks], acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); x_step(4 * ks + 1, c + 2); __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1[ks], fx[0][ks], acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); x_step(4 * ks + 2, c + 2); __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1[ks], fx[1][ks], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); x_step(4 * ks + 3, c + 2); __builtin_amdgcn_sched_barrier(0);
+        }
+        MVF_WG_PRIO(0);
+        MVF_PIN2(acc[0][0], acc[0][1]); MVF_PIN2(acc[1][0], acc[1][1]);
+        __builtin_amdgcn_s_barrier();
+    };
+    auto phase_y = [&](int c, int buf, bf16x8_t (&d1)[4], bf16x8_t (&d1n)[4]) {
+        fetch_x(buf, 2, fx[0]);
+        fetch_x(buf, 3, fx[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_dz(buf ^ 1, 1, d1n);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_dz(1, buf, c + 2);
+        stage_x(0, buf);                                   // x-half 0 of chunk c + 2 (offsets from this chunk's X phase)
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MVF_PIN2(acc[0][2], acc[0][3]); MVF_PIN2(acc[1][2], acc[1][3]);
+        MVF_WG_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd0[ks], fx[0][ks], acc[0][2], 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd0[ks], fx[1][ks], acc[0][3], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1[ks], fx[0][ks], acc[1][2], 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1[ks], fx[1][ks], acc[1][3], 0, 0, 0);
+        }
+        MVF_WG_PRIO(0);
+        MVF_PIN2(acc[0][2], acc[0][3]); MVF_PIN2(acc[1][2], acc[1][3]);
+        __builtin_amdgcn_s_barrier();
+    };
+#ifdef MVF_WGRAD_ABLATE
+    const int nloop = (a.abl & 1) ? 0 : nchunks;
+#else
+    const int nloop = nchunks;
+#endif
+    for (int c = 0; c < nloop; c += 2) {
+        phase_x(c, 0, fd1a);
+        phase_y(c, 0, fd1a, fd1b);
+        if (c + 1 < nchunks) {
+            phase_x(c + 1, 1, fd1b);
+            phase_y(c + 1, 1, fd1b, fd1a);
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef MVF_PIN2
+#ifdef MVF_WGRAD_ABLATE
+    if (a.abl & 2) {
+        if (acc[0][0][0] == 123.456f) a.part[0] = acc[1][3][5];      // keep the accumulators live
+        return;
+    }
+#endif
+    // partial[split][co][kcol] with the fragment -> column maps above
+    float* outp = a.part + (long)wg_split * a.Cout * a.K;
+    const int lr = lane >> 5, lc = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = k0 + (j >> 1) * 128 + wn * 64 + (j & 1) * 32 + lc;
+        if (col >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + i * 128 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
+                if (row < a.Cout) outp[(long)row * a.K + col] = acc[i][j][r];
+            }
+    }
+}
+
 template <int TM, int TN>
 int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
     constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
@@ -468,7 +741,7 @@ int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
             MVF_HIP_OK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_d = true;
         }
-        hipLaunchKernelGGL(kd, dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), lds, st, a);
+        hipLaunchKernelGGL(kd, dim3(nsplit * tiles), dim3(kThreads), lds, st, a);
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
@@ -478,7 +751,7 @@ int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
         MVF_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(nsplit * tiles), dim3(kThreads), lds, st, a);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -486,12 +759,21 @@ int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
 int launch_wgrad_bf16_big(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * BMR16 * (256 * 2 + 256 * 2);
     auto kd = wgrad_bf16_kernel<2, 4, true, 4>;
+    auto kp = wgrad_bf16_p4_kernel;
     static bool attr_d = false;
     if (!attr_d) {
         MVF_HIP_OK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_d = true;
     }
-    hipLaunchKernelGGL(kd, dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(512), lds, st, a);
+    // the four-phase ping-pong loop carries the tile when a 64-column block lies inside one tap (MVF_WGRAD_P4=0: the two-barrier loop)
+    static const int p4_on = getenv("MVF_WGRAD_P4") ? atoi(getenv("MVF_WGRAD_P4")) : 1;
+    if (p4_on && a.Cin % 64 == 0) {
+        hipLaunchKernelGGL(kp, dim3(nsplit * tiles), dim3(512), lds, st, a);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
+    hipLaunchKernelGGL(kd, dim3(nsplit * tiles), dim3(512), lds, st, a);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -696,6 +978,11 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
     a.tiles = tiles;
     a.nsplit = nsplit;
+    static const int map_env = getenv("MVF_WGRAD_MAP") ? atoi(getenv("MVF_WGRAD_MAP")) : -1;      // A/B: 0 balanced ranges everywhere, 1 round-robin wherever legal
+    a.xcd_rr = (nsplit % 8 == 0) && map_env != 0;
+#ifdef MVF_WGRAD_ABLATE
+    a.abl = getenv("MVF_WGRAD_ABL") ? atoi(getenv("MVF_WGRAD_ABL")) : 0;
+#endif
     wg_fd_make((unsigned)(a.Ho * a.Wo), a.fd_hw_mul, a.fd_hw_shr);
     wg_fd_make((unsigned)a.Wo, a.fd_w_mul, a.fd_w_shr);
     hipStream_t st = (hipStream_t)stream;
@@ -707,13 +994,13 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
                        ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
                        (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 4 < 0x7ffffff0L && ((long)a.rows_per_split + 64) * d->cout * 4 < 0x7ffffff0L;
     if (dma32) {
-        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2, true>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
-        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1, true>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2, true>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
+        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2, true>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
+        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1, true>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2, true>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
     } else if (d->dtype == MVF_F32) {
-        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
-        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
+        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
+        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
     } else if (d->cin % 8 == 0 && d->cout % 8 == 0 && d->x_pix_stride % 4 == 0 && (d->split_c % 8) == 0 &&
                ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
                ((long)a.rows_per_split + 6 * 64) * d->cout * 2 < 0x7ffffff0L) {      // 32-bit split-relative dz offsets (incl. look-ahead chunks)
@@ -724,9 +1011,9 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
         else rc = launch_wgrad_bf16<2, 2>(a, tiles, nsplit, st);
         if (rc) return rc;
     } else {     // odd channel counts: widen to fp32 on the way into LDS
-        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 2>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
-        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 1>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 2>), dim3(((nsplit + 7) / 8) * 8 * tiles), dim3(kThreads), 0, st, a);
+        if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 2>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
+        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 1>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 2>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
     }
     MVF_LAUNCH_CHECK();
     const long total = (long)d->cout * d->kh * d->kw * d->cin;

@@ -318,7 +318,10 @@ def test_strided_dgrad_bnsums_equals_separate_reduce(shape, dtype):
 # (n, h, w, cin, cout, k, stride, pad)
 GRAD_CASES = [(2, 8, 8, 64, 32, 1, 1, 0), (2, 9, 9, 32, 64, 3, 1, 1), (2, 10, 10, 32, 32, 3, 2, 1), (3, 8, 8, 64, 128, 1, 2, 0),
               (1, 14, 14, 256, 256, 3, 1, 1), (2, 7, 7, 132, 36, 3, 1, 1),
-              (150, 1, 1, 64, 64, 1, 1, 0), (3, 2, 33, 64, 96, 3, 1, 1), (5, 13, 11, 128, 64, 3, 2, 1), (2, 20, 20, 64, 256, 1, 1, 0)]
+              (150, 1, 1, 64, 64, 1, 1, 0), (3, 2, 33, 64, 96, 3, 1, 1), (5, 13, 11, 128, 64, 3, 2, 1), (2, 20, 20, 64, 256, 1, 1, 0),
+              # [r3] shapes of the 256 x 256 weight-gradient tile (cout % 256 == 0, K % 256 == 0, cin % 64 == 0): 6 / 7 / 11 pixel chunks incl.
+              # ragged last ones, stride 2, more than one split (M = 1452 -> 256-row splits), 512-wide output
+              (4, 9, 9, 256, 512, 1, 1, 0), (7, 8, 8, 512, 256, 1, 1, 0), (2, 13, 11, 256, 256, 3, 2, 1), (12, 11, 11, 256, 256, 1, 1, 0)]
 
 
 @pytest.mark.parametrize("case", GRAD_CASES, ids=lambda c: "n%d_%dx%d_c%d_o%d_k%d_s%d" % c[:7])
@@ -995,8 +998,8 @@ def test_process_group_does_not_cost_the_stream_overlap():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2", "MVF_WGRAD_DMA_F32=0"],
-                         ids=["register_staged_wgrad", "lds_dma_wgrad_everywhere", "register_staged_wgrad_f32"])
+@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2", "MVF_WGRAD_DMA_F32=0", "MVF_WGRAD_P4=0", "MVF_WGRAD_BIG=0"],
+                         ids=["register_staged_wgrad", "lds_dma_wgrad_everywhere", "register_staged_wgrad_f32", "big_tile_two_barrier_loop", "no_big_tile"])
 def test_wgrad_loader_variants_forced_by_env(env):
     """The weight-gradient loader choice is a per-process policy; both forced settings re-run this file's gradient comparisons
     (conv weight gradients vs the oracle, whole-network goldens) in a child process."""
