@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--eager-seconds", type=float, default=150.0, help="wall-clock bound per eager comparator run")
     ap.add_argument("--streams", type=int, default=2, help="infer: independent clip-group launch chains (HIP streams)")
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch timing table to stderr")
+    ap.add_argument("--host-input", action="store_true",
+                    help="train mode: every step's batch starts in (pinned) HOST memory and is uploaded by runner.DevicePrefetcher one batch ahead "
+                         "on a copy stream, as a data-loader-fed run does (reference: MMDistributedDataParallel.scatter, parallel/distributed.py:40-62); "
+                         "the JSON line then carries `host_input` with the H2D bytes per step.  `value` of the default run stays the HBM-resident one")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default 1-GPU train run only: skip the short runs of BASELINE.json's other configurations (configs[1] fp32 inference, "
                          "configs[3] R101 16x4 bf16 train, configs[4] 30-clip video) that are appended as `other_configs` AFTER the timed region")
@@ -531,6 +535,27 @@ def main():
 
         def step():
             return eng.train_step(imgs, labels)
+
+        if args.host_input:
+            from mvfnet_amd.runner import DevicePrefetcher
+            host = dict(img_group=imgs.cpu().pin_memory(), label=labels.cpu().pin_memory())
+
+            class _Loader(object):              # the same host batch again and again: every step pays its own upload
+                def __init__(self, n):
+                    self.n = n
+
+                def __len__(self):
+                    return self.n
+
+                def __iter__(self):
+                    for _ in range(self.n):
+                        yield host
+
+            feed = iter(DevicePrefetcher(_Loader(10 ** 9)))           # (also feeds the extra steps of the replica verification)
+
+            def step():                         # noqa: F811
+                data = next(feed)
+                return eng.train_step(data["img_group"], data["label"])
     else:
         model.backbone.engine().streams = args.streams
 
@@ -557,8 +582,12 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     assert torch.isfinite(out).all()
+    rank_ms = None
     if dist is not None:
         t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     replicas = None
@@ -587,6 +616,11 @@ def main():
                                       ("replicas x%d (clips sharded, no collective)" % world)},
             "model_tflops": round(value * flop_clip / 1e12, 2),
         }
+        if rank_ms is not None:
+            res["rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "all": [round(v, 3) for v in rank_ms]}
+        if train and args.host_input:
+            res["host_input"] = {"h2d_bytes_per_step": int(imgs.numel() * imgs.element_size() + labels.numel() * labels.element_size()),
+                                 "path": "pinned host batch -> runner.DevicePrefetcher (copy stream, one batch ahead) -> train_step"}
         if replicas is not None:
             res["replicas"] = replicas
         if video:

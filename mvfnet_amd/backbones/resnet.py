@@ -103,6 +103,7 @@ class _BlockFn(torch.autograd.Function):
         tr = ctx.tr
         if ctx.token != getattr(tr, "forward_token", 0):
             raise RuntimeError("Bottleneck: backward() of an output whose activations are gone (the block keeps one forward)")
+        tr.forward_token += 1                               # one backward per forward: the block's activations are consumed
         dx = tr.backward(gy.contiguous())
         grads = []
         for p in tr.model.parameters():

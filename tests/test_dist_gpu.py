@@ -21,13 +21,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, overlap):
+def _worker(rank, world, port, q, overlap, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import numpy as np
     import mvfnet_amd
     from mvfnet_amd import synth
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo: both ranks on cuda:0 (a 1-GPU box); nccl (= RCCL, only when >= 2 devices are visible): one device per rank
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0), None, dict(average_clips=None))
     sd = m.state_dict()
     vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()})
@@ -49,11 +50,11 @@ def _worker(rank, world, port, q, overlap):
     dist.destroy_process_group()
 
 
-def _run(overlap):
+def _run(overlap, backend="gloo"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap, backend)) for r in range(2)]
     for p in procs:
         p.start()
     out = sorted(q.get(timeout=280) for _ in range(2))
@@ -74,6 +75,16 @@ def test_two_rank_train_steps_keep_replicas_bit_identical_and_buckets_equal_flat
         assert l0 != l1                                           # different clips per rank: the losses differ
         assert all(x == x for x in l0 + l1)
     assert a[0][2][0] == b[0][2][0]                               # two-bucket overlapped exchange == single collective, bit for bit
+    if torch.cuda.device_count() >= 2:
+        # [r3] a multi-GPU node: the same two ranks over RCCL (one device each).  Replicas bit-identical, two buckets == one collective;
+        # the summed gradient may differ from gloo's in the last bit (another reduction order), so no cross-backend bit comparison
+        c = _run(True, "nccl")
+        d = _run(False, "nccl")
+        for out in (c, d):
+            (r0, l0, c0, g0, n0), (r1, l1, c1, g1, n1) = out
+            assert c0[0] == c0[1] == c1[0] == c1[1] and g0 == g1 and n0 == n1
+        assert c[0][2][0] == d[0][2][0]
+        assert [abs(x - y) < 1e-3 * abs(y) for x, y in zip(c[0][1], a[0][1])] == [True] * 3      # same losses as the gloo run, rank 0
 
 
 # ------------------------------------------------------------------------------------------------ [r3] oracle semantics of the exchange
