@@ -173,7 +173,11 @@ class DevicePrefetcher(object):
     """Wraps a loader of host batches (dicts of CPU tensors): each batch is copied into pinned staging memory and uploaded on a
     copy stream ONE BATCH AHEAD of the consumer, so the H2D copy (154 MB fp32 / 38.5 MB uint8 per 32-clip step) overlaps the
     previous step's kernels instead of sitting at the head of the step (reference: MMDistributedDataParallel.scatter on the
-    compute stream's critical path, parallel/distributed.py:54-62).  Batches already on the device pass through."""
+    compute stream's critical path, parallel/distributed.py:54-62).  Batches already on the device pass through.
+    [r3] A batch that is already pinned (DataLoader(pin_memory=True)) is uploaded straight from where it lies -- the staging memcpy of
+    154 MB costs the host ~12 ms per step, more than the upload itself -- and lands in one of two PERSISTENT device buffers per key
+    (no allocator traffic); a slot is refilled only after the step that read it (an event on the consumer's stream, waited for by
+    the copy stream, never by the host).  The yielded tensors are therefore valid until the batch after the next is requested."""
 
     def __init__(self, loader, device=None):
         self.loader, self.device = loader, torch.device(device or "cuda")
@@ -181,6 +185,8 @@ class DevicePrefetcher(object):
         self.dataset = getattr(loader, "dataset", None)
         self._copy = None
         self._pinned = [{}, {}]
+        self._device = [{}, {}]
+        self._consumed = [None, None]      # the consumer's last kernel that READ each device slot: the next upload into it waits for that
         self._slot_event = [None, None]      # the upload that last READ each staging slot: must be complete before the host refills it
 
     def __len__(self):
@@ -190,17 +196,27 @@ class DevicePrefetcher(object):
         out, any_host = {}, False
         if self._slot_event[slot] is not None:
             self._slot_event[slot].synchronize()      # two batches old: normally long done, never skipped
+        if self._consumed[slot] is not None:          # the device buffers of this slot were read by the step two batches ago:
+            torch.cuda.current_stream().wait_event(self._consumed[slot])      # the copy stream waits for that step, the host does not
         for k, v in batch.items():
             if not isinstance(v, torch.Tensor) or v.is_cuda:
                 out[k] = v
                 continue
             any_host = True
-            pin = self._pinned[slot].get(k)
-            if pin is None or pin.shape != v.shape or pin.dtype != v.dtype:
-                pin = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
-                self._pinned[slot][k] = pin
-            pin.copy_(v)
-            out[k] = pin.to(self.device, non_blocking=True)
+            src = v
+            if not v.is_pinned():                     # pageable memory: stage through this slot's pinned buffer (a loader with pin_memory=True skips this copy)
+                pin = self._pinned[slot].get(k)
+                if pin is None or pin.shape != v.shape or pin.dtype != v.dtype:
+                    pin = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                    self._pinned[slot][k] = pin
+                pin.copy_(v)
+                src = pin
+            dev = self._device[slot].get(k)           # persistent device-side landing buffers, two slots: no allocator traffic per step
+            if dev is None or dev.shape != v.shape or dev.dtype != v.dtype:
+                dev = torch.empty(v.shape, dtype=v.dtype, device=self.device)
+                self._device[slot][k] = dev
+            dev.copy_(src, non_blocking=True)
+            out[k] = dev
         ev = None
         if any_host:
             ev = torch.cuda.Event()
@@ -229,14 +245,16 @@ class DevicePrefetcher(object):
         nxt = fetch()
         while nxt is not None:
             cur, ev = nxt
+            cur_slot = slot
             slot ^= 1
             nxt = fetch()                                  # the next batch's copy is in flight while the consumer runs this one
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
-                for v in cur.values():
-                    if isinstance(v, torch.Tensor) and v.is_cuda:
-                        v.record_stream(torch.cuda.current_stream())
             yield cur
+            if ev is not None:                             # the consumer has queued its work on this batch: mark the slot's last reader
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream())
+                self._consumed[cur_slot] = done
 
 
 def build_dataloader(dataset, videos_per_gpu, workers_per_gpu=0, dist_mode=False, shuffle=True, drop_last=False, pin_memory=False):

@@ -1327,3 +1327,23 @@ def test_dist_eval_hook_with_the_references_signature_and_validate_registration(
     assert any("Epoch(val) [2]" in l and "top1 acc" in l for l in logs)
     with pytest.raises(NotImplementedError):
         train_network(_model(50, 4), batches, Config(dict(cfg, data=dict(videos_per_gpu=2, val=dict(type="RawFramesDataset")))), validate=True)
+
+
+def test_device_prefetcher_slot_reuse_waits_for_the_consumers_kernels():
+    """[r3] DevicePrefetcher keeps two persistent device buffers per key: the upload of batch k + 2 into the slot batch k used must wait (on the
+    copy stream) for the consumer's ASYNCHRONOUS work on batch k.  The consumer parks a ~20 ms spin kernel in front of its read of every batch,
+    so an upload that does not wait would overwrite the data first; pinned and pageable host batches alternate."""
+    from mvfnet_amd.runner import DevicePrefetcher
+    host = []
+    for i in range(7):
+        t = torch.full((1 << 20,), float(i + 1))
+        host.append(dict(x=t.pin_memory() if i % 2 else t, tag=i))
+    sums, ptrs = [], set()
+    for b in DevicePrefetcher(host):
+        assert b["x"].is_cuda and b["tag"] == len(sums)
+        ptrs.add(b["x"].data_ptr())
+        torch.cuda._sleep(40_000_000)                       # the consumer's kernels are far behind the host
+        sums.append(b["x"].double().sum())
+    torch.cuda.synchronize()
+    assert [float(s) for s in sums] == [float((i + 1) * (1 << 20)) for i in range(7)]
+    assert len(ptrs) == 2                                   # two persistent landing buffers, no per-batch allocation
