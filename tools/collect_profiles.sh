@@ -9,13 +9,13 @@ O=$R/gpurun_out/prof_$DT
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 STEPS=6; [ "$DT" = f32 ] && STEPS=4
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$DT -- python $R/bench.py --dtype $DT --steps $STEPS --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$DT -- python $R/bench.py --dtype $DT --steps $STEPS --warmup 2 --no-cpu-baseline --no-other-configs > $O/stats.log 2>&1
 cp $(find /tmp/ks_$DT -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kn_$DT -- python $R/bench.py --dtype $DT --steps $STEPS --warmup 2 --no-cpu-baseline --no-overlap > $O/stats_nooverlap.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kn_$DT -- python $R/bench.py --dtype $DT --steps $STEPS --warmup 2 --no-cpu-baseline --no-other-configs --no-overlap > $O/stats_nooverlap.log 2>&1
 cp $(find /tmp/kn_$DT -name "*kernel_stats.csv" | head -1) $O/kernel_stats_nooverlap.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$DT -- python $R/bench.py --dtype $DT --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$DT -- python $R/bench.py --dtype $DT --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$DT -- python $R/bench.py --dtype $DT --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$DT -- python $R/bench.py --dtype $DT --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > $O/write.log 2>&1
 python $R/tools/pmc_summary.py /tmp/pf_$DT /tmp/pw_$DT > $O/pmc_summary.json 2> $O/pmc_summary.err
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d /tmp/sq_$DT -- python $R/bench.py --dtype $DT --no-cpu-baseline --no-overlap --steps 1 --warmup 1 > $O/sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d /tmp/sq_$DT -- python $R/bench.py --dtype $DT --no-cpu-baseline --no-other-configs --no-overlap --steps 1 --warmup 1 > $O/sq.log 2>&1
 python $R/tools/sq_summary.py $O/sq_counters.json $(find /tmp/sq_$DT -name "*.db") > $O/sq_summary.txt 2>&1
 tail -1 $O/stats.log | cut -c1-200

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The table of DESIGN.md section 5: every bench configuration once (gpurun box). Output: gpurun_out/final_numbers.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/final_numbers.txt; : > $O
-run() { echo "## bench.py $*" >> $O; timeout 900 python $R/bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> $O; }
+run() { echo "## bench.py $*" >> $O; timeout 900 python $R/bench.py --no-cpu-baseline --no-other-configs "$@" 2>/dev/null | tail -1 >> $O; }
 run --steps 20 --warmup 5
 run --steps 20 --warmup 5
 run --dtype f32
