@@ -280,3 +280,54 @@ def test_mvf_fused_into_conv_loader_equals_stencil_then_conv(case, dtype, mode, 
     wq = wgt.to(dtype).float().cpu()
     ref = F.relu(F.conv2d(torch.from_numpy(xin), wq, bias.cpu())).permute(0, 2, 3, 1).numpy()
     assert rel_err(y1.float().cpu().numpy(), ref) < (2e-5 if dtype == torch.float32 else 1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ [r3] race screen of the four-phase loops
+def _race_child():
+    """Runs in a child process with the 256 x 256 tiles forced: the SAME conv / weight gradient 40 times at the BASELINE layer3 size while a
+    copy kernel on another stream perturbs the timing; every output must equal the first bit for bit (an LDS hazard in the ping-pong loops --
+    a read ahead of its DMA, a slot restaged under a late reader -- shows up as a rare different tile, never as a deterministic error)."""
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    torch.manual_seed(5)
+    n, hw, cin, cout, k = 256, 14, 256, 256, 3
+    m = n * hw * hw
+    x = torch.randn(n, hw, hw, cin, device="cuda").bfloat16()
+    wp = (torch.randn(cout, k, k, cin, device="cuda") * 0.03).bfloat16()
+    dz = torch.randn(m, cout, device="cuda").bfloat16()
+    d = _lib.ConvDesc(n, hw, hw, cin, cout, k, k, 1, 1, hw, hw, cin, 1, 0, 0, 0, 0, 0)
+    ws = torch.empty(lib.mvf_conv2d_workspace_bytes(C.byref(d)), dtype=torch.uint8, device="cuda")
+    rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+    shift = torch.zeros(cout, device="cuda")
+    wws = torch.empty(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device="cuda")
+    junk_a, junk_b = torch.empty(1 << 28, dtype=torch.uint8, device="cuda"), torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    first = None
+    for it in range(40):
+        if it % 3:
+            with torch.cuda.stream(side):
+                junk_b.copy_(junk_a)                       # ~0.1 ms of HBM streaming beside the GEMMs, on and off
+        y = torch.empty(m, cout, device="cuda", dtype=torch.bfloat16)
+        part = torch.empty(cout, rows, 2, device="cuda")
+        check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), p(x), None, p(wp), p(y), p(part), p(shift), p(ws), ws.numel(), None))
+        dw = torch.empty(cout, cin, k, k, device="cuda")
+        check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), p(dz), p(x), None, k, cin, k, cin, p(dw), p(wws), wws.numel(), None))
+        torch.cuda.synchronize()
+        if first is None:
+            first = (y.clone(), part.clone(), dw.clone())
+            assert torch.isfinite(y.float()).all() and torch.isfinite(dw).all() and float(dw.abs().max()) > 0
+        else:
+            assert torch.equal(y, first[0]) and torch.equal(part, first[1]), "conv tile differs in run %d" % it
+            assert torch.equal(dw, first[2]), "weight gradient differs in run %d" % it
+    print("race screen ok")
+
+
+def test_four_phase_loops_are_run_to_run_bit_identical_under_a_perturbing_stream():
+    import os
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_conv_gpu as t; t._race_child()" % (
+        os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVF_CONV_BIG2="1", MVF_CONV_BIG2_FORCE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "race screen ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
