@@ -200,6 +200,11 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         nbytes = esz * (in_px * (4 if self.stem else self.cin) + n * ho * wo * self.cout + self.w.numel())
         return (2.0 * n * ho * wo * self.cout * k_alg, "fwd   M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)
 
+    def dfap(self, out, d, x, bn, residual, rbn, o, bits, ws):      # conv3 again + bn3 apply + residual + ReLU + sign bits (no z3 read)
+        m = d.n * d.ho * d.wo
+        nbytes = esz * (m * self.cin + 2 * m * self.cout + self.w.numel()) + m * self.cout // 4
+        return (2.0 * m * self.cout * self.cin, "fwd+bn M%d N%d K%d s%d" % (m, self.cout, self.cin, self.stride), nbytes)
+
     def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
         fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin          # algorithmic = the forward conv's MACs
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * (2 if residual is not None else 1) + self.w.numel())
@@ -238,7 +243,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         taps = 3 * bin(d.mode).count("1")
         return (2.0 * m * d.cs * taps, "mvf stencil%s M%d Cs%d" % ("^T" if flip else "", m, d.cs), nb)
 
-    undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb),
+    undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "launch_fwd_apply", dfap), tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb),
             tw.wrap(TE._TConv, "wgrad", dwgr), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
             tb.wrap(TE._BN, "backward_pair", dbpr),
             tm.wrap(TE._TMvf, "launch_stencil", dmvf)]

@@ -132,6 +132,15 @@ int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* 
  * channel (absent views: zeros); act = 1: affine + hard-swish (use_hs), 0: the bare tap sum.  cs % 64 == 0 (bf16) / 32 (fp32). */
 int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void* w_packed, const float* bias, const float* mvf_coef,
                             int cs, int n_segment, int act, void* y, void* ws, size_t ws_bytes, void* stream);
+/* [r3] Second pass of a bottleneck's last conv in TRAINING (Bottleneck.forward, codes/models/backbones/resnet.py:229-244: out = conv3(out);
+ * out = norm3(out); out += identity; out = relu(out)): the conv is recomputed from its narrow input (a quarter of z3's bytes) and the epilogue
+ * applies the BatchNorm whose batch statistics the first pass (mvf_conv2d_nhwc_fwd_stats) produced: the accumulators are rounded to the storage
+ * type (= the z3 that first pass stored), out = relu(bn_scale * z3 + bn_shift + r), r = residual or -- a downsample block -- res_scale * residual
+ * + res_shift (that branch's BatchNorm applied to its raw conv output); sign_bits [n*ho*wo][cout/4] bytes as mvf_bn_apply_bits writes them.
+ * Same result as mvf_bn_apply_bits on the stored z3, bit for bit, without reading z3.  d->relu = 0, in_dil <= 1. */
+int mvf_conv2d_nhwc_fwd_bnapply(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bn_scale,
+                                const float* bn_shift, const void* residual, const float* res_scale, const float* res_shift, void* out,
+                                unsigned char* sign_bits, void* ws, size_t ws_bytes, void* stream);
 /* ... with the residual gated per element by sign bits ([n*ho*wo][cout/4] bytes, see mvf_bn_apply_bits); stride-1 launches */
 int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                                 const float* bias, const void* residual, const unsigned char* res_sign_bits, void* y,

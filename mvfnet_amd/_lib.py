@@ -74,6 +74,8 @@ def _load():
     lib.mvf_conv2d_nhwc_dgrad_bnsums.argtypes = [cp, vp, vp, vp, vp, fp, fp, fp, fp, fp, vp, sz, vp]
     lib.mvf_bn_bwd_finalize.restype = i32
     lib.mvf_bn_bwd_finalize.argtypes = [fp, i32, i32, fp, fp, vp]
+    lib.mvf_conv2d_nhwc_fwd_bnapply.restype = i32
+    lib.mvf_conv2d_nhwc_fwd_bnapply.argtypes = [cp, vp, vp, vp, fp, fp, vp, fp, fp, vp, vp, vp, sz, vp]
     lib.mvf_conv2d_nhwc_fwd_resmask.restype = i32
     lib.mvf_conv2d_nhwc_fwd_resmask.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, vp, sz, vp]
     lib.mvf_conv2d_stats_rows.restype = i32

@@ -67,6 +67,13 @@ struct ConvArgs {
     // gm = y * [bn_scale*z + bn_shift > 0], xhat = (z - bn_mean) * bn_invstd; z has the output's shape
     const char* bn_z;
     const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
+    // EPI 8 (training forward, second pass of a bottleneck's conv3: reference resnet.py:229-244 conv3 -> bn3 -> += identity -> relu): the
+    // accumulators are rounded to the storage type (= the z3 the first pass stored), then out = relu(ap_scale * z3 + ap_shift + residual')
+    // with residual' = residual, or ap_rscale * residual + ap_rshift for a downsample branch whose BatchNorm is applied here as well;
+    // ap_bits ([M][Cout/4] bytes, bit j of byte k = [out channel 4k+j > 0]) are the sign bits the backward pass gates with.  The arithmetic
+    // is bn_apply_kernel's (train_ops.hip), expression by expression.
+    const float *ap_scale, *ap_shift, *ap_rscale, *ap_rshift;
+    unsigned char* ap_bits;
     // MVFL (inference, MVF fused into the wrapped 1x1 conv's A-operand load, reference MVF.py:104-138): channels [0, mvf_cs) of the
     // input are replaced ON THE FLY by hswish(scale * (9-tap T/H/W stencil) + shift); mvf_coef = [mvf_cs][12] floats per channel:
     // {wt[0..2], wh[0..2], ww[0..2], scale, shift, 0}; mvf_act = 1: affine + hard-swish, 0: the bare tap sum (use_hs = False)
@@ -918,8 +925,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
     // residual loads.
     const bool e_bias = EPI == 0 ? a.bias != nullptr : (EPI == 4 || EPI == 5);
-    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5);
+    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8);
     const bool e_relu = EPI == 0 ? a.relu != 0 : (EPI == 4 || EPI == 5);
+    constexpr bool e_apply = EPI == 8;                   // BatchNorm apply + residual + ReLU + sign bits on the rounded accumulators
     const bool e_stats = EPI == 0 ? a.stats_part != nullptr : EPI == 1;
     constexpr bool e_bnb = EPI == 6;                     // BatchNorm-backward sums instead of forward statistics
     const bool e_scatter = (EPI == 0 || EPI == 6) && a.o_s > 0;      // a strided data gradient's parity class (plain or + BN sums)
@@ -941,6 +949,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // fused BatchNorm statistics of the tensor being written (training): this thread's rows of its 4 columns
     float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = st1, kk = st1;
     if (e_stats && a.stats_shift && col < a.Cout) kk = *reinterpret_cast<const float4*>(a.stats_shift + col);
+    float4 ap_s = st1, ap_b = st1, ap_rs = make_float4(1.f, 1.f, 1.f, 1.f), ap_rb = st1;
+    if (e_apply && col < a.Cout) {
+        ap_s = *reinterpret_cast<const float4*>(a.ap_scale + col); ap_b = *reinterpret_cast<const float4*>(a.ap_shift + col);
+        if (a.ap_rscale) { ap_rs = *reinterpret_cast<const float4*>(a.ap_rscale + col); ap_rb = *reinterpret_cast<const float4*>(a.ap_rshift + col); }
+    }
     float4 b_mu = st1, b_rs = st1, b_sc = st1, b_sh = st1;
     if (e_bnb && col < a.Cout) {
         b_mu = *reinterpret_cast<const float4*>(a.bn_mean + col); b_rs = *reinterpret_cast<const float4*>(a.bn_invstd + col);
@@ -1176,8 +1189,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 const unsigned off = offs[ps];
                 const bool ok = off != kOOB;
                 float4 v = *reinterpret_cast<const float4*>(smem + (r0 + ps * RPP) * CP + cq * 16);
+                if constexpr (e_apply) {
+                    if constexpr (sizeof(ET) == 2) {         // z3 as the first pass stored it
+                        const unsigned p0 = pack_bf16x2(v.x, v.y), p1 = pack_bf16x2(v.z, v.w);
+                        v = make_float4(__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u));
+                    }
+                    const float4 q = unpack(rraw[ps]);
+                    float t0 = v.x * ap_s.x + ap_b.x, t1 = v.y * ap_s.y + ap_b.y, t2 = v.z * ap_s.z + ap_b.z, t3 = v.w * ap_s.w + ap_b.w;
+                    t0 += q.x * ap_rs.x + ap_rb.x; t1 += q.y * ap_rs.y + ap_rb.y; t2 += q.z * ap_rs.z + ap_rb.z; t3 += q.w * ap_rs.w + ap_rb.w;
+                    v = make_float4(fmaxf(t0, 0.f), fmaxf(t1, 0.f), fmaxf(t2, 0.f), fmaxf(t3, 0.f));
+                    if (ok) a.ap_bits[(long)(m0 + hf * HR + r0 + ps * RPP) * (a.Cout / 4) + (col >> 2)] =
+                        (unsigned char)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u));
+                }
                 if (e_bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-                if (e_res) {
+                if (e_res && !e_apply) {
                     float4 rv = unpack(rraw[ps]);
                     if (a.res_mask) {
                         const unsigned mb = mask_lds ? (unsigned)*reinterpret_cast<const unsigned char*>(smem + kMaskOff + (hf * HR + r0 + ps * RPP) * (BN / 4) + cq)
@@ -1593,6 +1618,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
                 "conv2d: output image too large for tile-relative 32-bit addressing");
     MVF_REQUIRE(!a.bn_z || !(a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L), MVF_EUNSUPPORTED,
                 "conv2d_dgrad_bnsums: shape needs the generic kernel, which has no BatchNorm-backward epilogue");
+    MVF_REQUIRE(!a.ap_scale || !(a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L || a.o_s > 0), MVF_EUNSUPPORTED,
+                "conv2d_fwd_bnapply: shape needs the generic kernel / a scattered output, which have no BatchNorm-apply epilogue");
     if (a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L || (long)a.Cout * a.wK * (long)sizeof(ET) >= 0x7ffffff0L) {
         auto kern_gen = conv_igemm_gen_kernel<ET, WM, WN, TM, TN>;
         static bool gen_attr = false;
@@ -1643,8 +1670,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
-    if (a.bn_z) sk_wins = false;                 // the BatchNorm-backward epilogue lives in the single-buffer kernel only
-    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
+    if (a.bn_z || a.ap_scale) sk_wins = false;   // the BatchNorm-backward / BatchNorm-apply epilogues live in the single-buffer kernels only
+    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();
         static const int epi_spec = getenv("MVF_CONV_EPI") ? atoi(getenv("MVF_CONV_EPI")) : 3;     // A/B switch: bit 0 epilogues, bit 1 pointwise loader
         const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
@@ -1653,7 +1680,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
         const bool bnsum_epi = (epi_spec & 1) && a.bn_z && !a.bias && !a.relu && !a.res;      // contiguous or a scattered parity class
         // long K, wide output: the 256 x 128 LDS-DMA tile (MVF_CONV_BIG = <min chunks>, 0 = off)
-        if (BN == 128 && sizeof(ET) == 2 && g_big2_min > 0 && a.nchunks >= g_big2_min && a.Cout % 256 == 0 && a.o_s <= 0) {
+        if (BN == 128 && sizeof(ET) == 2 && g_big2_min > 0 && a.nchunks >= g_big2_min && a.Cout % 256 == 0 && a.o_s <= 0 && !a.ap_scale) {
             const long t2 = (long)((a.M + 255) / 256) * (a.Cout / 256);
             const int cus = slots / 2;
             const long rounds = (t2 + cus - 1) / cus;
@@ -1686,7 +1713,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
                 return MVF_OK;
             }
         }
-        if (BN == 128 && g_big_min > 0 && a.nchunks >= g_big_min && a.Cout >= 128 && a.M >= 256) {
+        if (BN == 128 && g_big_min > 0 && a.nchunks >= g_big_min && a.Cout >= 128 && a.M >= 256 && !a.ap_scale) {
             int rc;
             if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_big<ET, 1>(st, a);
             else if (bnsum_epi) rc = launch_big<ET, 6>(st, a);
@@ -1712,7 +1739,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
                               : (sizeof(ET) == 2 ? (infer_like ? 16 : 8) : ((infer_like && g_glds1_f32_infer) ? 8 : 0));
         if (glds1_max > 0 && a.nchunks <= glds1_max && !(bnsum_epi && g_glds1_max < 0)) {
             int rc;
-            if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(1, tiles, st, a);
+            if (a.ap_scale) rc = launch_glds<ET, WM, WN, TM, TN, 8>(1, tiles, st, a);
+            else if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(1, tiles, st, a);
             else if (bnsum_epi) rc = launch_glds<ET, WM, WN, TM, TN, 6>(1, tiles, st, a);
             else if (train_like && !a.stats_part && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 2>(1, tiles, st, a);
             else if (train_like && !a.stats_part && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 3>(1, tiles, st, a);
@@ -1726,7 +1754,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         const bool glds_auto = g_glds_min < 0 && sizeof(ET) == 2 && (a.nchunks >= 32 || (BN == 64 && a.nchunks >= 9));
         if ((g_glds_min > 0 && a.nchunks >= g_glds_min) || glds_auto) {
             int rc;
-            if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(g_glds_nb, tiles, st, a);
+            if (a.ap_scale) rc = launch_glds<ET, WM, WN, TM, TN, 8>(g_glds_nb, tiles, st, a);
+            else if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(g_glds_nb, tiles, st, a);
             else if (bnsum_epi) rc = launch_glds<ET, WM, WN, TM, TN, 6>(g_glds_nb, tiles, st, a);
             else if (train_like && !a.stats_part && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 2>(g_glds_nb, tiles, st, a);
             else if (train_like && !a.stats_part && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 3>(g_glds_nb, tiles, st, a);
@@ -1737,7 +1766,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
             MVF_LAUNCH_CHECK();
             return MVF_OK;
         }
-        if (train_like && a.stats_part && !a.res && !a.bn_z) launch_lowk<ET, WM, WN, TM, TN, 1>(pw, tiles, lds_lk, st, a);
+        if (a.ap_scale) launch_lowk<ET, WM, WN, TM, TN, 8>(pw, tiles, lds_lk, st, a);
+        else if (train_like && a.stats_part && !a.res && !a.bn_z) launch_lowk<ET, WM, WN, TM, TN, 1>(pw, tiles, lds_lk, st, a);
         else if (bnsum_epi) launch_lowk<ET, WM, WN, TM, TN, 6>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && !a.res) launch_lowk<ET, WM, WN, TM, TN, 2>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && a.res) launch_lowk<ET, WM, WN, TM, TN, 3>(pw, tiles, lds_lk, st, a);
@@ -1798,9 +1828,14 @@ struct MvfFuse {              // optional: MVF-proper applied to channels [0, cs
     const float* coef;
     int cs, T, act;
 };
+struct BnApply {              // optional: the epilogue applies a BatchNorm + residual + ReLU and writes the sign bits (see ConvArgs::ap_scale)
+    const float *scale, *shift, *rscale, *rshift;
+    unsigned char* bits;
+};
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream, const unsigned char* res_mask = nullptr, const BnBwdSums* bnb = nullptr, const MvfFuse* mf = nullptr);
+                         void* stream, const unsigned char* res_mask = nullptr, const BnBwdSums* bnb = nullptr, const MvfFuse* mf = nullptr,
+                         const BnApply* ap = nullptr);
 
 int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void* w_packed, const float* bias, const float* mvf_coef,
                             int cs, int n_segment, int act, void* y, void* ws, size_t ws_bytes, void* stream) {
@@ -1819,6 +1854,18 @@ int mvf_conv2d_nhwc_dgrad_bnsums(const mvf_conv_desc_t* d, const void* dz, const
     MVF_REQUIRE(d && bn_z && bn_mean && bn_invstd && bn_scale && bn_shift && sums_part, MVF_EINVAL, "conv2d_dgrad_bnsums: NULL argument");
     const BnBwdSums b = {bn_z, bn_mean, bn_invstd, bn_scale, bn_shift};
     return conv_fwd_impl(d, dz, nullptr, w_packed_dgrad, nullptr, nullptr, y, sums_part, nullptr, ws, ws_bytes, stream, nullptr, &b);
+}
+
+int mvf_conv2d_nhwc_fwd_bnapply(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bn_scale,
+                                const float* bn_shift, const void* residual, const float* res_scale, const float* res_shift, void* out,
+                                unsigned char* sign_bits, void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && bn_scale && bn_shift && residual && sign_bits, MVF_EINVAL, "conv2d_fwd_bnapply: NULL argument");
+    MVF_REQUIRE((res_scale == nullptr) == (res_shift == nullptr), MVF_EINVAL, "conv2d_fwd_bnapply: res_scale / res_shift must come together");
+    MVF_REQUIRE(d->in_dil <= 1 && !d->relu && d->cout % 4 == 0, MVF_EINVAL, "conv2d_fwd_bnapply: a forward launch (in_dil <= 1), relu = 0 in the descriptor");
+    MVF_REQUIRE(((uintptr_t)bn_scale | (uintptr_t)bn_shift | (uintptr_t)(res_scale ? res_scale : bn_scale) | (uintptr_t)(res_shift ? res_shift : bn_shift)) % 16 == 0,
+                MVF_EINVAL, "conv2d_fwd_bnapply: coefficient vectors must be 16-byte aligned");
+    const BnApply ap = {bn_scale, bn_shift, res_scale, res_shift, sign_bits};
+    return conv_fwd_impl(d, x, x2, w_packed, nullptr, residual, out, nullptr, nullptr, ws, ws_bytes, stream, nullptr, nullptr, nullptr, &ap);
 }
 
 int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
@@ -1856,7 +1903,7 @@ int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const voi
 
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream, const unsigned char* res_mask, const BnBwdSums* bnb, const MvfFuse* mf) {
+                         void* stream, const unsigned char* res_mask, const BnBwdSums* bnb, const MvfFuse* mf, const BnApply* ap) {
     MVF_REQUIRE(d && x && w_packed && y, MVF_EINVAL, "conv2d: NULL argument");
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -1908,6 +1955,9 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     a.stats_rows = stats_part ? mvf_conv2d_stats_rows(d) : 0;
     if (mf) {
         a.mvf_coef = mf->coef; a.mvf_cs = mf->cs; a.mvf_T = mf->T; a.mvf_act = mf->act;
+    }
+    if (ap) {
+        a.ap_scale = ap->scale; a.ap_shift = ap->shift; a.ap_rscale = ap->rscale; a.ap_rshift = ap->rshift; a.ap_bits = ap->bits;
     }
     if (bnb) {
         a.bn_z = (const char*)bnb->z; a.bn_mean = bnb->mean; a.bn_invstd = bnb->invstd; a.bn_scale = bnb->scale; a.bn_shift = bnb->shift;

@@ -241,6 +241,23 @@ class _TConv(object):
         bn.finalize(part, rows, n * ho * wo)
         return z, ho, wo
 
+    def forward_apply(self, x, n, h, w, bn, residual, rbn=None):
+        """[r3] The block's last conv AGAIN, with bn's apply + residual + ReLU + sign bits as its epilogue (mvf_conv2d_nhwc_fwd_bnapply): the
+        same `out` / bits as bn.apply(z3, residual, rbn, bits=True), bit for bit, reading the conv's narrow input instead of z3."""
+        ho, wo = self.out_hw(h, w)
+        d = self.desc(n, h, w, ho, wo, self.cin)
+        m = n * ho * wo
+        out = self.eng.buf((id(bn), "apply"), (m, self.cout))
+        bits = self.eng.buf((id(bn), "bits"), (m, self.cout // 4), torch.uint8)
+        self.launch_fwd_apply(d, x, bn, residual, rbn, out, bits, _conv_ws(x.device))
+        return out, bits
+
+    def launch_fwd_apply(self, d, x, bn, residual, rbn, out, bits, ws):
+        """Exactly one implicit-GEMM launch (bench.py brackets this call with HIP events)."""
+        check(lib.mvf_conv2d_nhwc_fwd_bnapply(C.byref(d), _p(x), None, _p(self.wp), _p(bn.scale), _p(bn.shift), _p(residual),
+                                              _p(rbn.scale if rbn else None), _p(rbn.shift if rbn else None), _p(out), _p(bits),
+                                              _p(ws), ws.numel(), _st()), "conv fwd + bn apply")
+
     def launch_fwd(self, d, x, x2, z, ws, part, shift):
         """Exactly one implicit-GEMM launch (bench.py brackets this call with HIP events)."""
         if part is None:
@@ -384,6 +401,14 @@ class _TBlock(object):
     def convs(self):
         return [c for c in (self.c1, self.c2, self.c3, self.cd) if c is not None]
 
+    def fuse_apply(self, eng):
+        """bn3's apply + residual + ReLU as the epilogue of a SECOND conv3 pass instead of a pass over z3 (eng.fuse_bn3_apply: 0 never,
+        1 where it measured faster in the step -- planes <= 128 (layer1: 187 vs 260 us per block, layer2: 110 vs 126): conv3 reads a quarter
+        of z3's bytes and the matrix cores idle; from planes = 256 on the extra GEMM costs more than the bytes save (layer3: 71 vs 64 us) --,
+        2 every block)."""
+        f = eng.fuse_bn3_apply
+        return f == 2 or (f == 1 and self.c3.cin <= 128)
+
     def forward(self, x, nt, h, w, c, eng):
         m = nt * h * w
         s = dict(x=x, h=h, w=w, c=c)
@@ -416,8 +441,13 @@ class _TBlock(object):
                 eng.main_stream().wait_stream(side)               # the downsample branch (queued before conv1, see above)
             else:
                 zd, _, _ = self.cd.forward(x, nt, h, w, bn=self.bd)
-            out, bits = self.b3.apply(z3, m2, 1, residual=zd, rbn=self.bd, bits=True)
+            if self.fuse_apply(eng):
+                out, bits = self.c3.forward_apply(a2, nt, ho, wo, self.b3, zd, self.bd)
+            else:
+                out, bits = self.b3.apply(z3, m2, 1, residual=zd, rbn=self.bd, bits=True)
             s["zd"] = zd
+        elif self.fuse_apply(eng):
+            out, bits = self.c3.forward_apply(a2, nt, ho, wo, self.b3, x)
         else:
             out, bits = self.b3.apply(z3, m2, 1, residual=x, bits=True)
         s.update(z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, out=out, bits=bits, ho=ho, wo=wo)
@@ -569,6 +599,7 @@ class _ParamStore(object):
     overlap_downsample = os.environ.get("MVF_SIDE_DOWNSAMPLE", "1") != "0"     # forward: downsample branch on the side stream
     keep_io = False            # keep references to every block's input / output / gradients after backward (teacher-forced parity tests)
     fuse_stats = True          # BatchNorm batch statistics accumulated in the producing conv's epilogue
+    fuse_bn3_apply = int(os.environ.get("MVF_FUSE_BN3_APPLY", "1"))      # [r3] bn3 apply + residual + ReLU as a second conv3 pass (0 / 1 planes <= 128 / 2 all)
     fuse_bn_bwd_sums = os.environ.get("MVF_FUSE_BN_BWD", "1") != "0"    # ... and the backward sums in the data gradient's
     pair_bn_bwd = os.environ.get("MVF_PAIR_BN_BWD", "1") != "0"         # downsample blocks: bn3 + downsample-BN backward in one pass over g
     fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes

@@ -882,7 +882,9 @@ def test_engine_switch_variants_reproduce_the_default_step(dtype):
         return losses, eng.flat_params.clone()
 
     base = run()
-    for attrs in (dict(overlap_downsample_bwd=True), dict(fuse_stem_bwd=2), dict(pair_bn_bwd=False), dict(stem_wgrad_main=False)):
+    # [r3] fuse_bn3_apply: bn3's apply + residual + ReLU as the epilogue of a second conv3 pass (0 = the pass over z3, 2 = every block incl. layer4)
+    for attrs in (dict(overlap_downsample_bwd=True), dict(fuse_stem_bwd=2), dict(pair_bn_bwd=False), dict(stem_wgrad_main=False),
+                  dict(fuse_bn3_apply=0), dict(fuse_bn3_apply=2)):
         got = run(**attrs)
         assert got[0] == base[0], attrs
         assert torch.equal(got[1], base[1]), attrs
@@ -1347,3 +1349,41 @@ def test_device_prefetcher_slot_reuse_waits_for_the_consumers_kernels():
     torch.cuda.synchronize()
     assert [float(s) for s in sums] == [float((i + 1) * (1 << 20)) for i in range(7)]
     assert len(ptrs) == 2                                   # two persistent landing buffers, no per-batch allocation
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 9, 7, 64, 256, False), (3, 6, 6, 128, 96, True), (1, 14, 14, 256, 1024, True), (2, 7, 7, 512, 2048, False),
+                                   (5, 5, 5, 32, 64, False)], ids=str)
+def test_conv_bnapply_pass_equals_bn_apply_on_the_stored_conv_output(shape, dtype):
+    """[r3] mvf_conv2d_nhwc_fwd_bnapply (reference resnet.py:229-244: conv3 -> bn3 -> += identity -> relu, as a second pass of the conv): `out` and the
+    sign bits equal mvf_bn_apply_bits on the z3 the first pass (mvf_conv2d_nhwc_fwd_stats) stored, BIT FOR BIT -- with a plain identity and with a
+    downsample branch whose BatchNorm is applied to the residual operand."""
+    from mvfnet_amd import _lib
+    from mvfnet_amd._lib import ConvDesc
+    lib, check = _lib.lib, _lib.check
+    n, h, w, cin, cout, with_rbn = shape
+    dt = 0 if dtype == torch.float32 else 1
+    g = torch.Generator().manual_seed(cin + cout)
+    m = n * h * w
+    x = torch.randn(m, cin, generator=g).to(dtype).cuda()
+    wgt = (torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).cuda()
+    wp = torch.empty(cout, 1, 1, cin, dtype=dtype, device="cuda")
+    check(lib.mvf_pack_conv_weight(P(wgt), cout, cin, 1, 1, 1, cin, None, P(wp), dt, None))
+    res = torch.randn(m, cout, generator=g).to(dtype).cuda()
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.3).cuda()
+    rscale = (torch.rand(cout, generator=g) + 0.5).cuda() if with_rbn else None
+    rshift = (torch.randn(cout, generator=g) * 0.3).cuda() if with_rbn else None
+    d = ConvDesc(n, h, w, cin, cout, 1, 1, 1, 0, h, w, cin, dt, 0, 0, 0, 0, 0)
+    ws = torch.zeros(max(lib.mvf_conv2d_workspace_bytes(C.byref(d)), 1), dtype=torch.uint8, device="cuda")
+    rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+    part = torch.empty(cout, rows, 2, device="cuda")
+    z3 = torch.empty(m, cout, dtype=dtype, device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(x), None, P(wp), P(z3), P(part), None, P(ws), ws.numel(), None))
+    want, wbits = torch.empty_like(z3), torch.empty(m, cout // 4, dtype=torch.uint8, device="cuda")
+    check(lib.mvf_bn_apply_bits(P(z3), m, cout, P(scale), P(shift), P(res), P(rscale), P(rshift), 1, P(want), P(wbits), dt, None))
+    got, gbits = torch.full_like(z3, 7.0), torch.full((m, cout // 4), 255, dtype=torch.uint8, device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd_bnapply(C.byref(d), P(x), None, P(wp), P(scale), P(shift), P(res), P(rscale), P(rshift), P(got), P(gbits), P(ws), ws.numel(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    assert torch.equal(gbits, wbits)
+    assert 0.2 < float((want > 0).float().mean()) < 0.8          # the ReLU and the bits are exercised on both sides

@@ -41,7 +41,9 @@ def bench_conv(dt=1, only=None):
               ("l1.c3 dgrad", 56, 256, 64, 1, "bnb"), ("l2.c3 fwd", 28, 128, 512, 1, "stats"), ("l2.c1 dgrad", 28, 128, 512, 1, "res"),
               ("l3.c3 fwd", 14, 256, 1024, 1, "stats"), ("l3.c1 fwd", 14, 1024, 256, 1, "stats"), ("l3.c1 dgrad", 14, 256, 1024, 1, "res"),
               ("l3.c3 dgrad", 14, 1024, 256, 1, "bnb"), ("l3.c2 fwd", 14, 256, 256, 3, "stats"), ("l3.c2 dgrad", 14, 256, 256, 3, "bnb"),
-              ("l4.c3 fwd", 7, 512, 2048, 1, "stats"), ("l2.c2 fwd", 28, 128, 128, 3, "stats"), ("l1.c2 fwd", 56, 64, 64, 3, "stats")]
+              ("l4.c3 fwd", 7, 512, 2048, 1, "stats"), ("l2.c2 fwd", 28, 128, 128, 3, "stats"), ("l1.c2 fwd", 56, 64, 64, 3, "stats"),
+              ("l1.c3 apply", 56, 64, 256, 1, "infer_res"), ("l2.c3 apply", 28, 128, 512, 1, "infer_res"), ("l3.c3 apply", 14, 256, 1024, 1, "infer_res"),
+              ("l4.c3 apply", 7, 512, 2048, 1, "infer_res")]
     n = 256
     for name, hw, cin, cout, k, kind in shapes:
         if only and only not in name:
@@ -58,6 +60,12 @@ def bench_conv(dt=1, only=None):
         nbytes = esz * (m * cin + m * cout + cout * k * k * cin)
         if kind == "stats":
             fn = lambda: check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(x), None, P(wp), P(y), P(part), P(shift), P(ws), ws.numel(), None))  # noqa: E731
+        elif kind == "infer_res":      # bias + residual + ReLU (the inference epilogue): what a fused bn3-apply pass of conv3 would cost, minus the sign bits
+            res = torch.randn(m, cout, device=dev).to(tdt)
+            bias = torch.randn(cout, device=dev)
+            nbytes += esz * m * cout
+            d = ConvDesc(n, hw, hw, cin, cout, k, k, 1, k // 2, hw, hw, cin, dt, 1, 0, 0, 0, 0)
+            fn = lambda: check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(x), None, P(wp), P(bias), P(res), P(y), P(ws), ws.numel(), None))  # noqa: E731
         elif kind == "plain":
             fn = lambda: check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(x), None, P(wp), None, None, P(y), P(ws), ws.numel(), None))  # noqa: E731
         elif kind == "res":
