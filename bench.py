@@ -197,13 +197,21 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         n, h, w, ho, wo = d.n, d.h, d.w, d.ho, d.wo
         k_alg = 147 if self.stem else self.kh * self.kw * self.cin
         in_px = n * ho * wo if (self.kh == 1 and self.stride > 1) else n * h * w
-        nbytes = esz * (in_px * (4 if self.stem else self.cin) + n * ho * wo * self.cout + self.w.numel())
-        return (2.0 * n * ho * wo * self.cout * k_alg, "fwd   M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)
+        nbytes = esz * (in_px * (4 if self.stem else self.cin) + (n * ho * wo * self.cout if z is not None else 0) + self.w.numel())
+        return (2.0 * n * ho * wo * self.cout * k_alg, "fwd%s M%d N%d K%d s%d" % ("   " if z is not None else "(s)", n * ho * wo, self.cout, k_alg, self.stride), nbytes)
 
     def dfap(self, out, d, x, bn, residual, rbn, o, bits, ws):      # conv3 again + bn3 apply + residual + ReLU + sign bits (no z3 read)
         m = d.n * d.ho * d.wo
         nbytes = esz * (m * self.cin + 2 * m * self.cout + self.w.numel()) + m * self.cout // 4
         return (2.0 * m * self.cout * self.cin, "fwd+bn M%d N%d K%d s%d" % (m, self.cout, self.cin, self.stride), nbytes)
+
+    def dbws(self, out, d, a_in, g, bits, bn, part, ws):            # conv3 again + bn3 backward sums (reads a2, g, bits; stores nothing)
+        m = d.n * d.ho * d.wo
+        return (2.0 * m * self.cout * self.cin, "bwd-sums M%d N%d K%d" % (m, self.cout, self.cin), esz * (m * self.cin + m * self.cout + self.w.numel()) + m * self.cout // 4)
+
+    def dbwa(self, out, d, a_in, g, bits, bn, dz, ws):              # conv3 again + bn3 backward apply (reads a2, g, bits; writes dz3)
+        m = d.n * d.ho * d.wo
+        return (2.0 * m * self.cout * self.cin, "bwd-apply M%d N%d K%d" % (m, self.cout, self.cin), esz * (m * self.cin + 2 * m * self.cout + self.w.numel()) + m * self.cout // 4)
 
     def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
         fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin          # algorithmic = the forward conv's MACs
@@ -243,7 +251,8 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         taps = 3 * bin(d.mode).count("1")
         return (2.0 * m * d.cs * taps, "mvf stencil%s M%d Cs%d" % ("^T" if flip else "", m, d.cs), nb)
 
-    undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "launch_fwd_apply", dfap), tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb),
+    undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "launch_fwd_apply", dfap), tc.wrap(TE._TConv, "launch_bwd_sums", dbws), tc.wrap(TE._TConv, "launch_bwd_apply", dbwa),
+            tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb),
             tw.wrap(TE._TConv, "wgrad", dwgr), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
             tb.wrap(TE._BN, "backward_pair", dbpr),
             tm.wrap(TE._TMvf, "launch_stencil", dmvf)]

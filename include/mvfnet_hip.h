@@ -141,6 +141,18 @@ int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void*
 int mvf_conv2d_nhwc_fwd_bnapply(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bn_scale,
                                 const float* bn_shift, const void* residual, const float* res_scale, const float* res_shift, void* out,
                                 unsigned char* sign_bits, void* ws, size_t ws_bytes, void* stream);
+/* [r3] BatchNorm backward of that bn3 WITHOUT a stored z3 (autograd of resnet.py:229-244): the conv is recomputed from its input and its
+ * accumulators, rounded to the storage type, are z3; g = gradient of the block output, sign_bits = the bits the forward wrote, gm = g * bit.
+ *   _sums : sums_part CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] = per-128-row column sums of gm and gm * (z3 - mean) * invstd;
+ *           mvf_bn_bwd_finalize turns them into dbeta / dgamma.  Nothing else is written.
+ *   _apply: dz = gamma * invstd * (gm - dbeta / M - (z3 - mean) * invstd * dgamma / M), M = n*ho*wo (bn_bwd_apply's formula, mask mode 4).
+ * With these two and mvf_conv2d_nhwc_fwd_bnapply the first pass may run as a statistics-only pass: mvf_conv2d_nhwc_fwd_stats(..., y = NULL). */
+int mvf_conv2d_nhwc_fwd_bnbwd_sums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* g,
+                                   const unsigned char* sign_bits, const float* bn_mean, const float* bn_invstd, float* sums_part, void* ws,
+                                   size_t ws_bytes, void* stream);
+int mvf_conv2d_nhwc_fwd_bnbwd_apply(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* g,
+                                    const unsigned char* sign_bits, const float* bn_gamma, const float* bn_mean, const float* bn_invstd,
+                                    const float* dgamma, const float* dbeta, void* dz, void* ws, size_t ws_bytes, void* stream);
 /* ... with the residual gated per element by sign bits ([n*ho*wo][cout/4] bytes, see mvf_bn_apply_bits); stride-1 launches */
 int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                                 const float* bias, const void* residual, const unsigned char* res_sign_bits, void* y,

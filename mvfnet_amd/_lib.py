@@ -76,6 +76,10 @@ def _load():
     lib.mvf_bn_bwd_finalize.argtypes = [fp, i32, i32, fp, fp, vp]
     lib.mvf_conv2d_nhwc_fwd_bnapply.restype = i32
     lib.mvf_conv2d_nhwc_fwd_bnapply.argtypes = [cp, vp, vp, vp, fp, fp, vp, fp, fp, vp, vp, vp, sz, vp]
+    lib.mvf_conv2d_nhwc_fwd_bnbwd_sums.restype = i32
+    lib.mvf_conv2d_nhwc_fwd_bnbwd_sums.argtypes = [cp, vp, vp, vp, vp, vp, fp, fp, fp, vp, sz, vp]
+    lib.mvf_conv2d_nhwc_fwd_bnbwd_apply.restype = i32
+    lib.mvf_conv2d_nhwc_fwd_bnbwd_apply.argtypes = [cp, vp, vp, vp, vp, vp, fp, fp, fp, fp, fp, vp, vp, sz, vp]
     lib.mvf_conv2d_nhwc_fwd_resmask.restype = i32
     lib.mvf_conv2d_nhwc_fwd_resmask.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, vp, sz, vp]
     lib.mvf_conv2d_stats_rows.restype = i32

@@ -74,6 +74,13 @@ struct ConvArgs {
     // is bn_apply_kernel's (train_ops.hip), expression by expression.
     const float *ap_scale, *ap_shift, *ap_rscale, *ap_rshift;
     unsigned char* ap_bits;
+    // EPI 9 / 10 (training backward of out = relu(bn3(conv3(a2)) + identity), BatchNorm backward WITHOUT a stored z3): the conv is recomputed,
+    // its accumulators rounded to the storage type are z3; `res` is the block-output gradient g, `res_mask` the sign bits of out, gm = g * bit.
+    //   bw_mode 10: per-128-row column sums of gm and gm * (z3 - bn_mean) * bn_invstd into stats_part (-> mvf_bn_bwd_finalize); nothing is stored
+    //   bw_mode  9: y = dz3 = bw_gamma * bn_invstd * (gm - bw_dbeta / M - (z3 - bn_mean) * bn_invstd * bw_dgamma / M)
+    // The arithmetic is bn_bwd_reduce_kernel's / bn_bwd_apply_kernel's (train_ops.hip, mask mode 4), expression by expression.
+    const float *bw_gamma, *bw_dgamma, *bw_dbeta;
+    int bw_mode;
     // MVFL (inference, MVF fused into the wrapped 1x1 conv's A-operand load, reference MVF.py:104-138): channels [0, mvf_cs) of the
     // input are replaced ON THE FLY by hswish(scale * (9-tap T/H/W stencil) + shift); mvf_coef = [mvf_cs][12] floats per channel:
     // {wt[0..2], wh[0..2], ww[0..2], scale, shift, 0}; mvf_act = 1: affine + hard-swish, 0: the bare tap sum (use_hs = False)
@@ -925,7 +932,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
     // residual loads.
     const bool e_bias = EPI == 0 ? a.bias != nullptr : (EPI == 4 || EPI == 5);
-    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8);
+    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8 || EPI == 9 || EPI == 10);
+    constexpr bool e_bw = EPI == 9 || EPI == 10;         // BatchNorm backward on the recomputed conv output (g and its sign-bit gate arrive as the residual operand)
     const bool e_relu = EPI == 0 ? a.relu != 0 : (EPI == 4 || EPI == 5);
     constexpr bool e_apply = EPI == 8;                   // BatchNorm apply + residual + ReLU + sign bits on the rounded accumulators
     const bool e_stats = EPI == 0 ? a.stats_part != nullptr : EPI == 1;
@@ -959,6 +967,18 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         b_mu = *reinterpret_cast<const float4*>(a.bn_mean + col); b_rs = *reinterpret_cast<const float4*>(a.bn_invstd + col);
         b_sc = *reinterpret_cast<const float4*>(a.bn_scale + col); b_sh = *reinterpret_cast<const float4*>(a.bn_shift + col);
     }
+    float4 w_a = st1, w_d0 = st1, w_kx = st1;            // EPI 9: gamma * invstd, dbeta / M, invstd * dgamma / M (bn_bwd_apply_kernel's folding)
+    if (e_bw && col < a.Cout) {
+        b_mu = *reinterpret_cast<const float4*>(a.bn_mean + col); b_rs = *reinterpret_cast<const float4*>(a.bn_invstd + col);
+        if constexpr (EPI == 9) {
+            const float inv_m = 1.0f / (float)a.M;
+            const float4 ga = *reinterpret_cast<const float4*>(a.bw_gamma + col), dg = *reinterpret_cast<const float4*>(a.bw_dgamma + col),
+                         db = *reinterpret_cast<const float4*>(a.bw_dbeta + col);
+            w_a = make_float4(ga.x * b_rs.x, ga.y * b_rs.y, ga.z * b_rs.z, ga.w * b_rs.w);
+            w_d0 = make_float4(db.x * inv_m, db.y * inv_m, db.z * inv_m, db.w * inv_m);
+            w_kx = make_float4(b_rs.x * dg.x * inv_m, b_rs.y * dg.y * inv_m, b_rs.z * dg.z * inv_m, b_rs.w * dg.w * inv_m);
+        }
+    }
     // output / residual descriptors: tile-relative 32-bit offsets (contiguous rows from m0, or the full-resolution images
     // from the tile's first image for a scattered data-gradient class)
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -969,7 +989,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         const long base = (e_scatter ? (long)eimg0 * a.o_hfull * a.o_wfull : (long)m0) * a.Cout * ESZ;
         const long left = total - base;
         const unsigned nrec = (unsigned)(left < 0x7ffffff0L ? left : 0x7ffffff0L);
-        rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + base), 0, nrec, 0x00020000);
+        rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + base), 0, a.y ? nrec : 0u, 0x00020000);      // no output tensor (a statistics-only pass): every store is out of range = dropped
         rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(e_res ? a.res + base : (e_bnb ? a.bn_z + base : a.y + base)), 0, nrec, 0x00020000);
     }
     // residual gate bits (contiguous outputs only): one byte per 4 channels, addressed like the output / (4 * ESZ)
@@ -1201,8 +1221,28 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     if (ok) a.ap_bits[(long)(m0 + hf * HR + r0 + ps * RPP) * (a.Cout / 4) + (col >> 2)] =
                         (unsigned char)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u));
                 }
+                if constexpr (e_bw) {
+                    if constexpr (sizeof(ET) == 2) {         // z3 as the forward pass rounded it
+                        const unsigned p0 = pack_bf16x2(v.x, v.y), p1 = pack_bf16x2(v.z, v.w);
+                        v = make_float4(__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u));
+                    }
+                    float4 gm = unpack(rraw[ps]);            // g, gated by the sign bits of the block output
+                    const unsigned mb = mask_lds ? (unsigned)*reinterpret_cast<const unsigned char*>(smem + kMaskOff + (hf * HR + r0 + ps * RPP) * (BN / 4) + cq)
+                                                 : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, ok ? off / (4 * ESZ) : kOOB, 0, 0);
+                    gm.x = (mb & 1u) ? gm.x : 0.f; gm.y = (mb & 2u) ? gm.y : 0.f; gm.z = (mb & 4u) ? gm.z : 0.f; gm.w = (mb & 8u) ? gm.w : 0.f;
+                    if constexpr (EPI == 10) {
+                        if (!ok) gm = make_float4(0.f, 0.f, 0.f, 0.f);
+                        st1.x += gm.x; st1.y += gm.y; st1.z += gm.z; st1.w += gm.w;
+                        st2.x += gm.x * ((v.x - b_mu.x) * b_rs.x); st2.y += gm.y * ((v.y - b_mu.y) * b_rs.y);
+                        st2.z += gm.z * ((v.z - b_mu.z) * b_rs.z); st2.w += gm.w * ((v.w - b_mu.w) * b_rs.w);
+                        continue;                            // nothing is stored
+                    } else {
+                        v.x = w_a.x * (gm.x - w_d0.x - (v.x - b_mu.x) * w_kx.x); v.y = w_a.y * (gm.y - w_d0.y - (v.y - b_mu.y) * w_kx.y);
+                        v.z = w_a.z * (gm.z - w_d0.z - (v.z - b_mu.z) * w_kx.z); v.w = w_a.w * (gm.w - w_d0.w - (v.w - b_mu.w) * w_kx.w);
+                    }
+                }
                 if (e_bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-                if (e_res && !e_apply) {
+                if (e_res && !e_apply && !e_bw) {
                     float4 rv = unpack(rraw[ps]);
                     if (a.res_mask) {
                         const unsigned mb = mask_lds ? (unsigned)*reinterpret_cast<const unsigned char*>(smem + kMaskOff + (hf * HR + r0 + ps * RPP) * (BN / 4) + cq)
@@ -1248,7 +1288,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 }
             }
         }
-        if ((e_stats || e_bnb) && (hf + 1) % HPP == 0) {   // column sums over the RPP row-threads, fixed order, one writer per column
+        if ((e_stats || e_bnb || EPI == 10) && (hf + 1) % HPP == 0) {   // column sums over the RPP row-threads, fixed order, one writer per column
             __syncthreads();
             float4* red = reinterpret_cast<float4*>(smem);
             red[(r0 * 2 + 0) * TPR + cq] = st1;
@@ -1618,6 +1658,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
                 "conv2d: output image too large for tile-relative 32-bit addressing");
     MVF_REQUIRE(!a.bn_z || !(a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L), MVF_EUNSUPPORTED,
                 "conv2d_dgrad_bnsums: shape needs the generic kernel, which has no BatchNorm-backward epilogue");
+    MVF_REQUIRE(!a.bw_mode || !(a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L || a.o_s > 0), MVF_EUNSUPPORTED,
+                "conv2d_fwd_bnbwd: shape needs the generic kernel / a scattered output, which have no BatchNorm-backward-on-recompute epilogue");
     MVF_REQUIRE(!a.ap_scale || !(a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L || a.o_s > 0), MVF_EUNSUPPORTED,
                 "conv2d_fwd_bnapply: shape needs the generic kernel / a scattered output, which have no BatchNorm-apply epilogue");
     if (a.dil > 1 || a.KH > 31 || a.KW > 31 || img_bytes * span_imgs >= 0x7ffffff0L || (long)a.Cout * a.wK * (long)sizeof(ET) >= 0x7ffffff0L) {
@@ -1670,8 +1712,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
-    if (a.bn_z || a.ap_scale) sk_wins = false;   // the BatchNorm-backward / BatchNorm-apply epilogues live in the single-buffer kernels only
-    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
+    if (a.bn_z || a.ap_scale || a.bw_mode) sk_wins = false;   // the BatchNorm-backward / BatchNorm-apply epilogues live in the single-buffer kernels only
+    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale || a.bw_mode) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();
         static const int epi_spec = getenv("MVF_CONV_EPI") ? atoi(getenv("MVF_CONV_EPI")) : 3;     // A/B switch: bit 0 epilogues, bit 1 pointwise loader
         const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
@@ -1680,7 +1722,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
         const bool bnsum_epi = (epi_spec & 1) && a.bn_z && !a.bias && !a.relu && !a.res;      // contiguous or a scattered parity class
         // long K, wide output: the 256 x 128 LDS-DMA tile (MVF_CONV_BIG = <min chunks>, 0 = off)
-        if (BN == 128 && sizeof(ET) == 2 && g_big2_min > 0 && a.nchunks >= g_big2_min && a.Cout % 256 == 0 && a.o_s <= 0 && !a.ap_scale) {
+        if (BN == 128 && sizeof(ET) == 2 && g_big2_min > 0 && a.nchunks >= g_big2_min && a.Cout % 256 == 0 && a.o_s <= 0 && !a.ap_scale && !a.bw_mode) {
             const long t2 = (long)((a.M + 255) / 256) * (a.Cout / 256);
             const int cus = slots / 2;
             const long rounds = (t2 + cus - 1) / cus;
@@ -1713,7 +1755,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
                 return MVF_OK;
             }
         }
-        if (BN == 128 && g_big_min > 0 && a.nchunks >= g_big_min && a.Cout >= 128 && a.M >= 256 && !a.ap_scale) {
+        if (BN == 128 && g_big_min > 0 && a.nchunks >= g_big_min && a.Cout >= 128 && a.M >= 256 && !a.ap_scale && !a.bw_mode) {
             int rc;
             if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_big<ET, 1>(st, a);
             else if (bnsum_epi) rc = launch_big<ET, 6>(st, a);
@@ -1737,9 +1779,11 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         // (bf16 inference epilogues -- bias + ReLU [+ residual], half-batch launch chains -- keep winning up to 16 chunks: +1.9 %)
         const int glds1_max = g_glds1_max >= 0 ? g_glds1_max
                               : (sizeof(ET) == 2 ? (infer_like ? 16 : 8) : ((infer_like && g_glds1_f32_infer) ? 8 : 0));
-        if (glds1_max > 0 && a.nchunks <= glds1_max && !(bnsum_epi && g_glds1_max < 0)) {
+        if (glds1_max > 0 && a.nchunks <= glds1_max && !((bnsum_epi || a.bw_mode == 10) && g_glds1_max < 0)) {      // (the two sum epilogues spill at 128 registers)
             int rc;
             if (a.ap_scale) rc = launch_glds<ET, WM, WN, TM, TN, 8>(1, tiles, st, a);
+            else if (a.bw_mode == 9) rc = launch_glds<ET, WM, WN, TM, TN, 9>(1, tiles, st, a);
+            else if (a.bw_mode == 10) rc = launch_glds<ET, WM, WN, TM, TN, 10>(1, tiles, st, a);
             else if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(1, tiles, st, a);
             else if (bnsum_epi) rc = launch_glds<ET, WM, WN, TM, TN, 6>(1, tiles, st, a);
             else if (train_like && !a.stats_part && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 2>(1, tiles, st, a);
@@ -1755,6 +1799,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         if ((g_glds_min > 0 && a.nchunks >= g_glds_min) || glds_auto) {
             int rc;
             if (a.ap_scale) rc = launch_glds<ET, WM, WN, TM, TN, 8>(g_glds_nb, tiles, st, a);
+            else if (a.bw_mode == 9) rc = launch_glds<ET, WM, WN, TM, TN, 9>(g_glds_nb, tiles, st, a);
+            else if (a.bw_mode == 10) rc = launch_glds<ET, WM, WN, TM, TN, 10>(g_glds_nb, tiles, st, a);
             else if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 1>(g_glds_nb, tiles, st, a);
             else if (bnsum_epi) rc = launch_glds<ET, WM, WN, TM, TN, 6>(g_glds_nb, tiles, st, a);
             else if (train_like && !a.stats_part && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 2>(g_glds_nb, tiles, st, a);
@@ -1767,6 +1813,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
             return MVF_OK;
         }
         if (a.ap_scale) launch_lowk<ET, WM, WN, TM, TN, 8>(pw, tiles, lds_lk, st, a);
+        else if (a.bw_mode == 9) launch_lowk<ET, WM, WN, TM, TN, 9>(pw, tiles, lds_lk, st, a);
+        else if (a.bw_mode == 10) launch_lowk<ET, WM, WN, TM, TN, 10>(pw, tiles, lds_lk, st, a);
         else if (train_like && a.stats_part && !a.res && !a.bn_z) launch_lowk<ET, WM, WN, TM, TN, 1>(pw, tiles, lds_lk, st, a);
         else if (bnsum_epi) launch_lowk<ET, WM, WN, TM, TN, 6>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && !a.res) launch_lowk<ET, WM, WN, TM, TN, 2>(pw, tiles, lds_lk, st, a);
@@ -1828,6 +1876,10 @@ struct MvfFuse {              // optional: MVF-proper applied to channels [0, cs
     const float* coef;
     int cs, T, act;
 };
+struct BnBwdRecompute {       // optional: BatchNorm backward on the recomputed conv output (see ConvArgs::bw_mode); g / sign bits travel as residual / res_mask
+    int mode;                 // 9 apply (y = dz), 10 sums (stats_part)
+    const float *mean, *invstd, *gamma, *dgamma, *dbeta;
+};
 struct BnApply {              // optional: the epilogue applies a BatchNorm + residual + ReLU and writes the sign bits (see ConvArgs::ap_scale)
     const float *scale, *shift, *rscale, *rshift;
     unsigned char* bits;
@@ -1835,7 +1887,7 @@ struct BnApply {              // optional: the epilogue applies a BatchNorm + re
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
                          void* stream, const unsigned char* res_mask = nullptr, const BnBwdSums* bnb = nullptr, const MvfFuse* mf = nullptr,
-                         const BnApply* ap = nullptr);
+                         const BnApply* ap = nullptr, const BnBwdRecompute* bw = nullptr);
 
 int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void* w_packed, const float* bias, const float* mvf_coef,
                             int cs, int n_segment, int act, void* y, void* ws, size_t ws_bytes, void* stream) {
@@ -1866,6 +1918,27 @@ int mvf_conv2d_nhwc_fwd_bnapply(const mvf_conv_desc_t* d, const void* x, const v
                 MVF_EINVAL, "conv2d_fwd_bnapply: coefficient vectors must be 16-byte aligned");
     const BnApply ap = {bn_scale, bn_shift, res_scale, res_shift, sign_bits};
     return conv_fwd_impl(d, x, x2, w_packed, nullptr, residual, out, nullptr, nullptr, ws, ws_bytes, stream, nullptr, nullptr, nullptr, &ap);
+}
+
+int mvf_conv2d_nhwc_fwd_bnbwd_sums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* g,
+                                   const unsigned char* sign_bits, const float* bn_mean, const float* bn_invstd, float* sums_part, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && g && sign_bits && bn_mean && bn_invstd && sums_part, MVF_EINVAL, "conv2d_fwd_bnbwd_sums: NULL argument");
+    MVF_REQUIRE(d->in_dil <= 1 && !d->relu, MVF_EINVAL, "conv2d_fwd_bnbwd_sums: a forward launch (in_dil <= 1), relu = 0");
+    MVF_REQUIRE(((uintptr_t)bn_mean | (uintptr_t)bn_invstd) % 16 == 0, MVF_EINVAL, "conv2d_fwd_bnbwd_sums: coefficient vectors must be 16-byte aligned");
+    const BnBwdRecompute bw = {10, bn_mean, bn_invstd, nullptr, nullptr, nullptr};
+    return conv_fwd_impl(d, x, x2, w_packed, nullptr, g, nullptr, sums_part, nullptr, ws, ws_bytes, stream, sign_bits, nullptr, nullptr, nullptr, &bw);
+}
+
+int mvf_conv2d_nhwc_fwd_bnbwd_apply(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* g,
+                                    const unsigned char* sign_bits, const float* bn_gamma, const float* bn_mean, const float* bn_invstd,
+                                    const float* dgamma, const float* dbeta, void* dz, void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && g && sign_bits && bn_gamma && bn_mean && bn_invstd && dgamma && dbeta && dz, MVF_EINVAL, "conv2d_fwd_bnbwd_apply: NULL argument");
+    MVF_REQUIRE(d->in_dil <= 1 && !d->relu, MVF_EINVAL, "conv2d_fwd_bnbwd_apply: a forward launch (in_dil <= 1), relu = 0");
+    MVF_REQUIRE(((uintptr_t)bn_gamma | (uintptr_t)bn_mean | (uintptr_t)bn_invstd | (uintptr_t)dgamma | (uintptr_t)dbeta) % 16 == 0, MVF_EINVAL,
+                "conv2d_fwd_bnbwd_apply: coefficient vectors must be 16-byte aligned");
+    const BnBwdRecompute bw = {9, bn_mean, bn_invstd, bn_gamma, dgamma, dbeta};
+    return conv_fwd_impl(d, x, x2, w_packed, nullptr, g, dz, nullptr, nullptr, ws, ws_bytes, stream, sign_bits, nullptr, nullptr, nullptr, &bw);
 }
 
 int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
@@ -1903,8 +1976,8 @@ int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const voi
 
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream, const unsigned char* res_mask, const BnBwdSums* bnb, const MvfFuse* mf, const BnApply* ap) {
-    MVF_REQUIRE(d && x && w_packed && y, MVF_EINVAL, "conv2d: NULL argument");
+                         void* stream, const unsigned char* res_mask, const BnBwdSums* bnb, const MvfFuse* mf, const BnApply* ap, const BnBwdRecompute* bw) {
+    MVF_REQUIRE(d && x && w_packed && (y || (stats_part && !bnb)), MVF_EINVAL, "conv2d: NULL argument");      // (y may be NULL for a statistics-only pass)
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
                     d->stride > 0 && d->pad >= 0, MVF_ESHAPE, "conv2d: bad dims");
@@ -1955,6 +2028,9 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     a.stats_rows = stats_part ? mvf_conv2d_stats_rows(d) : 0;
     if (mf) {
         a.mvf_coef = mf->coef; a.mvf_cs = mf->cs; a.mvf_T = mf->T; a.mvf_act = mf->act;
+    }
+    if (bw) {
+        a.bw_mode = bw->mode; a.bn_mean = bw->mean; a.bn_invstd = bw->invstd; a.bw_gamma = bw->gamma; a.bw_dgamma = bw->dgamma; a.bw_dbeta = bw->dbeta;
     }
     if (ap) {
         a.ap_scale = ap->scale; a.ap_shift = ap->shift; a.ap_rscale = ap->rscale; a.ap_rshift = ap->rshift; a.ap_bits = ap->bits;

@@ -222,13 +222,14 @@ class _TConv(object):
     def out_hw(self, h, w):
         return (h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1
 
-    def forward(self, x, n, h, w, x_pitch=None, x2=None, split_c=0, ho=None, wo=None, bn=None):
+    def forward(self, x, n, h, w, x_pitch=None, x2=None, split_c=0, ho=None, wo=None, bn=None, store=True):
         """z = conv(x); with `bn` the epilogue also accumulates that BatchNorm's batch statistics and they are finalised
-        right away (no separate pass over z)."""
+        right away (no separate pass over z).  store=False ([r3], needs the fused statistics): a statistics-only pass, z is never written
+        (returned as None) -- the block recomputes the conv wherever z would be read (forward_apply, bwd_sums, bwd_apply)."""
         if ho is None:
             ho, wo = self.out_hw(h, w)
         d = self.desc(n, h, w, ho, wo, x_pitch or self.cin, split_c)
-        z = self.eng.buf((id(self), "z"), (n * ho * wo, self.cout))
+        z = self.eng.buf((id(self), "z"), (n * ho * wo, self.cout)) if store else None
         ws = _conv_ws(x.device)
         if bn is None or not self.eng.fuse_stats or bn.frozen:
             self.launch_fwd(d, x, x2, z, ws, None, None)
@@ -251,6 +252,29 @@ class _TConv(object):
         bits = self.eng.buf((id(bn), "bits"), (m, self.cout // 4), torch.uint8)
         self.launch_fwd_apply(d, x, bn, residual, rbn, out, bits, _conv_ws(x.device))
         return out, bits
+
+    def bwd_recompute(self, a_in, g, bits, n, h, w, bn):
+        """[r3] BatchNorm backward of bn = the block's bn3 without a stored z3 (mvf_conv2d_nhwc_fwd_bnbwd_sums / _apply): dgamma / dbeta into
+        the flat gradient buffer, returns dz3."""
+        ho, wo = self.out_hw(h, w)
+        d = self.desc(n, h, w, ho, wo, self.cin)
+        m = n * ho * wo
+        ws = _conv_ws(a_in.device)
+        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        part = self.eng.buf((id(self), "bwpart"), (rows, self.cout, 2), torch.float32)
+        self.launch_bwd_sums(d, a_in, g, bits, bn, part, ws)
+        check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cout, _p(bn.dgamma), _p(bn.dbeta), _st()), "mvf_bn_bwd_finalize")
+        dz = self.eng.buf((id(bn), "dz"), (m, self.cout))
+        self.launch_bwd_apply(d, a_in, g, bits, bn, dz, ws)
+        return dz
+
+    def launch_bwd_sums(self, d, a_in, g, bits, bn, part, ws):
+        check(lib.mvf_conv2d_nhwc_fwd_bnbwd_sums(C.byref(d), _p(a_in), None, _p(self.wp), _p(g), _p(bits), _p(bn.mean), _p(bn.invstd), _p(part),
+                                                 _p(ws), ws.numel(), _st()), "conv + bn backward sums")
+
+    def launch_bwd_apply(self, d, a_in, g, bits, bn, dz, ws):
+        check(lib.mvf_conv2d_nhwc_fwd_bnbwd_apply(C.byref(d), _p(a_in), None, _p(self.wp), _p(g), _p(bits), _p(bn.gamma), _p(bn.mean), _p(bn.invstd),
+                                                  _p(bn.dgamma), _p(bn.dbeta), _p(dz), _p(ws), ws.numel(), _st()), "conv + bn backward apply")
 
     def launch_fwd_apply(self, d, x, bn, residual, rbn, out, bits, ws):
         """Exactly one implicit-GEMM launch (bench.py brackets this call with HIP events)."""
@@ -409,6 +433,17 @@ class _TBlock(object):
         f = eng.fuse_bn3_apply
         return f == 2 or (f == 1 and self.c3.cin <= 128)
 
+    def z3_free(self, eng):
+        """[r3] The block never stores z3 (reference resnet.py:229-244: out = relu(bn3(conv3(a2)) + identity)): a statistics-only conv3 pass, the
+        fused apply pass, and bn3's backward on the recomputed conv (eng.z3_free).  Plain blocks only: a downsample block's paired backward
+        reads z3 and z_d in one pass over g; needs batch statistics fused into the conv epilogue."""
+        if not (eng.z3_free and self.cd is None and self.fuse_apply(eng) and eng.fuse_stats and not self.b3.frozen):
+            return False
+        # measured per block in the bf16 step (us; stored-z3 path -> recompute path): statistics-only pass 148 -> 79 (layer1) / 75 -> 52 (layer2),
+        # backward sums 168 -> 205 / 102 -> 119 (the conv kernel's sum epilogue streams g at 2.7 TB/s, the BatchNorm kernel at 5.2), backward apply
+        # 242 -> 204 / 116 -> 119: -70 per layer1 block, ~0 per layer2 block -> planes <= 64 by default, 2 = every block with the fused apply
+        return eng.z3_free == 2 or self.c3.cin <= 64
+
     def forward(self, x, nt, h, w, c, eng):
         m = nt * h * w
         s = dict(x=x, h=h, w=w, c=c)
@@ -435,7 +470,7 @@ class _TBlock(object):
         z2, ho, wo = self.c2.forward(a1, nt, h, w, bn=self.b2)
         m2 = nt * ho * wo
         a2 = self.b2.apply(z2, m2, 1)
-        z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3)
+        z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3, store=not self.z3_free(eng))
         if self.cd is not None:
             if side is not None:
                 eng.main_stream().wait_stream(side)               # the downsample branch (queued before conv1, see above)
@@ -471,6 +506,8 @@ class _TBlock(object):
                 aux.wait_stream(eng.main_stream())
                 with _on_stream(aux):
                     resid_aux = self.cd.dgrad(dzd, nt, ho, wo, h, w)
+        elif s["z3"] is None:          # z3 was never stored: bn3's backward on the recomputed conv3
+            dz3 = self.c3.bwd_recompute(s["a2"], g, bits, nt, ho, wo, self.b3)
         else:
             dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 4, ymask=bits)
         fuse = eng.fuse_bn_bwd_sums
@@ -599,6 +636,7 @@ class _ParamStore(object):
     overlap_downsample = os.environ.get("MVF_SIDE_DOWNSAMPLE", "1") != "0"     # forward: downsample branch on the side stream
     keep_io = False            # keep references to every block's input / output / gradients after backward (teacher-forced parity tests)
     fuse_stats = True          # BatchNorm batch statistics accumulated in the producing conv's epilogue
+    z3_free = int(os.environ.get("MVF_Z3_FREE", "1"))        # [r3] plain blocks with the fused apply: z3 never stored (0 off, 1 planes <= 64, 2 all of them)
     fuse_bn3_apply = int(os.environ.get("MVF_FUSE_BN3_APPLY", "1"))      # [r3] bn3 apply + residual + ReLU as a second conv3 pass (0 / 1 planes <= 128 / 2 all)
     fuse_bn_bwd_sums = os.environ.get("MVF_FUSE_BN_BWD", "1") != "0"    # ... and the backward sums in the data gradient's
     pair_bn_bwd = os.environ.get("MVF_PAIR_BN_BWD", "1") != "0"         # downsample blocks: bn3 + downsample-BN backward in one pass over g

@@ -883,11 +883,22 @@ def test_engine_switch_variants_reproduce_the_default_step(dtype):
 
     base = run()
     # [r3] fuse_bn3_apply: bn3's apply + residual + ReLU as the epilogue of a second conv3 pass (0 = the pass over z3, 2 = every block incl. layer4)
-    for attrs in (dict(overlap_downsample_bwd=True), dict(fuse_stem_bwd=2), dict(pair_bn_bwd=False), dict(stem_wgrad_main=False),
-                  dict(fuse_bn3_apply=0), dict(fuse_bn3_apply=2)):
+    for attrs in (dict(overlap_downsample_bwd=True), dict(fuse_stem_bwd=2), dict(pair_bn_bwd=False), dict(stem_wgrad_main=False)):
         got = run(**attrs)
         assert got[0] == base[0], attrs
         assert torch.equal(got[1], base[1]), attrs
+    base0 = run(z3_free=0)           # (with z3 stored everywhere: the apply fusion alone changes no bit)
+    for attrs in (dict(fuse_bn3_apply=0), dict(fuse_bn3_apply=2)):
+        got = run(z3_free=0, **attrs)
+        assert got[0] == base0[0], attrs
+        assert torch.equal(got[1], base0[1]), attrs
+    # [r3] z3_free: the plain blocks' bn3 backward on the recomputed conv3 sums dgamma / dbeta per 128-row tile instead of per row band: another
+    # summation order (one step; the forward -- statistics-only pass + fused apply -- is bit-identical, so the loss is)
+    ref = run(steps=1)
+    for z3f in (0, 2):
+        got = run(steps=1, z3_free=z3f)
+        assert got[0] == ref[0], z3f
+        assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-5 if dtype == torch.float32 else 1e-3), z3f
     # one step only: the 2-clip batch-statistics network amplifies last-bit differences by orders of magnitude per step
     got, ref = run(steps=1, fuse_stem_bwd=0), run(steps=1)
     tol = 1e-5 if dtype == torch.float32 else 1e-3          # bf16: the stem's dz is re-rounded from sums that differ in the last bits
@@ -1387,3 +1398,56 @@ def test_conv_bnapply_pass_equals_bn_apply_on_the_stored_conv_output(shape, dtyp
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
     assert torch.equal(gbits, wbits)
     assert 0.2 < float((want > 0).float().mean()) < 0.8          # the ReLU and the bits are exercised on both sides
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 9, 7, 64, 256), (3, 6, 6, 128, 96), (1, 14, 14, 256, 1024), (5, 5, 5, 32, 64), (4, 16, 16, 128, 512)], ids=str)
+def test_bn_backward_on_the_recomputed_conv_equals_the_backward_on_the_stored_output(shape, dtype):
+    """[r3] mvf_conv2d_nhwc_fwd_bnbwd_sums / _apply (BatchNorm backward of bn3 without a stored z3) against mvf_bn_bwd_reduce / mvf_bn_bwd_apply_masked
+    (mask mode 4) on the z3 the forward stored: dz3 BIT FOR BIT given the same dgamma / dbeta, the sums to fp32 summation order; and the
+    statistics-only first pass (y = NULL) leaves the partial sums unchanged."""
+    from mvfnet_amd import _lib
+    from mvfnet_amd._lib import ConvDesc
+    lib, check = _lib.lib, _lib.check
+    n, h, w, cin, cout = shape
+    dt = 0 if dtype == torch.float32 else 1
+    g_ = torch.Generator().manual_seed(cin * 3 + cout)
+    m = n * h * w
+    x = torch.randn(m, cin, generator=g_).to(dtype).cuda()
+    wgt = (torch.randn(cout, cin, 1, 1, generator=g_) * (2.0 / cin) ** 0.5).cuda()
+    wp = torch.empty(cout, 1, 1, cin, dtype=dtype, device="cuda")
+    check(lib.mvf_pack_conv_weight(P(wgt), cout, cin, 1, 1, 1, cin, None, P(wp), dt, None))
+    gout = torch.randn(m, cout, generator=g_).to(dtype).cuda()
+    bits = torch.randint(0, 16, (m, cout // 4), generator=g_, dtype=torch.uint8).cuda()
+    gamma = (torch.rand(cout, generator=g_) + 0.5).cuda()
+    mean, invstd = (torch.randn(cout, generator=g_) * 0.1).cuda(), (torch.rand(cout, generator=g_) + 0.5).cuda()
+    zero = torch.zeros(cout, device="cuda")
+    d = ConvDesc(n, h, w, cin, cout, 1, 1, 1, 0, h, w, cin, dt, 0, 0, 0, 0, 0)
+    ws = torch.zeros(max(lib.mvf_conv2d_workspace_bytes(C.byref(d)), 1), dtype=torch.uint8, device="cuda")
+    rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+    part, part0 = torch.empty(cout, rows, 2, device="cuda"), torch.full((cout, rows, 2), float("nan"), device="cuda")
+    z3 = torch.empty(m, cout, dtype=dtype, device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(x), None, P(wp), P(z3), P(part), None, P(ws), ws.numel(), None))
+    check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(x), None, P(wp), None, P(part0), None, P(ws), ws.numel(), None))      # statistics only
+    torch.cuda.synchronize()
+    assert torch.equal(part, part0)
+    # reference: reduce + apply on the stored z3
+    bws = torch.empty(lib.mvf_bn_workspace_bytes(m, cout), dtype=torch.uint8, device="cuda")
+    dg, db = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
+    check(lib.mvf_bn_bwd_reduce(P(gout), cout, P(z3), P(bits), m, cout, P(mean), P(invstd), P(zero), P(zero), 4, None, P(dg), P(db), P(bws), bws.numel(), dt, None))
+    want = torch.empty_like(z3)
+    check(lib.mvf_bn_bwd_apply_masked(P(gout), cout, P(z3), P(bits), m, cout, P(gamma), P(mean), P(invstd), P(zero), P(zero), P(dg), P(db), 4, P(want), dt, None))
+    # recompute path
+    sp = torch.full((cout, rows, 2), float("nan"), device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd_bnbwd_sums(C.byref(d), P(x), None, P(wp), P(gout), P(bits), P(mean), P(invstd), P(sp), P(ws), ws.numel(), None))
+    dg2, db2 = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
+    check(lib.mvf_bn_bwd_finalize(P(sp), rows, cout, P(dg2), P(db2), None))
+    got = torch.full_like(z3, 7.0)
+    check(lib.mvf_conv2d_nhwc_fwd_bnbwd_apply(C.byref(d), P(x), None, P(wp), P(gout), P(bits), P(gamma), P(mean), P(invstd), P(dg), P(db), P(got), P(ws), ws.numel(), None))
+    torch.cuda.synchronize()
+    assert torch.isfinite(sp).all()
+    assert rel_err(dg2.cpu().numpy(), dg.cpu().numpy()) < 3e-6 and rel_err(db2.cpu().numpy(), db.cpu().numpy()) < 3e-6
+    if dtype == torch.bfloat16:
+        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    else:           # fp32: the two kernels contract a * (g - d0 - (z - mu) * kx) into fused multiply-adds differently (last-bit differences)
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-6
