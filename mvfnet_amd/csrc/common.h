@@ -81,6 +81,19 @@ __device__ __forceinline__ float hswish_grad_f(float u) {
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// the direct 7x7 stride-2 stem conv (stem_direct.hip), reached from conv_nhwc.hip's conv_fwd_impl when the launch is the stem's
+struct StemDirectArgs {
+    const void* x;              // padded NHWC4 operand (mvf_stem_prep), (N, H, W, 4) bf16
+    const void* w;              // packed weights [64][7][8][4] bf16
+    void* y;                    // (N, Ho, Wo, 64) bf16
+    const float* bias;          // epi 4
+    float* stats_part;          // epi 1: [64][stats_rows][2]
+    const float* stats_shift;
+    int stats_rows, epi;        // epi 1: + BatchNorm statistics (training), 4: bias + ReLU (inference)
+    int N, H, W, Ho, Wo;
+    long wK;
+};
 #ifdef __HIPCC__
 // LDS-DMA issued from inline asm: hipcc counts a builtin LDS-DMA as a pending LDS write and drains it (vmcnt(0)) before the
 // next ds_read -- exactly the overlap this variant exists for -- so the statement is hidden from its bookkeeping and the loop

@@ -1868,6 +1868,11 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
     return mvf_conv2d_nhwc_fwd_ws(d, x, x2, w_packed, bias, residual, y, nullptr, 0, stream);
 }
 
+}
+namespace mvf_internal {
+int stem_direct_launch(const StemDirectArgs& a, hipStream_t st);
+}
+extern "C" {
 struct BnBwdSums {            // optional: the data gradient also accumulates the BatchNorm-backward sums of the BN it feeds
     const void* z;
     const float *mean, *invstd, *scale, *shift;
@@ -2049,6 +2054,16 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
         if (narrow) return launch_conv<bf16_t, 4, 1, 1, 2>(aa, skh, st);
         return launch_conv<bf16_t, 2, 2, 2, 2>(aa, skh, st);
     };
+    // the stem (7 x 1 taps over the 32-"channel" view of the padded NHWC4 operand, stride 2): its own direct kernel (stem_direct.hip)
+    if (dil == 1 && d->dtype == MVF_BF16 && d->kh == 7 && d->kw == 1 && d->cin == 32 && d->x_pix_stride == 4 && d->stride == 2 && d->pad == 0 &&
+        d->cout == 64 && !d->split_c && !residual && !res_mask && !bnb && !mf && !ap && !bw && y && d->res_c0 <= 0) {
+        const int epi = (stats_part && !bias && !d->relu) ? 1 : ((bias && d->relu && !stats_part) ? 4 : 0);
+        if (epi) {
+            StemDirectArgs s = {x, w_packed, y, bias, stats_part, stats_shift, a.stats_rows, epi, d->n, d->h, d->w, d->ho, d->wo, a.wK};
+            const int rc = mvf_internal::stem_direct_launch(s, st);
+            if (rc != -1) return rc;
+        }
+    }
     if (dil == 1) return launch(a);
     // Data gradient of a stride-s conv: output pixel (ih, iw) only sees taps with (ih - pad + kh) % s == 0, so the s*s
     // parity classes (ih % s, iw % s) are independent plain stride-1 convs over the gradient map with ceil(k/s)-tap

@@ -142,6 +142,62 @@ def test_stem_maxpool_head_ops_vs_oracle():
         assert rel_err(avg.cpu().numpy(), fn(ref).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 64), (2, 32, 32), (1, 48, 80), (2, 224, 224)], ids=lambda s: "n%d_%dx%d" % s)
+def test_stem_direct_conv_vs_oracle_and_the_implicit_gemm(shape):
+    """[r3] The bf16 stem (resnet.py:420-431 conv1) runs on its own direct kernel (csrc/stem_direct.hip: input patch staged once, weights in
+    registers); MVF_STEM_DIRECT=0 sends the same call to the implicit-GEMM kernel.  Both against F.conv2d on the bf16-rounded operands; the
+    two kernels against each other (same products, same k order: outputs within one bf16 rounding of the fp32 sum, statistics of the stored
+    values to summation order).  (1, 48, 80) has no whole statistic rows per row band: the training epilogue falls back, the inference one does not."""
+    import os
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    bias = (torch.randn(64, generator=g) * 0.2).cuda()
+    shift = (torch.randn(64, generator=g) * 0.1).cuda()
+    hp, wp = h + 6, (w + 6 + 2 + 1) // 2 * 2
+    ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    xg, wg = x.cuda(), wt.cuda()
+    xp = torch.empty(n, hp, wp, 4, device="cuda", dtype=torch.bfloat16)
+    check(lib.mvf_stem_prep(P(xg), n, 3, h, w, 3, wp, P(xp), 1, None))
+    wpk = torch.empty(64, 7, 8, 4, device="cuda", dtype=torch.bfloat16)
+    check(lib.mvf_pack_conv_weight(P(wg), 64, 3, 7, 7, 8, 4, None, P(wpk), 1, None))
+    ref = F.conv2d(x.bfloat16().float(), wt.bfloat16().float(), stride=2, padding=3)          # fp32 sums of the bf16 products
+    m = n * ho * wo
+
+    def run(direct):
+        os.environ["MVF_STEM_DIRECT"] = "1" if direct else "0"
+        try:
+            d = _lib.ConvDesc(n, hp, wp, 32, 64, 7, 1, 2, 0, ho, wo, 4, 1, 0, 0, 0, 0, 0)
+            rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+            z = torch.full((m, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+            part = torch.full((64, rows, 2), float("nan"), device="cuda")
+            check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(xp), None, P(wpk), P(z), P(part), P(shift), None, 0, None))
+            d.relu = 1
+            y = torch.full((m, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+            check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(xp), None, P(wpk), P(bias), None, P(y), None, 0, None))
+            torch.cuda.synchronize()
+            return z, part.double().sum(1), y
+        finally:
+            os.environ.pop("MVF_STEM_DIRECT", None)
+
+    z1, st1, y1 = run(True)
+    z0, st0, y0 = run(False)
+    nchw = lambda t: t.float().cpu().reshape(n, ho, wo, 64).permute(0, 3, 1, 2).numpy()
+    for z, st, y in ((z1, st1, y1), (z0, st0, y0)):
+        assert rel_err(nchw(z), ref.numpy()) < 6e-3
+        assert rel_err(nchw(y), F.relu(ref + bias.cpu().view(1, -1, 1, 1)).numpy()) < 6e-3
+        dz = z.double() - shift.double()                              # the statistics are those of the STORED values, minus the shift
+        assert rel_err(st[:, 0].cpu().numpy(), dz.sum(0).cpu().numpy()) < 1e-4
+        assert rel_err(st[:, 1].cpu().numpy(), (dz * dz).sum(0).cpu().numpy()) < 1e-5
+    # the two kernels: same k order -> identical except where the fp32 sums differ in their last bits right at a rounding boundary
+    assert (z1 != z0).float().mean().item() < 1e-3 and rel_err(z1.float().cpu().numpy(), z0.float().cpu().numpy()) < 1e-3
+    assert (y1 != y0).float().mean().item() < 1e-3
+
+
 @pytest.mark.parametrize("case", [
     (256, 14, 14, 256, 256, 3, 1, 1),     # 784 tiles on 512 slots: 1 full wave + stream-K tail of 272 tiles
     (256, 7, 7, 512, 512, 3, 1, 1),       # 392 tiles: everything is tail
