@@ -42,6 +42,7 @@ struct KArgs {
     int stats_rows;
     int H, W, Ho, Wo, R;
     int tiles_per_frame, nblocks;      // 32-pixel blocks per tile
+    int tiles, tiles_per_wg;           // a workgroup walks tiles_per_wg consecutive tiles (the weights are loaded once)
     int patch_units;                   // 16-byte units of the patch
     int patch_lds;                     // bytes reserved for it (whole 1 KB DMA instructions)
     unsigned fd_wo_mul, fd_wo_shr, fd_tpf_mul, fd_tpf_shr;
@@ -53,16 +54,16 @@ __global__ __launch_bounds__(256, 2) void stem_direct_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int frame = fdiv(blockIdx.x, a.fd_tpf_mul, a.fd_tpf_shr), tile = blockIdx.x - frame * a.tiles_per_frame;
-    const int oh0 = tile * a.R;
     const int row_bytes = a.W * 8;
-    // ---- the input patch: rows [2 oh0, 2 oh0 + 2R + 5) of this frame's padded image, contiguous ----
-    {
+    auto stage_patch = [&](int t) {          // rows [2 oh0, 2 oh0 + 2R + 5) of the tile's frame (padded image), contiguous in memory
+        const int frame = fdiv(t, a.fd_tpf_mul, a.fd_tpf_shr), oh0 = (t - frame * a.tiles_per_frame) * a.R;
         const char* src = a.x + ((long)frame * a.H + 2 * oh0) * row_bytes;
         const i32x4 rs = rsrc_words(src, (unsigned)a.patch_units * 16u);
-        for (int u0 = wave * 64; u0 < a.patch_units; u0 += 256)         // (rows past the patch: out-of-range offsets DMA zeros)
+        for (int u0 = wave * 64; u0 < a.patch_units; u0 += 256)         // (units past the patch: out-of-range offsets DMA zeros)
             glds16(rs, (unsigned)(u0 * 16), (unsigned)(u0 + lane) * 16u);
-    }
+    };
+    const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(t_begin + a.tiles_per_wg, a.tiles);
+    stage_patch(t_begin);
     // ---- the weights: fragment (k-step t, column block j) = 8 K-values of output channel 32 j + (lane & 31) ----
     bf16x8 wf[kKS][2];
     {
@@ -96,10 +97,11 @@ __global__ __launch_bounds__(256, 2) void stem_direct_kernel(KArgs a) {
             kk[0] = u.x; kk[1] = u.y; kk[2] = u.z; kk[3] = u.w; kk[4] = v.x; kk[5] = v.y; kk[6] = v.z; kk[7] = v.w;
         }
     }
+    char* stg = smem + a.patch_lds + wave * kStgBytes;
+    for (int t = t_begin; t < t_end; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
-    char* stg = smem + a.patch_lds + wave * kStgBytes;
+    const int frame = fdiv(t, a.fd_tpf_mul, a.fd_tpf_shr), oh0 = (t - frame * a.tiles_per_frame) * a.R;
     const long m0 = ((long)frame * a.Ho + oh0) * a.Wo;           // first output pixel of the tile
     char* ytile = a.y + m0 * 128;
     for (int mb = wave; mb < a.nblocks; mb += 4) {
@@ -115,12 +117,13 @@ __global__ __launch_bounds__(256, 2) void stem_direct_kernel(KArgs a) {
             fa[2 * kh] = *reinterpret_cast<const uint4*>(ap + kh * row_bytes);
             fa[2 * kh + 1] = *reinterpret_cast<const uint4*>(ap + kh * row_bytes + 32);
         }
+        __builtin_amdgcn_sched_barrier(0);       // all 14 fragment reads in flight before the first matrix instruction (left alone, the scheduler issues them pair by pair)
 #pragma unroll
-        for (int t = 0; t < kKS; ++t) {
+        for (int t2 = 0; t2 < kKS; ++t2) {
             bf16x8 av;
-            __builtin_memcpy(&av, &fa[t], 16);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][0], av, acc[0], 0, 0, 0);     // D^T: pixel = lane & 31, channel = 8 (r >> 2) + 4 half + (r & 3)
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][1], av, acc[1], 0, 0, 0);
+            __builtin_memcpy(&av, &fa[t2], 16);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t2][0], av, acc[0], 0, 0, 0);     // D^T: pixel = lane & 31, channel = 8 (r >> 2) + 4 half + (r & 3)
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t2][1], av, acc[1], 0, 0, 0);
         }
         // ---- transpose through the wave's slab: rows = pixels, 128 B of channels ----
 #pragma unroll
@@ -161,8 +164,11 @@ __global__ __launch_bounds__(256, 2) void stem_direct_kernel(KArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();                                              // every wave is done with the patch (and its slab)
+    if (t + 1 < t_end) stage_patch(t + 1);
     if constexpr (EPI == 1) {
-        // column sums: over the 8 row lanes of a channel group (fixed butterfly), then the 4 waves in order; one partial row per workgroup
+        // column sums of the tile: over the 8 row lanes of a channel group (fixed butterfly), then the 4 waves in order; one partial row
+        // per tile, the other partial rows it covers are zeros
 #pragma unroll
         for (int off = 8; off < 64; off <<= 1)
 #pragma unroll
@@ -170,12 +176,13 @@ __global__ __launch_bounds__(256, 2) void stem_direct_kernel(KArgs a) {
                 s1[k] += __shfl_xor(s1[k], off, 64);
                 s2[k] += __shfl_xor(s2[k], off, 64);
             }
-        __syncthreads();                                          // every wave is done with its slab
         float2* red = reinterpret_cast<float2*>(smem + a.patch_lds);
         if (lane < 8) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) red[wave * 64 + lane * 8 + k] = make_float2(s1[k], s2[k]);
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
         __syncthreads();
         const int rows_per_tile = a.nblocks / 4;                  // partial rows (one per 128 output pixels) this tile covers
         const long row0 = m0 >> 7;
@@ -188,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void stem_direct_kernel(KArgs a) {
             const int c = e / (rows_per_tile - 1), r = e - c * (rows_per_tile - 1) + 1;
             reinterpret_cast<float2*>(a.stats_part)[(long)c * a.stats_rows + row0 + r] = make_float2(0.f, 0.f);
         }
+    }
     }
 }
 
@@ -228,8 +236,13 @@ int stem_direct_launch(const StemDirectArgs& s, hipStream_t st) {
     fd_make_local((unsigned)s.Wo, a.fd_wo_mul, a.fd_wo_shr);
     fd_make_local((unsigned)a.tiles_per_frame, a.fd_tpf_mul, a.fd_tpf_shr);
     const size_t lds = (size_t)a.patch_lds + 4 * kStgBytes;
-    const long grid = (long)s.N * a.tiles_per_frame;
-    if (grid >= (1L << 31)) return -1;
+    const long tiles = (long)s.N * a.tiles_per_frame;
+    if (tiles >= (1L << 31)) return -1;
+    a.tiles = (int)tiles;
+    const char* tw = getenv("MVF_STEM_TPW");
+    a.tiles_per_wg = tw ? atoi(tw) : (int)((tiles + 511) / 512);           // ~2 workgroups per CU, each reusing its weight registers
+    if (a.tiles_per_wg < 1) a.tiles_per_wg = 1;
+    const long grid = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     if (s.epi == 1) {
         static bool attr = false;
         if (!attr) { MVF_HIP_OK(hipFuncSetAttribute((const void*)stem_direct_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr = true; }
