@@ -94,6 +94,25 @@ struct StemDirectArgs {
     int N, H, W, Ho, Wo;
     long wK;
 };
+// the direct 3x3 conv with 64 input / 64 output channels (conv3x3_c64.hip), reached from conv_fwd_impl for layer1's conv2 and its data gradient
+struct Conv3x3C64Args {
+    const void* x;              // (N, H, W, xps >= 64) bf16, channels [0, 64)
+    const void* w;              // packed weights [64][3][3][64] bf16 (forward pack, or the data-gradient pack)
+    void* y;                    // (N, H, W, 64) bf16
+    const float* bias;          // epi 4
+    float* stats_part;          // epi 1 / 6: [64][stats_rows][2]
+    const float* stats_shift;   // epi 1
+    const void* bn_z;           // epi 6: the pre-activation the gradient's ReLU gate is taken from, (N, H, W, 64)
+    const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
+    int stats_rows, epi;        // epi 1: + BatchNorm statistics, 2: plain, 4: bias + ReLU, 6: + BatchNorm-backward sums
+    int N, H, W, xps;
+    long wK;
+};
+namespace mvf_internal {
+int stem_direct_launch(const StemDirectArgs& a, hipStream_t st);
+int conv3x3_c64_launch(const Conv3x3C64Args& a, hipStream_t st);
+}
+
 #ifdef __HIPCC__
 // LDS-DMA issued from inline asm: hipcc counts a builtin LDS-DMA as a pending LDS write and drains it (vmcnt(0)) before the
 // next ds_read -- exactly the overlap this variant exists for -- so the statement is hidden from its bookkeeping and the loop

@@ -1,0 +1,314 @@
+// 3x3 stride-1 pad-1 conv with 64 input and 64 output channels (layer1's conv2 and its data gradient: reference
+// codes/models/backbones/resnet.py:213-224 conv2 of a Bottleneck with planes = 64, and its autograd backward) as a DIRECT convolution for
+// gfx950, bf16 storage, fp32 accumulation.
+//
+// Why: with N = 64 output channels the implicit-GEMM kernel (conv_nhwc.hip) moves 9 x the input through L2 -> LDS (one 128 B row per tap and
+// output pixel: 925 MB per launch at the C3 shape, 8.2 TB/s = the chip's L2 -> LDS ceiling) for 103 MB of input: 113 / 131 us (forward /
+// data gradient + BatchNorm sums) against 37 us for its HBM bytes and 24 us for its matrix work (profiles/r03_per_layer_bf16_train.txt).  Here
+//   * a workgroup (8 waves, one per CU) walks the row bands of its frames: R = 4 output rows = 224 pixels per band, whose (R + 2) x (W + 2)
+//     ZERO-PADDED input window is staged once by LDS-DMA (out-of-range offsets DMA zeros: no tap masks anywhere), double-buffered: band t + 1
+//     lands while band t is computed;
+//   * the window is UNIT-MAJOR in LDS ([8 units of 16 B = 8 channels][slot][16 B]): the operand fragment of 32 consecutive pixels is 32
+//     consecutive 16-byte units (conflict-free without a swizzle) and every tap / k-step is a compile-time immediate offset on ONE base
+//     address per 32-pixel block;
+//   * a wave owns 32 of the 64 output channels and keeps ALL its weights (9 taps x 64 ch x 32: 36 fragments = 144 VGPRs) in registers: one
+//     ds_read_b128 per matrix instruction, no weight traffic at all after the prologue;
+//   * the waves with the fewest pixel blocks issue the next band's DMA and are the only ones that ever wait for memory (vmcnt counts a wave's
+//     own loads AND stores): the others stream their outputs without draining them;
+//   * epilogues: 1 = + BatchNorm batch-statistic partial sums (training forward), 2 = plain, 4 = bias + ReLU (inference), 6 = + the
+//     BatchNorm-backward sums of the BatchNorm the gradient feeds (sum gm, sum gm * xhat with gm gated by bn_scale * z + bn_shift > 0).
+//     Partial rows: one per band, written at row = band index; the rows past the band count are zeroed (the finalize sums all rows).
+// Arithmetic = the implicit-GEMM kernel's: the same bf16 products accumulated in fp32 in the same k order (tap-major), rounded once.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kR = 4;                        // output rows per band
+constexpr int kSlabPitch = 72;               // bf16 C slab: 32 channels = 64 B per pixel + 2 dwords
+constexpr int kSlabBytes = 32 * kSlabPitch;
+
+__device__ __forceinline__ int fdiv(int n, unsigned mul, unsigned shr) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shr); }
+
+struct KArgs {
+    const char* x;
+    const char* w;
+    char* y;
+    const float* bias;
+    float* stats_part;
+    const float* stats_shift;
+    const char* bn_z;
+    const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
+    int stats_rows;
+    int H, xps;                        // image height, input pixel pitch in elements
+    int bands_per_frame, bands, bands_per_wg;
+    unsigned fd_bpf_mul, fd_bpf_shr;
+    long wK;
+};
+
+template <int W>
+struct Geo {
+    static constexpr int WP = W + 2;                              // padded row
+    static constexpr int NS = (kR + 2) * WP;                      // window slots
+    static constexpr int NSP = (NS + 63) / 64 * 64;               // ... in whole DMA instructions (64 slots of one unit)
+    static constexpr int BUF = 8 * NSP * 16;                      // one window buffer
+    static constexpr int NB = kR * W / 32;                        // 32-pixel blocks per band
+    static_assert((kR * W) % 32 == 0, "a band is whole 32-pixel blocks");
+    static constexpr int LDS = 2 * BUF + 8 * kSlabBytes;
+};
+
+template <int EPI, int W>
+__global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
+    using G = Geo<W>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nb = wave & 1, mg = wave >> 1;                     // output-channel half, pixel-block group (blocks mg, mg + 4, ...)
+    const bool loader = mg == 3;                                  // the group with the fewest blocks stages the windows
+    const int t_begin = blockIdx.x * a.bands_per_wg, t_end = min(t_begin + a.bands_per_wg, a.bands);
+    const unsigned pitch_b = (unsigned)a.xps * 2u;
+    // ---- window staging: DMA instruction (slot group g, unit u) fills slots [64 g, 64 g + 64) of unit u; lane = slot ----
+    constexpr int NG = G::NSP / 64;                               // slot groups; the two loader waves take alternate ones
+    auto stage = [&](int t, int buf) {
+        const int frame = fdiv(t, a.fd_bpf_mul, a.fd_bpf_shr), oh0 = (t - frame * a.bands_per_frame) * kR;
+        const i32x4 rs = rsrc_words(a.x + (long)frame * a.H * W * pitch_b, (unsigned)((long)a.H * W * pitch_b));
+#pragma unroll
+        for (int g = nb; g < NG; g += 2) {
+            const int slot = g * 64 + lane;
+            const int pr = slot / G::WP, pc = slot - pr * G::WP;     // (compile-time divisor)
+            const int ih = oh0 - 1 + pr, iw = pc - 1;
+            const bool ok = slot < G::NS && iw >= 0 && iw < W && ih >= 0 && ih < a.H;
+            const unsigned off = ok ? (unsigned)(ih * W + iw) * pitch_b : 0x80000000u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                glds16(rs, (unsigned)(buf * G::BUF + (u * G::NSP + g * 64) * 16), off + (ok ? u * 16u : 0u));
+        }
+    };
+    if (loader && t_begin < t_end) stage(t_begin, 0);
+    // ---- the weights of this wave's 32 output channels: fragment (tap, k-step) = 8 input channels of output channel 32 nb + (lane & 31) ----
+    bf16x8 wf[9][4];
+    {
+        const char* wp = a.w + ((long)(nb * 32 + l31) * a.wK + half * 8) * 2;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 v = *reinterpret_cast<const uint4*>(wp + (tap * 64 + ks * 16) * 2);
+                __builtin_memcpy(&wf[tap][ks], &v, 16);
+            }
+    }
+    const int cq = lane & 7, rq = lane >> 3;                     // read-back: 8-byte channel group (4 channels), row within 8
+    const int ch0 = nb * 32 + cq * 4;                             // this lane's 4 output channels
+    float bias[4][4];
+    (void)bias;
+    if constexpr (EPI == 4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + nb * 32 + 8 * g + 4 * half);
+            bias[g][0] = b.x; bias[g][1] = b.y; bias[g][2] = b.z; bias[g][3] = b.w;
+        }
+    }
+    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), b_mu = kk, b_rs = kk, b_sc = kk, b_sh = kk;
+    (void)b_mu; (void)b_rs; (void)b_sc; (void)b_sh;
+    if constexpr (EPI == 1) {
+        if (a.stats_shift) kk = *reinterpret_cast<const float4*>(a.stats_shift + ch0);
+    }
+    if constexpr (EPI == 6) {
+        b_mu = *reinterpret_cast<const float4*>(a.bn_mean + ch0); b_rs = *reinterpret_cast<const float4*>(a.bn_invstd + ch0);
+        b_sc = *reinterpret_cast<const float4*>(a.bn_scale + ch0); b_sh = *reinterpret_cast<const float4*>(a.bn_shift + ch0);
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    char* slab = smem + 2 * G::BUF + wave * kSlabBytes;
+    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (loader && t + 1 < t_end) stage(t + 1, buf ^ 1);       // (every wave left that buffer at the barrier below)
+        const int frame = fdiv(t, a.fd_bpf_mul, a.fd_bpf_shr), oh0 = (t - frame * a.bands_per_frame) * kR;
+        const long m0 = ((long)frame * a.H + oh0) * W;             // first output pixel of the band
+        char* yband = a.y + m0 * 128 + nb * 64;
+        const char* zband = a.bn_z + m0 * 128 + nb * 64;
+        (void)zband;
+        const char* win = smem + buf * G::BUF + half * (G::NSP * 16);
+        for (int mb = mg; mb < G::NB; mb += 4) {
+            const int p = mb * 32 + l31;
+            const int orow = p / W, ow = p - orow * W;
+            const char* ap = win + (orow * G::WP + ow) * 16;
+            uint2 zraw[4];
+            (void)zraw;
+            if constexpr (EPI == 6) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    zraw[i] = *reinterpret_cast<const uint2*>(zband + (long)(mb * 32 + rq + 8 * i) * 128 + cq * 8);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // two fragment sets: tap i + 1 is fetched behind the matrix instructions of tap i (the order is pinned: left alone the
+            // scheduler either serialises read -> wait -> 4 MFMAs or hoists all 36 reads and spills)
+            uint4 fa[2][4];
+            auto fetch = [&](int tap, uint4 (&f)[4]) {
+                const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const uint4*>(ap + (kh * G::WP + kw) * 16 + ks * (2 * G::NSP * 16));
+            };
+            fetch(0, fa[0]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) fetch(tap + 1, fa[(tap + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8 av;
+                    __builtin_memcpy(&av, &fa[tap & 1][ks], 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][ks], av, acc, 0, 0, 0);   // D^T: pixel = lane & 31, channel = 8 (r >> 2) + 4 half + (r & 3)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- transpose through the wave's slab: rows = pixels, 64 B = this wave's 32 channels ----
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v0 = acc[4 * g], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
+                if constexpr (EPI == 4) {
+                    v0 = fmaxf(v0 + bias[g][0], 0.f); v1 = fmaxf(v1 + bias[g][1], 0.f);
+                    v2 = fmaxf(v2 + bias[g][2], 0.f); v3 = fmaxf(v3 + bias[g][3], 0.f);
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(v0, v1);
+                pk.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(slab + l31 * kSlabPitch + (8 * g + 4 * half) * 2) = pk;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rq + 8 * i;
+                const uint2 pk = *reinterpret_cast<const uint2*>(slab + row * kSlabPitch + cq * 8);
+                *reinterpret_cast<uint2*>(yband + (long)(mb * 32 + row) * 128 + cq * 8) = pk;
+                if constexpr (EPI == 1 || EPI == 6) {             // sums over what is STORED
+                    const float4 v = make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                                                 __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u));
+                    if constexpr (EPI == 1) {
+                        const float4 d = make_float4(v.x - kk.x, v.y - kk.y, v.z - kk.z, v.w - kk.w);
+                        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+                        s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+                    } else {
+                        const float4 zv = make_float4(__uint_as_float(zraw[i].x << 16), __uint_as_float(zraw[i].x & 0xffff0000u),
+                                                      __uint_as_float(zraw[i].y << 16), __uint_as_float(zraw[i].y & 0xffff0000u));
+                        const float g0 = (zv.x * b_sc.x + b_sh.x) > 0.f ? v.x : 0.f, g1 = (zv.y * b_sc.y + b_sh.y) > 0.f ? v.y : 0.f;
+                        const float g2 = (zv.z * b_sc.z + b_sh.z) > 0.f ? v.z : 0.f, g3 = (zv.w * b_sc.w + b_sh.w) > 0.f ? v.w : 0.f;
+                        s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
+                        s2.x += g0 * ((zv.x - b_mu.x) * b_rs.x); s2.y += g1 * ((zv.y - b_mu.y) * b_rs.y);
+                        s2.z += g2 * ((zv.z - b_mu.z) * b_rs.z); s2.w += g3 * ((zv.w - b_mu.w) * b_rs.w);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (EPI == 1 || EPI == 6) {
+            // the band's column sums: over the 8 row lanes of a channel group (fixed butterfly), then the 4 pixel-block groups in order
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64); s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
+                s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64); s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
+            }
+        }
+        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next window has landed (and this wave's stores are out)
+        __syncthreads();
+        if constexpr (EPI == 1 || EPI == 6) {
+            float4* red = reinterpret_cast<float4*>(smem + 2 * G::BUF);     // (the slabs are idle between the two barriers)
+            if (lane < 8) {
+                red[(mg * 16 + nb * 8 + lane) * 2] = s1;
+                red[(mg * 16 + nb * 8 + lane) * 2 + 1] = s2;
+            }
+            s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            s2 = s1;
+            __syncthreads();
+            if (tid < 64) {                                                  // channel tid = 4 * group + j
+                const float* rf = reinterpret_cast<const float*>(red);
+                const int grp = tid >> 2, j = tid & 3;
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    t1 += rf[((q * 16 + grp) * 2) * 4 + j];
+                    t2 += rf[((q * 16 + grp) * 2 + 1) * 4 + j];
+                }
+                float2* dst = reinterpret_cast<float2*>(a.stats_part) + (long)tid * a.stats_rows;
+                dst[t] = make_float2(t1, t2);
+                for (int r = a.bands + t; r < a.stats_rows; r += a.bands) dst[r] = make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+inline void fd_make_local(unsigned d, unsigned& mul, unsigned& shr) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    shr = l;
+}
+
+template <int EPI, int W>
+int launch_w(const KArgs& a, int grid, hipStream_t st) {
+    auto k = conv3x3_c64_kernel<EPI, W>;
+    static bool attr = false;
+    if (!attr) {
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<W>::LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), Geo<W>::LDS, st, a);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+template <int W>
+int launch_epi(int epi, const KArgs& a, int grid, hipStream_t st) {
+    switch (epi) {
+        case 1: return launch_w<1, W>(a, grid, st);
+        case 2: return launch_w<2, W>(a, grid, st);
+        case 4: return launch_w<4, W>(a, grid, st);
+        case 6: return launch_w<6, W>(a, grid, st);
+    }
+    return -1;
+}
+
+}  // namespace
+
+namespace mvf_internal {
+
+// MVF_OK when launched, -1 when the shape is not this kernel's (the caller falls back to the implicit-GEMM path)
+int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
+    const char* sw = getenv("MVF_CONV3X3_DIRECT");        // A/B switch, read per call: 0 = the implicit-GEMM kernel
+    if (sw && atoi(sw) == 0) return -1;
+    if (s.W != 56 && s.W != 8) return -1;                 // instantiated widths: layer1 at 224 x 224 input (and a small one the tests reach)
+    if (s.H % kR || s.wK != 576 || s.xps < 64 || s.xps % 8) return -1;
+    const long bands = (long)s.N * (s.H / kR);
+    if (bands >= (1L << 30) || (long)s.N * s.H * s.W * s.xps * 2 >= (1L << 40)) return -1;
+    if ((s.epi == 1 || s.epi == 6) && bands > s.stats_rows) return -1;          // one partial row per band
+    KArgs a = {};
+    a.x = (const char*)s.x; a.w = (const char*)s.w; a.y = (char*)s.y; a.bias = s.bias;
+    a.stats_part = s.stats_part; a.stats_shift = s.stats_shift; a.stats_rows = s.stats_rows;
+    a.bn_z = (const char*)s.bn_z; a.bn_mean = s.bn_mean; a.bn_invstd = s.bn_invstd; a.bn_scale = s.bn_scale; a.bn_shift = s.bn_shift;
+    a.H = s.H; a.xps = s.xps; a.wK = s.wK;
+    a.bands_per_frame = s.H / kR;
+    a.bands = (int)bands;
+    fd_make_local((unsigned)a.bands_per_frame, a.fd_bpf_mul, a.fd_bpf_shr);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const char* bw = getenv("MVF_CONV3X3_BPW");
+    a.bands_per_wg = bw ? atoi(bw) : (int)((bands + cus - 1) / cus);            // one workgroup per CU, contiguous bands
+    if (a.bands_per_wg < 1) a.bands_per_wg = 1;
+    const int grid = (int)((bands + a.bands_per_wg - 1) / a.bands_per_wg);
+    if (s.W == 56) return launch_epi<56>(s.epi, a, grid, st);
+    return launch_epi<8>(s.epi, a, grid, st);
+}
+
+}  // namespace mvf_internal

@@ -1868,11 +1868,6 @@ int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2,
     return mvf_conv2d_nhwc_fwd_ws(d, x, x2, w_packed, bias, residual, y, nullptr, 0, stream);
 }
 
-}
-namespace mvf_internal {
-int stem_direct_launch(const StemDirectArgs& a, hipStream_t st);
-}
-extern "C" {
 struct BnBwdSums {            // optional: the data gradient also accumulates the BatchNorm-backward sums of the BN it feeds
     const void* z;
     const float *mean, *invstd, *scale, *shift;
@@ -2061,6 +2056,21 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
         if (epi) {
             StemDirectArgs s = {x, w_packed, y, bias, stats_part, stats_shift, a.stats_rows, epi, d->n, d->h, d->w, d->ho, d->wo, a.wK};
             const int rc = mvf_internal::stem_direct_launch(s, st);
+            if (rc != -1) return rc;
+        }
+    }
+    // layer1's 3x3 (64 -> 64 channels, stride 1) and its data gradient: the direct kernel with register-resident weights (conv3x3_c64.hip)
+    if (dil == 1 && d->dtype == MVF_BF16 && d->kh == 3 && d->kw == 3 && d->cin == 64 && d->cout == 64 && d->stride == 1 && d->pad == 1 &&
+        d->ho == d->h && d->wo == d->w && !d->split_c && !residual && !res_mask && !mf && !ap && !bw && y && d->res_c0 <= 0) {
+        int epi = 0;
+        if (bnb) epi = (!bias && !d->relu && stats_part) ? 6 : 0;
+        else if (stats_part) epi = (!bias && !d->relu) ? 1 : 0;
+        else if (bias && d->relu) epi = 4;
+        else if (!bias && !d->relu) epi = 2;
+        if (epi) {
+            Conv3x3C64Args s = {x, w_packed, y, bias, stats_part, stats_shift, bnb ? bnb->z : nullptr, bnb ? bnb->mean : nullptr, bnb ? bnb->invstd : nullptr,
+                                bnb ? bnb->scale : nullptr, bnb ? bnb->shift : nullptr, a.stats_rows, epi, d->n, d->h, d->w, d->x_pix_stride, a.wK};
+            const int rc = mvf_internal::conv3x3_c64_launch(s, st);
             if (rc != -1) return rc;
         }
     }

@@ -17,10 +17,6 @@
 // Arithmetic = the implicit-GEMM kernel's: the same bf16 products accumulated in fp32 in the same k order (kh-major), rounded once.
 #include "common.h"
 
-namespace mvf_internal {
-int stem_direct_launch(const StemDirectArgs& a, hipStream_t st);
-}
-
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -142,6 +142,72 @@ def test_stem_maxpool_head_ops_vs_oracle():
         assert rel_err(avg.cpu().numpy(), fn(ref).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 56, 56, 64), (5, 56, 56, 128), (4, 8, 8, 64)], ids=lambda s: "n%d_%dx%d_pitch%d" % s)
+def test_conv3x3_c64_direct_vs_oracle_and_the_implicit_gemm(shape):
+    """[r3] layer1's 3x3 (resnet.py:213-224 conv2 at planes = 64) and its data gradient run on a direct kernel (csrc/conv3x3_c64.hip: padded
+    window staged once per row band, the wave's weights in registers); MVF_CONV3X3_DIRECT=0 sends the same calls to the implicit-GEMM kernel.
+    Every epilogue (statistics, plain, bias + ReLU, data gradient + BatchNorm-backward sums) against torch on the bf16-rounded operands and
+    against the other kernel; a pixel pitch wider than the 64 channels read (the input as a slice of a wider tensor)."""
+    import os
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    n, h, w, pitch = shape
+    g = torch.Generator().manual_seed(h + n)
+    xw = torch.randn(n, h, w, pitch, generator=g).bfloat16().cuda()
+    x = xw[..., :64].float().cpu().permute(0, 3, 1, 2)
+    wt = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    bias = (torch.randn(64, generator=g) * 0.2).cuda()
+    shift = (torch.randn(64, generator=g) * 0.1).cuda()
+    wpk = torch.empty(64, 3, 3, 64, device="cuda", dtype=torch.bfloat16)
+    wg = wt.cuda()
+    check(lib.mvf_pack_conv_weight(P(wg), 64, 64, 3, 3, 3, 64, None, P(wpk), 1, None))
+    wdg = torch.empty(64, 3, 3, 64, device="cuda", dtype=torch.bfloat16)
+    check(lib.mvf_pack_conv_weight_dgrad(P(wg), 64, 64, 3, 3, P(wdg), 1, None))
+    wb = wt.bfloat16().float()
+    ref = F.conv2d(x, wb, padding=1)
+    ref_d = F.conv_transpose2d(x, wb, padding=1)                       # the data gradient of conv(., wt) applied to `x` as the incoming gradient
+    zb = torch.randn(n * h * w, 64, generator=g).bfloat16().cuda()     # the pre-activation whose ReLU gate / xhat the sums use
+    mu, rs = (torch.randn(64, generator=g) * 0.1).cuda(), (torch.rand(64, generator=g) + 0.5).cuda()
+    sc, sh = (torch.randn(64, generator=g)).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()
+    m = n * h * w
+
+    def run(direct):
+        os.environ["MVF_CONV3X3_DIRECT"] = "1" if direct else "0"
+        try:
+            d = _lib.ConvDesc(n, h, w, 64, 64, 3, 3, 1, 1, h, w, pitch, 1, 0, 0, 0, 0, 0)
+            rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+            new = lambda: torch.full((m, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+            z, y2, y4, dx = new(), new(), new(), new()
+            part = torch.full((64, rows, 2), float("nan"), device="cuda")
+            sums = torch.full((64, rows, 2), float("nan"), device="cuda")
+            check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(xw), None, P(wpk), P(z), P(part), P(shift), None, 0, None))
+            check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(xw), None, P(wpk), None, None, P(y2), None, 0, None))
+            check(lib.mvf_conv2d_nhwc_dgrad_bnsums(C.byref(d), P(xw), P(wdg), P(dx), P(zb), P(mu), P(rs), P(sc), P(sh), P(sums), None, 0, None))
+            d.relu = 1
+            check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(xw), None, P(wpk), P(bias), None, P(y4), None, 0, None))
+            torch.cuda.synchronize()
+            return z, part.double().sum(1), y2, y4, dx, sums.double().sum(1)
+        finally:
+            os.environ.pop("MVF_CONV3X3_DIRECT", None)
+
+    r1, r0 = run(True), run(False)
+    nchw = lambda t: t.float().cpu().reshape(n, h, w, 64).permute(0, 3, 1, 2).numpy()
+    for z, st, y2, y4, dx, bs in (r1, r0):
+        assert rel_err(nchw(z), ref.numpy()) < 6e-3 and rel_err(nchw(y2), ref.numpy()) < 6e-3
+        assert rel_err(nchw(y4), F.relu(ref + bias.cpu().view(1, -1, 1, 1)).numpy()) < 6e-3
+        assert rel_err(nchw(dx), ref_d.numpy()) < 6e-3
+        dz = z.double() - shift.double()                              # statistics of the STORED values, minus the shift
+        assert rel_err(st[:, 0].cpu().numpy(), dz.sum(0).cpu().numpy()) < 1e-4
+        assert rel_err(st[:, 1].cpu().numpy(), (dz * dz).sum(0).cpu().numpy()) < 1e-5
+        gm = dx.double() * ((zb.float() * sc + sh) > 0)               # the gate in fp32, as the kernels (and bn_apply) evaluate it
+        xhat = ((zb.float() - mu) * rs).double()
+        assert rel_err(bs[:, 0].cpu().numpy(), gm.sum(0).cpu().numpy()) < 1e-4
+        assert rel_err(bs[:, 1].cpu().numpy(), (gm * xhat).sum(0).cpu().numpy()) < 1e-4
+    for a_, b_ in zip((r1[0], r1[2], r1[3], r1[4]), (r0[0], r0[2], r0[3], r0[4])):      # same products, same k order
+        assert (a_ != b_).float().mean().item() < 1e-3 and rel_err(a_.float().cpu().numpy(), b_.float().cpu().numpy()) < 1e-3
+
+
 @pytest.mark.parametrize("shape", [(3, 64, 64), (2, 32, 32), (1, 48, 80), (2, 224, 224)], ids=lambda s: "n%d_%dx%d" % s)
 def test_stem_direct_conv_vs_oracle_and_the_implicit_gemm(shape):
     """[r3] The bf16 stem (resnet.py:420-431 conv1) runs on its own direct kernel (csrc/stem_direct.hip: input patch staged once, weights in
