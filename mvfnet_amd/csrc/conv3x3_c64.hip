@@ -17,7 +17,8 @@
 //     own loads AND stores): the others stream their outputs without draining them;
 //   * epilogues: 1 = + BatchNorm batch-statistic partial sums (training forward), 2 = plain, 4 = bias + ReLU (inference), 6 = + the
 //     BatchNorm-backward sums of the BatchNorm the gradient feeds (sum gm, sum gm * xhat with gm gated by bn_scale * z + bn_shift > 0).
-//     Partial rows: one per band, written at row = band index; the rows past the band count are zeroed (the finalize sums all rows).
+//     Partial rows: ONE per workgroup (its bands' sums), written at row = workgroup index; the rows past the grid are zeroed (the finalize
+//     sums all rows).
 // Arithmetic = the implicit-GEMM kernel's: the same bf16 products accumulated in fp32 in the same k order (tap-major), rounded once.
 #include "common.h"
 
@@ -46,11 +47,13 @@ struct KArgs {
     int bands_per_frame, bands, bands_per_wg;
     unsigned fd_bpf_mul, fd_bpf_shr;
     long wK;
+    int abl;                           // -DMVF_CONV_ABLATE builds: bit 0 no window staging after the first band, bit 1 no pixel blocks, bit 2 no output stores
 };
 
 template <int W>
 struct Geo {
-    static constexpr int WP = W + 2;                              // padded row
+    static constexpr int WP = W + 16;                             // padded row: image column c sits at slot c + 1; 16 more than W, so a 32-pixel block that
+                                                                  // crosses an image row keeps every ds_read_b128 service group on 16 distinct 16-byte slots
     static constexpr int NS = (kR + 2) * WP;                      // window slots
     static constexpr int NSP = (NS + 63) / 64 * 64;               // ... in whole DMA instructions (64 slots of one unit)
     static constexpr int BUF = 8 * NSP * 16;                      // one window buffer
@@ -65,8 +68,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int nb = wave & 1, mg = wave >> 1;                     // output-channel half, pixel-block group (blocks mg, mg + 4, ...)
-    const bool loader = mg == 3;                                  // the group with the fewest blocks stages the windows
+    const int nb = wave & 1, mg = wave >> 1;                     // output-channel half, wave pair
+    // pixel-block group of this pair in band t: (mg + t - t_begin) & 3 -> blocks group, group + 4, ...  The groups ROTATE over the bands so
+    // that every SIMD (waves w and w + 4) gets the same number of blocks over 4 bands (7 blocks = 2 + 2 + 2 + 1), and the pair whose group
+    // has the fewest blocks (group 3) stages the next band's window in this band
     const int t_begin = blockIdx.x * a.bands_per_wg, t_end = min(t_begin + a.bands_per_wg, a.bands);
     const unsigned pitch_b = (unsigned)a.xps * 2u;
     // ---- window staging: DMA instruction (slot group g, unit u) fills slots [64 g, 64 g + 64) of unit u; lane = slot ----
@@ -75,7 +80,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
         const int frame = fdiv(t, a.fd_bpf_mul, a.fd_bpf_shr), oh0 = (t - frame * a.bands_per_frame) * kR;
         const i32x4 rs = rsrc_words(a.x + (long)frame * a.H * W * pitch_b, (unsigned)((long)a.H * W * pitch_b));
 #pragma unroll
-        for (int g = nb; g < NG; g += 2) {
+        for (int gk = 0; gk < (NG + 1) / 2; ++gk) {
+            const int g = nb + 2 * gk;
+            if (g >= NG) break;
             const int slot = g * 64 + lane;
             const int pr = slot / G::WP, pc = slot - pr * G::WP;     // (compile-time divisor)
             const int ih = oh0 - 1 + pr, iw = pc - 1;
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
                 glds16(rs, (unsigned)(buf * G::BUF + (u * G::NSP + g * 64) * 16), off + (ok ? u * 16u : 0u));
         }
     };
-    if (loader && t_begin < t_end) stage(t_begin, 0);
+    if (mg == 3 && t_begin < t_end) stage(t_begin, 0);
     // ---- the weights of this wave's 32 output channels: fragment (tap, k-step) = 8 input channels of output channel 32 nb + (lane & 31) ----
     bf16x8 wf[9][4];
     {
@@ -110,41 +117,49 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
             bias[g][0] = b.x; bias[g][1] = b.y; bias[g][2] = b.z; bias[g][3] = b.w;
         }
     }
-    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), b_mu = kk, b_rs = kk, b_sc = kk, b_sh = kk;
-    (void)b_mu; (void)b_rs; (void)b_sc; (void)b_sh;
+    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), b_mu = kk, b_sc = kk, b_sh = kk;
+    (void)b_mu; (void)b_sc; (void)b_sh;
     if constexpr (EPI == 1) {
         if (a.stats_shift) kk = *reinterpret_cast<const float4*>(a.stats_shift + ch0);
     }
     if constexpr (EPI == 6) {
-        b_mu = *reinterpret_cast<const float4*>(a.bn_mean + ch0); b_rs = *reinterpret_cast<const float4*>(a.bn_invstd + ch0);
+        b_mu = *reinterpret_cast<const float4*>(a.bn_mean + ch0);       // (invstd multiplies the finished sum: sum gm * (z - mean) * invstd)
         b_sc = *reinterpret_cast<const float4*>(a.bn_scale + ch0); b_sh = *reinterpret_cast<const float4*>(a.bn_shift + ch0);
     }
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     char* slab = smem + 2 * G::BUF + wave * kSlabBytes;
-    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // Barriers are raw (LDS only): __syncthreads() would also drain every wave's output stores.  Only the loader waves wait for memory.
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    if (mg == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
 
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
+        const int grp = (mg + t - t_begin) & 3;
+        const bool loader = grp == 3;
+#ifdef MVF_CONV_ABLATE
+        if (!(a.abl & 1))
+#endif
         if (loader && t + 1 < t_end) stage(t + 1, buf ^ 1);       // (every wave left that buffer at the barrier below)
         const int frame = fdiv(t, a.fd_bpf_mul, a.fd_bpf_shr), oh0 = (t - frame * a.bands_per_frame) * kR;
         const long m0 = ((long)frame * a.H + oh0) * W;             // first output pixel of the band
         char* yband = a.y + m0 * 128 + nb * 64;
-        const char* zband = a.bn_z + m0 * 128 + nb * 64;
-        (void)zband;
         const char* win = smem + buf * G::BUF + half * (G::NSP * 16);
-        for (int mb = mg; mb < G::NB; mb += 4) {
+#ifdef MVF_CONV_ABLATE
+        if (!(a.abl & 2))
+#endif
+        for (int mb = grp; mb < G::NB; mb += 4) {
             const int p = mb * 32 + l31;
             const int orow = p / W, ow = p - orow * W;
             const char* ap = win + (orow * G::WP + ow) * 16;
-            uint2 zraw[4];
-            (void)zraw;
+            uint2 zraw[4];                                        // EPI 6: this block's z, in flight under the matrix instructions (fetching one
+            (void)zraw;                                           // block ahead into a second register set measured no faster: 116 vs 111 us)
             if constexpr (EPI == 6) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    zraw[i] = *reinterpret_cast<const uint2*>(zband + (long)(mb * 32 + rq + 8 * i) * 128 + cq * 8);
+                    zraw[i] = *reinterpret_cast<const uint2*>(a.bn_z + (m0 + mb * 32 + rq + 8 * i) * 128 + nb * 64 + cq * 8);
             }
-            f32x16 acc;
+            f32x16 acc;                                           // (two accumulation chains, even / odd k-steps, measured the same: 71.8 vs 70.4 us)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             // two fragment sets: tap i + 1 is fetched behind the matrix instructions of tap i (the order is pinned: left alone the
@@ -186,6 +201,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int row = rq + 8 * i;
                 const uint2 pk = *reinterpret_cast<const uint2*>(slab + row * kSlabPitch + cq * 8);
+#ifdef MVF_CONV_ABLATE
+                if (!(a.abl & 4))
+#endif
                 *reinterpret_cast<uint2*>(yband + (long)(mb * 32 + row) * 128 + cq * 8) = pk;
                 if constexpr (EPI == 1 || EPI == 6) {             // sums over what is STORED
                     const float4 v = make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
@@ -195,51 +213,49 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
                         s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
                         s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
                     } else {
-                        const float4 zv = make_float4(__uint_as_float(zraw[i].x << 16), __uint_as_float(zraw[i].x & 0xffff0000u),
-                                                      __uint_as_float(zraw[i].y << 16), __uint_as_float(zraw[i].y & 0xffff0000u));
+                        const uint2 zr = zraw[i];
+                        const float4 zv = make_float4(__uint_as_float(zr.x << 16), __uint_as_float(zr.x & 0xffff0000u),
+                                                      __uint_as_float(zr.y << 16), __uint_as_float(zr.y & 0xffff0000u));
                         const float g0 = (zv.x * b_sc.x + b_sh.x) > 0.f ? v.x : 0.f, g1 = (zv.y * b_sc.y + b_sh.y) > 0.f ? v.y : 0.f;
                         const float g2 = (zv.z * b_sc.z + b_sh.z) > 0.f ? v.z : 0.f, g3 = (zv.w * b_sc.w + b_sh.w) > 0.f ? v.w : 0.f;
                         s1.x += g0; s1.y += g1; s1.z += g2; s1.w += g3;
-                        s2.x += g0 * ((zv.x - b_mu.x) * b_rs.x); s2.y += g1 * ((zv.y - b_mu.y) * b_rs.y);
-                        s2.z += g2 * ((zv.z - b_mu.z) * b_rs.z); s2.w += g3 * ((zv.w - b_mu.w) * b_rs.w);
+                        s2.x += g0 * (zv.x - b_mu.x); s2.y += g1 * (zv.y - b_mu.y);
+                        s2.z += g2 * (zv.z - b_mu.z); s2.w += g3 * (zv.w - b_mu.w);
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (EPI == 1 || EPI == 6) {
-            // the band's column sums: over the 8 row lanes of a channel group (fixed butterfly), then the 4 pixel-block groups in order
-#pragma unroll
-            for (int off = 8; off < 64; off <<= 1) {
-                s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64); s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
-                s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64); s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
-            }
-        }
         if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next window has landed (and this wave's stores are out)
-        __syncthreads();
-        if constexpr (EPI == 1 || EPI == 6) {
-            float4* red = reinterpret_cast<float4*>(smem + 2 * G::BUF);     // (the slabs are idle between the two barriers)
-            if (lane < 8) {
-                red[(mg * 16 + nb * 8 + lane) * 2] = s1;
-                red[(mg * 16 + nb * 8 + lane) * 2 + 1] = s2;
-            }
-            s1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            s2 = s1;
-            __syncthreads();
-            if (tid < 64) {                                                  // channel tid = 4 * group + j
-                const float* rf = reinterpret_cast<const float*>(red);
-                const int grp = tid >> 2, j = tid & 3;
-                float t1 = 0.f, t2 = 0.f;
+        lds_barrier();
+    }
+    if constexpr (EPI == 1 || EPI == 6) {
+        // the workgroup's column sums (all its bands): over the 8 row lanes of a channel group (fixed butterfly), then the 4 pixel-block
+        // groups in order; ONE partial row per workgroup, the rows past the grid are zeroed
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    t1 += rf[((q * 16 + grp) * 2) * 4 + j];
-                    t2 += rf[((q * 16 + grp) * 2 + 1) * 4 + j];
-                }
-                float2* dst = reinterpret_cast<float2*>(a.stats_part) + (long)tid * a.stats_rows;
-                dst[t] = make_float2(t1, t2);
-                for (int r = a.bands + t; r < a.stats_rows; r += a.bands) dst[r] = make_float2(0.f, 0.f);
+        for (int off = 8; off < 64; off <<= 1) {
+            s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64); s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
+            s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64); s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
+        }
+        float4* red = reinterpret_cast<float4*>(smem + 2 * G::BUF);         // (the slabs are idle after the last barrier)
+        if (lane < 8) {
+            red[(mg * 16 + nb * 8 + lane) * 2] = s1;
+            red[(mg * 16 + nb * 8 + lane) * 2 + 1] = s2;
+        }
+        lds_barrier();
+        if (tid < 64) {                                                      // channel tid = 4 * group + j
+            const float* rf = reinterpret_cast<const float*>(red);
+            const int grp = tid >> 2, j = tid & 3;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                t1 += rf[((q * 16 + grp) * 2) * 4 + j];
+                t2 += rf[((q * 16 + grp) * 2 + 1) * 4 + j];
             }
-            __syncthreads();
+            if constexpr (EPI == 6) t2 *= a.bn_invstd[tid];
+            float2* dst = reinterpret_cast<float2*>(a.stats_part) + (long)tid * a.stats_rows;
+            dst[blockIdx.x] = make_float2(t1, t2);
+            for (int r = gridDim.x + blockIdx.x; r < a.stats_rows; r += gridDim.x) dst[r] = make_float2(0.f, 0.f);
         }
     }
 }
@@ -287,7 +303,6 @@ int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     if (s.H % kR || s.wK != 576 || s.xps < 64 || s.xps % 8) return -1;
     const long bands = (long)s.N * (s.H / kR);
     if (bands >= (1L << 30) || (long)s.N * s.H * s.W * s.xps * 2 >= (1L << 40)) return -1;
-    if ((s.epi == 1 || s.epi == 6) && bands > s.stats_rows) return -1;          // one partial row per band
     KArgs a = {};
     a.x = (const char*)s.x; a.w = (const char*)s.w; a.y = (char*)s.y; a.bias = s.bias;
     a.stats_part = s.stats_part; a.stats_shift = s.stats_shift; a.stats_rows = s.stats_rows;
@@ -296,6 +311,9 @@ int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     a.bands_per_frame = s.H / kR;
     a.bands = (int)bands;
     fd_make_local((unsigned)a.bands_per_frame, a.fd_bpf_mul, a.fd_bpf_shr);
+#ifdef MVF_CONV_ABLATE
+    a.abl = getenv("MVF_CONV3X3_ABL") ? atoi(getenv("MVF_CONV3X3_ABL")) : 0;
+#endif
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -307,6 +325,7 @@ int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     a.bands_per_wg = bw ? atoi(bw) : (int)((bands + cus - 1) / cus);            // one workgroup per CU, contiguous bands
     if (a.bands_per_wg < 1) a.bands_per_wg = 1;
     const int grid = (int)((bands + a.bands_per_wg - 1) / a.bands_per_wg);
+    if ((s.epi == 1 || s.epi == 6) && grid > s.stats_rows) return -1;           // one partial row per workgroup
     if (s.W == 56) return launch_epi<56>(s.epi, a, grid, st);
     return launch_epi<8>(s.epi, a, grid, st);
 }
