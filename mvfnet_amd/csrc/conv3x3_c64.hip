@@ -5,7 +5,7 @@
 // Why: with N = 64 output channels the implicit-GEMM kernel (conv_nhwc.hip) moves 9 x the input through L2 -> LDS (one 128 B row per tap and
 // output pixel: 925 MB per launch at the C3 shape, 8.2 TB/s = the chip's L2 -> LDS ceiling) for 103 MB of input: 113 / 131 us (forward /
 // data gradient + BatchNorm sums) against 37 us for its HBM bytes and 24 us for its matrix work (profiles/r03_per_layer_bf16_train.txt).  Here
-//   * a workgroup (8 waves, one per CU) walks the row bands of its frames: R = 4 output rows = 224 pixels per band, whose (R + 2) x (W + 2)
+//   * a workgroup (8 waves, one per CU) walks the row bands of its frames: R = 4 output rows = 224 pixels per band, whose (R + 2) x (W + 16)
 //     ZERO-PADDED input window is staged once by LDS-DMA (out-of-range offsets DMA zeros: no tap masks anywhere), double-buffered: band t + 1
 //     lands while band t is computed;
 //   * the window is UNIT-MAJOR in LDS ([8 units of 16 B = 8 channels][slot][16 B]): the operand fragment of 32 consecutive pixels is 32
@@ -20,6 +20,11 @@
 //     Partial rows: ONE per workgroup (its bands' sums), written at row = workgroup index; the rows past the grid are zeroed (the finalize
 //     sums all rows).
 // Arithmetic = the implicit-GEMM kernel's: the same bf16 products accumulated in fp32 in the same k order (tap-major), rounded once.
+// Measured (C3 shape, 256 frames of 56 x 56, in the training step): forward + statistics 109 -> 69 us (852 TF/s), data gradient + BatchNorm
+// sums 120 -> 82 us; s_memtime trace of one workgroup (-DMVF_CONV_ABLATE, MVF_CONV3X3_TRACE): a band takes ~6900 ticks for 4608 of matrix
+// work per SIMD; what is left is the 28 DMA instructions per loader wave and band (2500-4000 ticks of issue) and epilogues that the second
+// wave of a SIMD only partly covers.  Measured without effect: two accumulation chains, staggering waves 4-7, wave priorities, z fetched a
+// block ahead (profiles/r03_conv3x3_c64_experiments.txt).
 #include "common.h"
 
 namespace {
@@ -47,6 +52,7 @@ struct KArgs {
     int bands_per_frame, bands, bands_per_wg;
     unsigned fd_bpf_mul, fd_bpf_shr;
     long wK;
+    unsigned long long* trace;         // -DMVF_CONV_ABLATE + MVF_CONV3X3_TRACE=1: s_memtime stamps of workgroup 0, [wave][band][8]
     int abl;                           // -DMVF_CONV_ABLATE builds: bit 0 no window staging after the first band, bit 1 no pixel blocks, bit 2 no output stores
 };
 
@@ -136,6 +142,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         const int grp = (mg + t - t_begin) & 3;
+#ifdef MVF_CONV_ABLATE
+        int stamp_i = 0;
+        auto stamp = [&]() { if (a.trace && blockIdx.x == 0 && lane == 0 && t - t_begin < 14 && stamp_i < 8) a.trace[(wave * 14 + (t - t_begin)) * 8 + stamp_i++] = __builtin_readcyclecounter(); };
+        stamp();
+#endif
         const bool loader = grp == 3;
 #ifdef MVF_CONV_ABLATE
         if (!(a.abl & 1))
@@ -183,6 +194,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef MVF_CONV_ABLATE
+            stamp();
+#endif
             // ---- transpose through the wave's slab: rows = pixels, 64 B = this wave's 32 channels ----
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -225,9 +239,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();
+#ifdef MVF_CONV_ABLATE
+            stamp();
+#endif
         }
-        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next window has landed (and this wave's stores are out)
+        // the next window has landed: everything this wave issued BEFORE its own block's output stores (vmcnt retires in issue order; the
+        // stores of the loader's block(s) are its youngest operations and stay in flight -- draining them too cost 1-2 us per band)
+        constexpr int kYoungStores = 4 * ((G::NB > 3) ? (G::NB - 3 + 3) / 4 : 0);
+        if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYoungStores) : "memory");
+#ifdef MVF_CONV_ABLATE
+        stamp_i = 5; stamp();
+#endif
         lds_barrier();
+#ifdef MVF_CONV_ABLATE
+        stamp();
+#endif
     }
     if constexpr (EPI == 1 || EPI == 6) {
         // the workgroup's column sums (all its bands): over the 8 row lanes of a channel group (fixed butterfly), then the 4 pixel-block
@@ -313,6 +339,10 @@ int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     fd_make_local((unsigned)a.bands_per_frame, a.fd_bpf_mul, a.fd_bpf_shr);
 #ifdef MVF_CONV_ABLATE
     a.abl = getenv("MVF_CONV3X3_ABL") ? atoi(getenv("MVF_CONV3X3_ABL")) : 0;
+    static unsigned long long* trace_buf = nullptr;
+    const bool tracing = getenv("MVF_CONV3X3_TRACE") && atoi(getenv("MVF_CONV3X3_TRACE")) == s.epi;
+    if (tracing && !trace_buf) MVF_HIP_OK(hipMalloc(&trace_buf, 8 * 14 * 8 * 8));
+    if (tracing) { MVF_HIP_OK(hipMemsetAsync(trace_buf, 0, 8 * 14 * 8 * 8, st)); a.trace = trace_buf; }
 #endif
     static int cus = 0;
     if (!cus) {
@@ -326,8 +356,25 @@ int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     if (a.bands_per_wg < 1) a.bands_per_wg = 1;
     const int grid = (int)((bands + a.bands_per_wg - 1) / a.bands_per_wg);
     if ((s.epi == 1 || s.epi == 6) && grid > s.stats_rows) return -1;           // one partial row per workgroup
-    if (s.W == 56) return launch_epi<56>(s.epi, a, grid, st);
-    return launch_epi<8>(s.epi, a, grid, st);
+    const int rc = s.W == 56 ? launch_epi<56>(s.epi, a, grid, st) : launch_epi<8>(s.epi, a, grid, st);
+#ifdef MVF_CONV_ABLATE
+    if (a.trace) {
+        static int dumped = 0;
+        if (dumped++ == 5) {            // a warm launch
+            static unsigned long long h[8 * 14 * 8];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
+            const unsigned long long t0 = h[0];
+            for (int w = 0; w < 8; ++w)
+                for (int b = 0; b < 14; ++b) {
+                    fprintf(stderr, "trace wave %d band %2d:", w, b);
+                    for (int i = 0; i < 8; ++i) fprintf(stderr, " %7lld", h[(w * 14 + b) * 8 + i] ? (long long)(h[(w * 14 + b) * 8 + i] - t0) : -1LL);
+                    fprintf(stderr, "\n");
+                }
+        }
+    }
+#endif
+    return rc;
 }
 
 }  // namespace mvf_internal
