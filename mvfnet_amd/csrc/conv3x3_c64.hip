@@ -32,7 +32,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kR = 4;                        // output rows per band
 constexpr int kSlabPitch = 72;               // bf16 C slab: 32 channels = 64 B per pixel + 2 dwords
 constexpr int kSlabBytes = 32 * kSlabPitch;
 
@@ -56,7 +55,7 @@ struct KArgs {
     int abl;                           // -DMVF_CONV_ABLATE builds: bit 0 no window staging after the first band, bit 1 no pixel blocks, bit 2 no output stores
 };
 
-template <int W>
+template <int W, int kR>             // image width, output rows per band
 struct Geo {
     static constexpr int WP = W + 16;                             // padded row: image column c sits at slot c + 1; 16 more than W, so a 32-pixel block that
                                                                   // crosses an image row keeps every ds_read_b128 service group on 16 distinct 16-byte slots
@@ -68,9 +67,9 @@ struct Geo {
     static constexpr int LDS = 2 * BUF + 8 * kSlabBytes;
 };
 
-template <int EPI, int W>
+template <int EPI, int W, int kR>
 __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(KArgs a) {
-    using G = Geo<W>;
+    using G = Geo<W, kR>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -293,26 +292,27 @@ inline void fd_make_local(unsigned d, unsigned& mul, unsigned& shr) {
     shr = l;
 }
 
-template <int EPI, int W>
+template <int EPI, int W, int R>
 int launch_w(const KArgs& a, int grid, hipStream_t st) {
-    auto k = conv3x3_c64_kernel<EPI, W>;
+    auto k = conv3x3_c64_kernel<EPI, W, R>;
+    constexpr int lds = Geo<W, R>::LDS;
     static bool attr = false;
     if (!attr) {
-        MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<W>::LDS));
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), Geo<W>::LDS, st, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
 
-template <int W>
+template <int W, int R>
 int launch_epi(int epi, const KArgs& a, int grid, hipStream_t st) {
     switch (epi) {
-        case 1: return launch_w<1, W>(a, grid, st);
-        case 2: return launch_w<2, W>(a, grid, st);
-        case 4: return launch_w<4, W>(a, grid, st);
-        case 6: return launch_w<6, W>(a, grid, st);
+        case 1: return launch_w<1, W, R>(a, grid, st);
+        case 2: return launch_w<2, W, R>(a, grid, st);
+        case 4: return launch_w<4, W, R>(a, grid, st);
+        case 6: return launch_w<6, W, R>(a, grid, st);
     }
     return -1;
 }
@@ -325,8 +325,10 @@ namespace mvf_internal {
 int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     const char* sw = getenv("MVF_CONV3X3_DIRECT");        // A/B switch, read per call: 0 = the implicit-GEMM kernel
     if (sw && atoi(sw) == 0) return -1;
-    if (s.W != 56 && s.W != 8) return -1;                 // instantiated widths: layer1 at 224 x 224 input (and a small one the tests reach)
-    if (s.H % kR || s.wK != 576 || s.xps < 64 || s.xps % 8) return -1;
+    // instantiated (width, rows per band): layer1 at 224 / 64 / 32-pixel inputs (the last two are what the small test networks reach; a
+    // 28 x 28 map has no band of whole 32-pixel blocks that divides its height and stays on the implicit-GEMM kernel)
+    const int kR = s.W == 56 ? 4 : s.W == 16 ? 8 : s.W == 8 ? 4 : 0;
+    if (!kR || s.H % kR || s.wK != 576 || s.xps < 64 || s.xps % 8) return -1;
     const long bands = (long)s.N * (s.H / kR);
     if (bands >= (1L << 30) || (long)s.N * s.H * s.W * s.xps * 2 >= (1L << 40)) return -1;
     KArgs a = {};
@@ -356,7 +358,7 @@ int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     if (a.bands_per_wg < 1) a.bands_per_wg = 1;
     const int grid = (int)((bands + a.bands_per_wg - 1) / a.bands_per_wg);
     if ((s.epi == 1 || s.epi == 6) && grid > s.stats_rows) return -1;           // one partial row per workgroup
-    const int rc = s.W == 56 ? launch_epi<56>(s.epi, a, grid, st) : launch_epi<8>(s.epi, a, grid, st);
+    const int rc = s.W == 56 ? launch_epi<56, 4>(s.epi, a, grid, st) : s.W == 16 ? launch_epi<16, 8>(s.epi, a, grid, st) : launch_epi<8, 4>(s.epi, a, grid, st);
 #ifdef MVF_CONV_ABLATE
     if (a.trace) {
         static int dumped = 0;

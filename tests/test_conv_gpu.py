@@ -142,7 +142,7 @@ def test_stem_maxpool_head_ops_vs_oracle():
         assert rel_err(avg.cpu().numpy(), fn(ref).numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(3, 56, 56, 64), (5, 56, 56, 128), (4, 8, 8, 64)], ids=lambda s: "n%d_%dx%d_pitch%d" % s)
+@pytest.mark.parametrize("shape", [(3, 56, 56, 64), (5, 56, 56, 128), (3, 16, 16, 64), (4, 8, 8, 64)], ids=lambda s: "n%d_%dx%d_pitch%d" % s)
 def test_conv3x3_c64_direct_vs_oracle_and_the_implicit_gemm(shape):
     """[r3] layer1's 3x3 (resnet.py:213-224 conv2 at planes = 64) and its data gradient run on a direct kernel (csrc/conv3x3_c64.hip: padded
     window staged once per row band, the wave's weights in registers); MVF_CONV3X3_DIRECT=0 sends the same calls to the implicit-GEMM kernel.
@@ -307,9 +307,9 @@ def test_conv_streamk_tail_matches_plain_launch_and_oracle(case, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", ["MVF_CONV_GLDS=0", "MVF_CONV_GLDS=1,1", "MVF_CONV_GLDS=1,2", "MVF_CONV_BIG=1", "MVF_CONV_BIG2=1,MVF_CONV_BIG2_FORCE=1",
-                                 "MVF_CONV_BIG2=1,MVF_CONV_BIG2_FORCE=1,MVF_CONV_P4=0"],
+                                 "MVF_CONV_BIG2=1,MVF_CONV_BIG2_FORCE=1,MVF_CONV_P4=0", "MVF_STEM_DIRECT=0,MVF_CONV3X3_DIRECT=0"],
                          ids=["register_staged_only", "lds_dma_1buf_everywhere", "lds_dma_2buf_everywhere", "tile_256x128_everywhere",
-                              "tile_256x256_four_phase_everywhere", "tile_256x256_two_barrier_everywhere"])
+                              "tile_256x256_four_phase_everywhere", "tile_256x256_two_barrier_everywhere", "no_direct_stem_or_layer1_3x3"])
 def test_conv_kernel_variants_forced_by_env(env):
     """The loader variant is a per-process policy (environment, read once), so each forced policy re-runs this file's oracle
     comparisons in a child process: register staging only, the LDS-DMA loop with one and two buffers for EVERY launch (the
