@@ -147,6 +147,113 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply(NhwcArgs a) {
     }
 }
 
+// The same stencil with the serial walk over t removed: a thread still owns (pixel, VEC channels) for every frame of its clip, but
+// loads a chunk of TB frames -- centre t0-1 .. t0+TB and the four in-plane neighbours of t0 .. t0+TB-1 (+ the addend and its gate byte) --
+// with ALL loads issued before the first use: one memory round trip per chunk instead of one per frame (the walk's (prev, cur, next)
+// window makes every frame wait for its own loads: 8 dependent round trips at T = 8 were most of the launch's 22 us for 25 MB).
+// The tap weights of the thread's VEC = 4 channels are 12 consecutive floats per view: three 16-byte loads instead of twelve scalars.
+template <typename ET, int TB>
+__global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
+    constexpr int VEC = 4;
+    const int HW = a.h * a.w, W = a.w, H = a.h, T = a.T, C = a.c;
+    const int n = blockIdx.x / a.bands, band = blockIdx.x % a.bands;
+    const int cgi = blockIdx.y * a.cgp + (threadIdx.x % a.cgp);
+    const int plane = threadIdx.x / a.cgp, nplanes = kThreads / a.cgp;
+    if (cgi >= a.cg) return;
+    const int c0 = cgi * VEC;
+    const bool vh = a.mode & MVF_VIEW_H, vw = a.mode & MVF_VIEW_W;
+    const bool hs = a.scale != nullptr;
+    float wt[VEC][3], wh[VEC][3], ww[VEC][3], sc[VEC], sh[VEC];
+    {
+        auto load12 = [&](const float* p, bool on, float (&dst)[VEC][3]) {
+            float f[12];
+            if (on) {
+                const float4 q0 = *reinterpret_cast<const float4*>(p + c0 * 3), q1 = *reinterpret_cast<const float4*>(p + c0 * 3 + 4),
+                             q2 = *reinterpret_cast<const float4*>(p + c0 * 3 + 8);
+                f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w; f[4] = q1.x; f[5] = q1.y; f[6] = q1.z; f[7] = q1.w;
+                f[8] = q2.x; f[9] = q2.y; f[10] = q2.z; f[11] = q2.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) f[k] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                dst[i][0] = a.flip ? f[i * 3 + 2] : f[i * 3];
+                dst[i][1] = f[i * 3 + 1];
+                dst[i][2] = a.flip ? f[i * 3] : f[i * 3 + 2];
+            }
+        };
+        load12(a.wt, true, wt);
+        load12(a.wh, vh, wh);
+        load12(a.ww, vw, ww);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sc[i] = hs ? a.scale[c0 + i] : 1.f;
+            sh[i] = hs ? a.shift[c0 + i] : 0.f;
+        }
+    }
+    const ET* x = reinterpret_cast<const ET*>(a.x);
+    ET* out = reinterpret_cast<ET*>(a.out);
+    const long fstride = (long)HW * C;                         // one frame
+    const int pend = min(HW, (band + 1) * a.pixw);
+    for (int pix = band * a.pixw + plane; pix < pend; pix += nplanes) {
+        const int hh = pix / W, wv = pix - hh * W;
+        const long e0 = ((long)n * T * HW + pix) * C + c0;     // (n, t=0, pix, c0)
+        const long o0 = ((long)n * T * HW + pix) * a.out_c + c0;
+        // neighbour validity is per thread, constant over t: out-of-range neighbours re-read the centre pixel and are zeroed afterwards
+        const bool ok_up = vh && hh > 0, ok_dn = vh && hh < H - 1, ok_lf = vw && wv > 0, ok_rt = vw && wv < W - 1;
+        const long d_up = ok_up ? -(long)W * C : 0, d_dn = ok_dn ? (long)W * C : 0, d_lf = ok_lf ? -(long)C : 0, d_rt = ok_rt ? (long)C : 0;
+        for (int t0 = 0; t0 < T; t0 += TB) {
+            float cen[TB + 2][VEC], up[TB][VEC], dn[TB][VEC], lf[TB][VEC], rt[TB][VEC], ad[TB][VEC];
+            unsigned mb[TB];
+#pragma unroll
+            for (int k = 0; k < TB + 2; ++k) {                 // frames t0 - 1 .. t0 + TB (clamped into the clip; zeroed below where outside)
+                int t = t0 - 1 + k;
+                t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+                Vec<ET, VEC>::load(x + e0 + (long)t * fstride, cen[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < TB; ++k) {
+                const int t = min(t0 + k, T - 1);
+                const ET* f = x + e0 + (long)t * fstride;
+                Vec<ET, VEC>::load(f + d_up, up[k]);
+                Vec<ET, VEC>::load(f + d_dn, dn[k]);
+                Vec<ET, VEC>::load(f + d_lf, lf[k]);
+                Vec<ET, VEC>::load(f + d_rt, rt[k]);
+                mb[k] = 0xfu;
+                if (a.add) {
+                    const long apix = ((long)n * T + t) * HW + pix;
+                    Vec<ET, VEC>::load(reinterpret_cast<const ET*>(a.add) + apix * a.add_c + c0, ad[k]);
+                    if (a.add_mask) mb[k] = a.add_mask[apix * (a.add_c / 4) + c0 / 4] >> (c0 & 3);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TB; ++k) {
+                const int t = t0 + k;
+                if (t >= T) break;
+                float y[VEC];
+                const bool ok_pv = t > 0, ok_nx = t + 1 < T;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float pv = ok_pv ? cen[k][i] : 0.f, cu = cen[k + 1][i], nx = ok_nx ? cen[k + 2][i] : 0.f;
+                    const float u_ = ok_up ? up[k][i] : 0.f, d_ = ok_dn ? dn[k][i] : 0.f, l_ = ok_lf ? lf[k][i] : 0.f, r_ = ok_rt ? rt[k][i] : 0.f;
+                    float yt = wt[i][0] * pv + wt[i][1] * cu + wt[i][2] * nx;
+                    float yh = wh[i][0] * u_ + wh[i][1] * cu + wh[i][2] * d_;
+                    float yw = ww[i][0] * l_ + ww[i][1] * cu + ww[i][2] * r_;
+                    float v = (yt + yh) + yw;
+                    if (hs) {
+                        float u = sc[i] * v + sh[i];
+                        v = u * (fminf(fmaxf(u + 3.0f, 0.0f), 6.0f) / 6.0f);
+                    }
+                    if (a.add) v += ((mb[k] >> i) & 1u) ? ad[k][i] : 0.f;
+                    y[i] = v;
+                }
+                Vec<ET, VEC>::store(out + o0 + (long)t * HW * a.out_c, y);
+            }
+        }
+    }
+}
+
 // copy channels [cs, c) of every pixel (out != x case)
 template <typename ET>
 __global__ void copy_tail_nhwc(const ET* src, ET* dst, long npix, int c, int cs) {
@@ -201,11 +308,16 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     static const int tsplit_env = getenv("MVF_STENCIL_TSPLIT") ? atoi(getenv("MVF_STENCIL_TSPLIT")) : 0;
     a.tsplit = tsplit_env != 0 && a.T > 1;
     dim3 grid(a.n_clips * a.bands, (a.cg + cgp - 1) / cgp, a.tsplit ? a.T : 1);
+    // [r3] all of a chunk's loads in flight at once instead of the serial walk over t (MVF_STENCIL_CHUNKED=0: the walk)
+    static const int chunked_env = getenv("MVF_STENCIL_CHUNKED") ? atoi(getenv("MVF_STENCIL_CHUNKED")) : 1;
+    const bool chunked = chunked_env != 0 && vec && !a.tsplit && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0;
     if (d->dtype == MVF_F32) {
-        if (vec) hipLaunchKernelGGL((mvf_nhwc_apply<float, 4>), grid, dim3(kThreads), 0, st, a);
+        if (chunked) hipLaunchKernelGGL((mvf_nhwc_apply_chunked<float, 4>), grid, dim3(kThreads), 0, st, a);
+        else if (vec) hipLaunchKernelGGL((mvf_nhwc_apply<float, 4>), grid, dim3(kThreads), 0, st, a);
         else hipLaunchKernelGGL((mvf_nhwc_apply<float, 1>), grid, dim3(kThreads), 0, st, a);
     } else {
-        if (vec) hipLaunchKernelGGL((mvf_nhwc_apply<bf16_t, 4>), grid, dim3(kThreads), 0, st, a);
+        if (chunked) hipLaunchKernelGGL((mvf_nhwc_apply_chunked<bf16_t, 8>), grid, dim3(kThreads), 0, st, a);
+        else if (vec) hipLaunchKernelGGL((mvf_nhwc_apply<bf16_t, 4>), grid, dim3(kThreads), 0, st, a);
         else hipLaunchKernelGGL((mvf_nhwc_apply<bf16_t, 1>), grid, dim3(kThreads), 0, st, a);
     }
     MVF_LAUNCH_CHECK();
