@@ -306,13 +306,15 @@ int launch_w(const KArgs& a, int grid, hipStream_t st) {
     return MVF_OK;
 }
 
-template <int W, int R>
+template <int W, int R, bool TRAIN = true>
 int launch_epi(int epi, const KArgs& a, int grid, hipStream_t st) {
     switch (epi) {
-        case 1: return launch_w<1, W, R>(a, grid, st);
         case 2: return launch_w<2, W, R>(a, grid, st);
         case 4: return launch_w<4, W, R>(a, grid, st);
-        case 6: return launch_w<6, W, R>(a, grid, st);
+    }
+    if constexpr (TRAIN) {
+        if (epi == 1) return launch_w<1, W, R>(a, grid, st);
+        if (epi == 6) return launch_w<6, W, R>(a, grid, st);
     }
     return -1;
 }
@@ -325,9 +327,10 @@ namespace mvf_internal {
 int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     const char* sw = getenv("MVF_CONV3X3_DIRECT");        // A/B switch, read per call: 0 = the implicit-GEMM kernel
     if (sw && atoi(sw) == 0) return -1;
-    // instantiated (width, rows per band): layer1 at 224 / 64 / 32-pixel inputs (the last two are what the small test networks reach; a
-    // 28 x 28 map has no band of whole 32-pixel blocks that divides its height and stays on the implicit-GEMM kernel)
-    const int kR = s.W == 56 ? 4 : s.W == 16 ? 8 : s.W == 8 ? 4 : 0;
+    // instantiated (width, rows per band): layer1 at 224 / 256 (the 30-clip video test, BASELINE configs[4]) / 64 / 32-pixel inputs (the last
+    // two are what the small test networks reach; a 28 x 28 map has no band of whole 32-pixel blocks that divides its height and stays on
+    // the implicit-GEMM kernel)
+    const int kR = s.W == 56 ? 4 : s.W == 64 ? 4 : s.W == 16 ? 8 : s.W == 8 ? 4 : 0;
     if (!kR || s.H % kR || s.wK != 576 || s.xps < 64 || s.xps % 8) return -1;
     const long bands = (long)s.N * (s.H / kR);
     if (bands >= (1L << 30) || (long)s.N * s.H * s.W * s.xps * 2 >= (1L << 40)) return -1;
@@ -358,7 +361,8 @@ int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     if (a.bands_per_wg < 1) a.bands_per_wg = 1;
     const int grid = (int)((bands + a.bands_per_wg - 1) / a.bands_per_wg);
     if ((s.epi == 1 || s.epi == 6) && grid > s.stats_rows) return -1;           // one partial row per workgroup
-    const int rc = s.W == 56 ? launch_epi<56, 4>(s.epi, a, grid, st) : s.W == 16 ? launch_epi<16, 8>(s.epi, a, grid, st) : launch_epi<8, 4>(s.epi, a, grid, st);
+    const int rc = s.W == 56 ? launch_epi<56, 4>(s.epi, a, grid, st) : s.W == 64 ? launch_epi<64, 4, false>(s.epi, a, grid, st)      // (inference only: the sum epilogues spill at this window size)
+                   : s.W == 16 ? launch_epi<16, 8>(s.epi, a, grid, st) : launch_epi<8, 4>(s.epi, a, grid, st);
 #ifdef MVF_CONV_ABLATE
     if (a.trace) {
         static int dumped = 0;

@@ -142,7 +142,7 @@ def test_stem_maxpool_head_ops_vs_oracle():
         assert rel_err(avg.cpu().numpy(), fn(ref).numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(3, 56, 56, 64), (5, 56, 56, 128), (3, 16, 16, 64), (4, 8, 8, 64)], ids=lambda s: "n%d_%dx%d_pitch%d" % s)
+@pytest.mark.parametrize("shape", [(3, 56, 56, 64), (5, 56, 56, 128), (2, 64, 64, 64), (3, 16, 16, 64), (4, 8, 8, 64)], ids=lambda s: "n%d_%dx%d_pitch%d" % s)
 def test_conv3x3_c64_direct_vs_oracle_and_the_implicit_gemm(shape):
     """[r3] layer1's 3x3 (resnet.py:213-224 conv2 at planes = 64) and its data gradient run on a direct kernel (csrc/conv3x3_c64.hip: padded
     window staged once per row band, the wave's weights in registers); MVF_CONV3X3_DIRECT=0 sends the same calls to the implicit-GEMM kernel.
