@@ -692,6 +692,74 @@ __global__ void maxpool_bn_fwd_kernel(const ET* z, int n, int h, int w, int c, i
     }
 }
 
+// [r3] BLOCK form of the forward (even h and w): a thread owns a 2 x 2 block of POOLED outputs x 16 bytes of channels; their four 3 x 3
+// windows share a 5 x 5 patch of z, loaded once as 25 16-byte accesses for 32 outputs where the element form issues nine 8-byte loads per
+// 4.  Each output scans its window in the same order with the same strict compare: identical y and argmax.
+template <typename ET>
+__global__ __launch_bounds__(256) void maxpool_bn_fwd_blk_kernel(const ET* z, int n, int h, int w, int c, int ho, int wo, const float* scale,
+                                                                 const float* shift, ET* y, unsigned char* amax) {
+    constexpr int VC = 16 / (int)sizeof(ET);
+    const int ncg = c / VC, bwn = wo >> 1, bhn = ho >> 1;
+    const long total = (long)n * bhn * bwn * ncg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % ncg);
+        long t = i / ncg;
+        const int bw = (int)(t % bwn); t /= bwn;
+        const int bh = (int)(t % bhn);
+        const int img = (int)(t / bhn);
+        float sc[VC], sh[VC];
+#pragma unroll
+        for (int j = 0; j < VC; ++j) { sc[j] = scale[cq * VC + j]; sh[j] = shift[cq * VC + j]; }
+        // patch rows 4 bh - 1 .. 4 bh + 3, columns 4 bw - 1 .. 4 bw + 3 (clamped loads; out-of-image taps are skipped in the compare)
+        float a[5][5][VC];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int ih = 4 * bh - 1 + r, iw = 4 * bw - 1 + q;
+                const int ihc = min(max(ih, 0), h - 1), iwc = min(max(iw, 0), w - 1);
+                const uint4 u = *reinterpret_cast<const uint4*>(z + (((long)img * h + ihc) * w + iwc) * c + cq * VC);
+                float f[VC];
+                if constexpr (sizeof(ET) == 4) {
+                    f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+                } else {
+                    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u); f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+                    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u); f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+                }
+#pragma unroll
+                for (int j = 0; j < VC; ++j) a[r][q][j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+            }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                     // pooled output (2 bh + (p >> 1), 2 bw + (p & 1))
+            const int oh = 2 * bh + (p >> 1), ow = 2 * bw + (p & 1);
+            float m[VC];
+            unsigned am[VC];
+#pragma unroll
+            for (int j = 0; j < VC; ++j) { m[j] = -INFINITY; am[j] = 0; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int r = 2 * (p >> 1) + k / 3, q = 2 * (p & 1) + k % 3;
+                const int ih = oh * 2 - 1 + k / 3, iw = ow * 2 - 1 + k % 3;
+                const bool in = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
+#pragma unroll
+                for (int j = 0; j < VC; ++j)
+                    if (in && a[r][q][j] > m[j]) { m[j] = a[r][q][j]; am[j] = k; }
+            }
+            const long oidx = (((long)img * ho + oh) * wo + ow) * c + cq * VC;
+            uint4 u;
+            if constexpr (sizeof(ET) == 4) u = make_uint4(__float_as_uint(m[0]), __float_as_uint(m[1]), __float_as_uint(m[2]), __float_as_uint(m[3]));
+            else u = make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7]));
+            *reinterpret_cast<uint4*>(y + oidx) = u;
+            if (amax) {
+                if constexpr (VC == 8)
+                    *reinterpret_cast<uint2*>(amax + oidx) = make_uint2(am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24), am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24));
+                else
+                    *reinterpret_cast<unsigned*>(amax + oidx) = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+            }
+        }
+    }
+}
+
 // ga[input pixel] = sum over the (<=4) windows containing it of g[window] * [this pixel is the window's arg-max].
 // Gather form (no atomics); the forward stored one byte per pooled element (window position of the first max), so the
 // backward reads 4 bytes + one 4-channel gradient per covering window instead of re-evaluating 9 activations.
@@ -881,6 +949,143 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_rows_apply_kernel(const un
                 o[j] = av[j] * (gm - d0[j] - (zz[j] - muv[j]) * kx[j]);
             }
             st4(dz + zi, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
+// [r3] BLOCK form of the two kernels above (even h and w): a thread owns a 2 x 2 block of input pixels x 16 bytes of channels.  The four
+// pool windows that cover the block -- (bh, bh + 1) x (bw, bw + 1) -- are the SAME for its four pixels, so their argmax bytes and gradients
+// are loaded once per block instead of once per pixel, as 16-byte (g, z) / 8-byte (argmax) accesses instead of 8 / 4: 12 loads per 32 outputs
+// where the row form issues 9 per 4 (it ran at 3.3 TB/s of HBM bytes with 7 x that in L1 / L2 traffic).  Per pixel the windows are visited in
+// the row form's order (row offset major) with its conditions, the gather is rounded to the storage type before the gate: identical dz / ga;
+// the sums differ from the row form's in summation order only (another thread -> pixel map).  MODE 0: sums (+ optional ga), MODE 1: apply.
+template <typename ET, int MODE>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_blk_kernel(const unsigned char* amax, const ET* g, int n, int h, int w, int c, int ho, int wo, ET* ga,
+                                                                 const ET* z, const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                                                 const float* shift, const float* dgamma, const float* dbeta, float inv_m, float* part, int nblk,
+                                                                 ET* dz) {
+    constexpr int VC = 16 / (int)sizeof(ET);           // channels per thread
+    __shared__ float red[MODE == 0 ? 256 * 2 * VC : 1];
+    const int ncg = c / VC, hw2 = w >> 1, hb = h >> 1;
+    const int cq = threadIdx.x % ncg;                  // fixed per thread: 256 % ncg == 0 (host-checked)
+    float scv[VC], shv[VC], muv[VC], k1[VC], k2[VC], k3[VC];      // MODE 0: k1 = invstd; MODE 1: k1 = gamma * invstd, k2 = dbeta / M, k3 = invstd * dgamma / M
+#pragma unroll
+    for (int j = 0; j < VC; ++j) {
+        const int ch = cq * VC + j;
+        scv[j] = scale[ch]; shv[j] = shift[ch]; muv[j] = mean[ch];
+        if constexpr (MODE == 0) { k1[j] = invstd[ch]; k2[j] = 0.f; k3[j] = 0.f; }
+        else { k1[j] = gamma[ch] * invstd[ch]; k2[j] = dbeta[ch] * inv_m; k3[j] = invstd[ch] * dgamma[ch] * inv_m; }
+    }
+    float s1[VC], s2[VC];
+#pragma unroll
+    for (int j = 0; j < VC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    auto ldv = [](const ET* p, float (&f)[VC]) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        if constexpr (sizeof(ET) == 4) {
+            f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+        } else {
+            f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u); f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+            f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u); f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+        }
+    };
+    auto stv = [](ET* p, const float (&f)[VC]) {
+        uint4 u;
+        if constexpr (sizeof(ET) == 4) {
+            u = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+        } else {
+            u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+        }
+        *reinterpret_cast<uint4*>(p) = u;
+    };
+    const int items = (kPoolRB / 2) * hw2 * ncg;         // 4 block rows per workgroup
+    const long brows = (long)n * hb;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int bi = i / ncg;                           // (block row, block column) of the item; i % ncg == cq
+        const int br = bi / hw2, bw = bi - br * hw2;
+        const long R = (long)blockIdx.x * (kPoolRB / 2) + br;
+        if (R >= brows) break;
+        const int img = (int)(R / hb), bh = (int)(R - (long)img * hb);
+        float gv[4][VC], zv[4][VC];
+        unsigned char am[4][VC];
+        bool okw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                     // window k = (bh + (k >> 1), bw + (k & 1))
+            const int oh = bh + (k >> 1), ow = bw + (k & 1);
+            okw[k] = oh < ho && ow < wo;
+            const long oidx = (((long)img * ho + min(oh, ho - 1)) * wo + min(ow, wo - 1)) * c + cq * VC;
+            if constexpr (VC == 8) {
+                const uint2 a8 = *reinterpret_cast<const uint2*>(amax + oidx);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { am[k][j] = (unsigned char)(a8.x >> (8 * j)); am[k][4 + j] = (unsigned char)(a8.y >> (8 * j)); }
+            } else {
+                const unsigned a4 = *reinterpret_cast<const unsigned*>(amax + oidx);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) am[k][j] = (unsigned char)(a4 >> (8 * j));
+            }
+            ldv(g + oidx, gv[k]);
+        }
+        long zi[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                     // pixel p = (2 bh + (p >> 1), 2 bw + (p & 1))
+            zi[p] = (((long)img * h + 2 * bh + (p >> 1)) * w + 2 * bw + (p & 1)) * c + cq * VC;
+            ldv(z + zi[p], zv[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int a = p >> 1, b = p & 1;
+            float acc[VC];
+#pragma unroll
+            for (int j = 0; j < VC; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int wi = k >> 1, wj = k & 1;
+                if ((wi == 1 && a == 0) || (wj == 1 && b == 0)) continue;      // an even row / column lies in one window only
+                const unsigned me = (unsigned)(a + 1 - 2 * wi) * 3u + (unsigned)(b + 1 - 2 * wj);
+#pragma unroll
+                for (int j = 0; j < VC; ++j)
+                    if (okw[k] && am[k][j] == me) acc[j] += gv[k][j];
+            }
+            if constexpr (MODE == 0) {
+                if (ga) stv(ga + zi[p], acc);
+            }
+            if constexpr (sizeof(ET) == 2) {             // what the apply pass reads back / re-gathers: rounded to storage
+#pragma unroll
+                for (int j = 0; j < VC; ++j) acc[j] = bf16_to_f32(f32_to_bf16(acc[j]));
+            }
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < VC; ++j) {
+                    const float gm = (zv[p][j] * scv[j] + shv[j]) > 0.f ? acc[j] : 0.f;
+                    s1[j] += gm;
+                    s2[j] += gm * ((zv[p][j] - muv[j]) * k1[j]);
+                }
+            } else {
+                float o[VC];
+#pragma unroll
+                for (int j = 0; j < VC; ++j) {
+                    const float gm = (zv[p][j] * scv[j] + shv[j]) > 0.f ? acc[j] : 0.f;
+                    o[j] = k1[j] * (gm - k2[j] - (zv[p][j] - muv[j]) * k3[j]);
+                }
+                stv(dz + zi[p], o);
+            }
+        }
+    }
+    if constexpr (MODE == 0) {
+        // threads t, t + ncg, t + 2 ncg, ... share the channel group: fixed-order sum through LDS, one channel-major partial row per workgroup
+#pragma unroll
+        for (int j = 0; j < VC; ++j) {
+            red[(2 * j) * 256 + threadIdx.x] = s1[j];
+            red[(2 * j + 1) * 256 + threadIdx.x] = s2[j];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < c) {
+            const int q = threadIdx.x / VC, j = threadIdx.x - q * VC;          // channel q * VC + j
+            float a = 0.f, b = 0.f;
+            for (int t = q; t < 256; t += ncg) {
+                a += red[(2 * j) * 256 + t];
+                b += red[(2 * j + 1) * 256 + t];
+            }
+            reinterpret_cast<float2*>(part)[(long)threadIdx.x * nblk + blockIdx.x] = make_float2(a, b);
         }
     }
 }
@@ -1339,6 +1544,19 @@ int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const flo
     MVF_REQUIRE(z && y && scale && shift && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool_bn_relu_fwd: bad argument");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
     const long total = (long)n * ho * wo * (c / 4);
+    {   // [r3] 2 x 2 pooled outputs per thread, 16-byte channel groups (MVF_POOL_FWD_BLOCK=0: the element form)
+        static const int blk_on = getenv("MVF_POOL_FWD_BLOCK") ? atoi(getenv("MVF_POOL_FWD_BLOCK")) : 1;
+        const int vc = dtype == MVF_F32 ? 4 : 8;
+        if (blk_on && h % 4 == 0 && w % 4 == 0 && c % vc == 0 && ((uintptr_t)z | (uintptr_t)y) % 16 == 0 && (uintptr_t)argmax % 8 == 0) {
+            const long tb = (long)n * (ho / 2) * (wo / 2) * (c / vc);
+            if (dtype == MVF_F32)
+                hipLaunchKernelGGL(maxpool_bn_fwd_blk_kernel<float>, dim3(grid_for(tb, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const float*)z, n, h, w, c, ho, wo, scale, shift, (float*)y, argmax);
+            else
+                hipLaunchKernelGGL(maxpool_bn_fwd_blk_kernel<bf16_t>, dim3(grid_for(tb, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, n, h, w, c, ho, wo, scale, shift, (bf16_t*)y, argmax);
+            MVF_LAUNCH_CHECK();
+            return MVF_OK;
+        }
+    }
     if (dtype == MVF_F32)
         hipLaunchKernelGGL(maxpool_bn_fwd_kernel<float>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (const float*)z, n, h, w, c, ho, wo, scale, shift, (float*)y, argmax);
     else
@@ -1367,6 +1585,14 @@ int mvf_maxpool_bn_relu_bwd(const unsigned char* argmax, const void* g, int n, i
     return MVF_OK;
 }
 
+// the block form (maxpool_bn_bwd_blk_kernel): even image sides, 16-byte channel groups that divide 256 threads, 16-byte aligned tensors
+static bool pool_blk_ok(const void* amax, const void* g, const void* ga, const void* z, const void* dz, int h, int w, int c, int dtype) {
+    static const int on = getenv("MVF_POOL_BWD_BLOCK") ? atoi(getenv("MVF_POOL_BWD_BLOCK")) : 1;
+    const int vc = dtype == MVF_F32 ? 4 : 8;
+    return on && h % 2 == 0 && w % 2 == 0 && c % vc == 0 && 256 % (c / vc) == 0 && c <= 256 && (uintptr_t)amax % 8 == 0 &&
+           ((uintptr_t)g | (uintptr_t)(ga ? ga : g) | (uintptr_t)z | (uintptr_t)(dz ? dz : z)) % 16 == 0;
+}
+
 int mvf_maxpool_bwd_sums_rows(int n, int h) { return n > 0 && h > 0 ? (int)(((long)n * h + kPoolRB - 1) / kPoolRB) : 0; }
 
 int mvf_maxpool_bn_relu_bwd_sums(const unsigned char* argmax, const void* g, int n, int h, int w, int c, void* ga, const void* z, const float* mean,
@@ -1375,6 +1601,16 @@ int mvf_maxpool_bn_relu_bwd_sums(const unsigned char* argmax, const void* g, int
                 "maxpool_bn_relu_bwd_sums: bad argument");             // ga may be NULL (mvf_maxpool_bn_relu_bwd_apply re-gathers it)
     MVF_REQUIRE(256 % (c / 4) == 0 && (long)n * h < (1L << 31), MVF_EUNSUPPORTED, "maxpool_bn_relu_bwd_sums: needs c/4 to divide 256 (use the two-pass form)");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1, nblk = mvf_maxpool_bwd_sums_rows(n, h);
+    if (pool_blk_ok(argmax, g, ga, z, nullptr, h, w, c, dtype)) {          // [r3] 2 x 2 pixel blocks per thread
+        if (dtype == MVF_F32)
+            hipLaunchKernelGGL((maxpool_bn_bwd_blk_kernel<float, 0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo, (float*)ga,
+                               (const float*)z, nullptr, mean, invstd, scale, shift, nullptr, nullptr, 0.f, sums_part, nblk, nullptr);
+        else
+            hipLaunchKernelGGL((maxpool_bn_bwd_blk_kernel<bf16_t, 0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const bf16_t*)g, n, h, w, c, ho, wo, (bf16_t*)ga,
+                               (const bf16_t*)z, nullptr, mean, invstd, scale, shift, nullptr, nullptr, 0.f, sums_part, nblk, nullptr);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     if (dtype == MVF_F32)
         hipLaunchKernelGGL(maxpool_bn_bwd_rows_sums_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo, (float*)ga,
                            (const float*)z, mean, invstd, scale, shift, sums_part, nblk);
@@ -1393,6 +1629,16 @@ int mvf_maxpool_bn_relu_bwd_apply(const unsigned char* argmax, const void* g, in
     MVF_REQUIRE(256 % (c / 4) == 0 && (long)n * h < (1L << 31), MVF_EUNSUPPORTED, "maxpool_bn_relu_bwd_apply: needs c/4 to divide 256 (use the two-pass form)");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1, nblk = mvf_maxpool_bwd_sums_rows(n, h);
     const float inv_m = 1.0f / (float)((long)n * h * w);
+    if (pool_blk_ok(argmax, g, nullptr, z, dz, h, w, c, dtype)) {
+        if (dtype == MVF_F32)
+            hipLaunchKernelGGL((maxpool_bn_bwd_blk_kernel<float, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo, (float*)nullptr,
+                               (const float*)z, gamma, mean, invstd, scale, shift, dgamma, dbeta, inv_m, nullptr, nblk, (float*)dz);
+        else
+            hipLaunchKernelGGL((maxpool_bn_bwd_blk_kernel<bf16_t, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const bf16_t*)g, n, h, w, c, ho, wo, (bf16_t*)nullptr,
+                               (const bf16_t*)z, gamma, mean, invstd, scale, shift, dgamma, dbeta, inv_m, nullptr, nblk, (bf16_t*)dz);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     if (dtype == MVF_F32)
         hipLaunchKernelGGL(maxpool_bn_bwd_rows_apply_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, argmax, (const float*)g, n, h, w, c, ho, wo,
                            (const float*)z, gamma, mean, invstd, scale, shift, dgamma, dbeta, inv_m, (float*)dz);

@@ -650,7 +650,9 @@ class _ParamStore(object):
             self._side = concurrent_stream(self.main_stream())      # not every new stream gets its own hardware queue (streams.py)
         return self._side
 
-    fuse_stem_bwd = int(os.environ.get("MVF_FUSE_STEM_BWD", "1"))        # 0: scatter, reduce, apply; 1: scatter + sums, apply (default); 2: gather + sums, gather + apply (no ga buffer; measured equal)
+    # 0: scatter, reduce, apply; 1: scatter + sums, apply; 2: gather + sums, gather + apply (no ga buffer) -- the default since the block-form kernels
+    # ([r3], train_ops.hip maxpool_bn_bwd_blk_kernel): sums 286 -> 126 us, apply 229 -> 175 us (mode 1 with the block form: 176 + 229)
+    fuse_stem_bwd = int(os.environ.get("MVF_FUSE_STEM_BWD", "2"))
     stem_wgrad_main = os.environ.get("MVF_STEM_WGRAD_MAIN", "1") != "0"
 
     overlap_downsample_bwd = os.environ.get("MVF_AUX_DOWNSAMPLE_BWD", "0") != "0"      # opt-in: measured 21.46 vs 21.51 ms (noise level), and a fourth stream beside RCCL's

@@ -865,8 +865,8 @@ def test_side_stream_overlap_is_bit_identical_to_single_stream(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_engine_switch_variants_reproduce_the_default_step(dtype):
     """The backward variants behind the engine's A/B switches compute the same step: the downsample data gradient on a third stream, the
-    stem backward without a materialised scatter (MVF_FUSE_STEM_BWD=2) and the unpaired bn3 / downsample-BN backward are BIT-identical to
-    the default over three optimizer steps; the stem backward with a separate reduce pass (mode 0) sums in another order (one step, 1e-5)."""
+    stem backward WITH a materialised scatter (MVF_FUSE_STEM_BWD=1; the default re-gathers it, [r3]) and the unpaired bn3 / downsample-BN backward are
+    BIT-identical to the default over three optimizer steps; the stem backward with a separate reduce pass (mode 0) sums in another order (one step, 1e-5)."""
     imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 96, 96)).cuda()
     labels = torch.from_numpy(synth.synth_labels(2)).cuda()
 
@@ -883,7 +883,7 @@ def test_engine_switch_variants_reproduce_the_default_step(dtype):
 
     base = run()
     # [r3] fuse_bn3_apply: bn3's apply + residual + ReLU as the epilogue of a second conv3 pass (0 = the pass over z3, 2 = every block incl. layer4)
-    for attrs in (dict(overlap_downsample_bwd=True), dict(fuse_stem_bwd=2), dict(pair_bn_bwd=False), dict(stem_wgrad_main=False)):
+    for attrs in (dict(overlap_downsample_bwd=True), dict(fuse_stem_bwd=1), dict(pair_bn_bwd=False), dict(stem_wgrad_main=False)):
         got = run(**attrs)
         assert got[0] == base[0], attrs
         assert torch.equal(got[1], base[1]), attrs
