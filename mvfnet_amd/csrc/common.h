@@ -108,9 +108,21 @@ struct Conv3x3C64Args {
     int N, H, W, xps;
     long wK;
 };
+// column sums of a pointwise conv that stores nothing (pw_sums.hip): the statistics-only pass and the BatchNorm-backward sums of a z3-free bottleneck
+struct PwSumsArgs {
+    const void* a;              // (M, xps >= 64) bf16 conv input, channels [0, 64)
+    const void* w;              // packed weights [N][64] bf16
+    const void* g;              // mode 1: block-output gradient (M, N) bf16
+    const unsigned char* bits;  // mode 1: sign bits of the block output, (M, N / 4) bytes
+    const float* c0;            // mode 0: statistics shift (or NULL); mode 1: BatchNorm mean
+    const float* c1;            // mode 1: BatchNorm invstd
+    float* part;                // [N][rows][2]
+    int rows, mode, M, N, K, xps;
+};
 namespace mvf_internal {
 int stem_direct_launch(const StemDirectArgs& a, hipStream_t st);
 int conv3x3_c64_launch(const Conv3x3C64Args& a, hipStream_t st);
+int pw_sums_launch(const PwSumsArgs& a, hipStream_t st);
 }
 
 #ifdef __HIPCC__

@@ -2059,6 +2059,17 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
             if (rc != -1) return rc;
         }
     }
+    // the two sum passes of a z3-free bottleneck over a 64-channel input (layer1's conv3: nothing is stored): their own kernel (pw_sums.hip)
+    if (dil == 1 && d->dtype == MVF_BF16 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->cin == 64 && !d->split_c && !y && stats_part &&
+        !bias && !d->relu && !bnb && !mf && !ap && d->ho == d->h && d->wo == d->w) {
+        const bool sums10 = bw && bw->mode == 10 && residual && res_mask;
+        if (sums10 || (!bw && !residual && !res_mask)) {
+            PwSumsArgs s = {x, w_packed, sums10 ? residual : nullptr, sums10 ? res_mask : nullptr, sums10 ? bw->mean : stats_shift, sums10 ? bw->invstd : nullptr,
+                            stats_part, a.stats_rows, sums10 ? 1 : 0, a.M, d->cout, 64, d->x_pix_stride};
+            const int rc = mvf_internal::pw_sums_launch(s, st);
+            if (rc != -1) return rc;
+        }
+    }
     // layer1's 3x3 (64 -> 64 channels, stride 1) and its data gradient: the direct kernel with register-resident weights (conv3x3_c64.hip)
     if (dil == 1 && d->dtype == MVF_BF16 && d->kh == 3 && d->kw == 3 && d->cin == 64 && d->cout == 64 && d->stride == 1 && d->pad == 1 &&
         d->ho == d->h && d->wo == d->w && !d->split_c && !residual && !res_mask && !mf && !ap && !bw && y && d->res_c0 <= 0) {

@@ -894,11 +894,16 @@ def test_engine_switch_variants_reproduce_the_default_step(dtype):
         assert torch.equal(got[1], base0[1]), attrs
     # [r3] z3_free: the plain blocks' bn3 backward on the recomputed conv3 sums dgamma / dbeta per 128-row tile instead of per row band: another
     # summation order (one step; the forward -- statistics-only pass + fused apply -- is bit-identical, so the loss is)
+    # [r3] in bf16 the layer1 statistics-only pass runs on csrc/pw_sums.hip (channel = lane sums): batch statistics to summation order, which the
+    # 2-clip bf16 network amplifies (rounding flips) -- the loss then agrees to 1e-2 instead of bit for bit
     ref = run(steps=1)
     for z3f in (0, 2):
         got = run(steps=1, z3_free=z3f)
-        assert got[0] == ref[0], z3f
-        assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-5 if dtype == torch.float32 else 1e-3), z3f
+        if dtype == torch.float32:
+            assert got[0] == ref[0], z3f
+        else:
+            assert abs(got[0][0] - ref[0][0]) < 1e-2 * abs(ref[0][0]), (z3f, got[0], ref[0])
+        assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-5 if dtype == torch.float32 else 1e-2), z3f       # (measured 3.6e-3)
     # one step only: the 2-clip batch-statistics network amplifies last-bit differences by orders of magnitude per step
     got, ref = run(steps=1, fuse_stem_bwd=0), run(steps=1)
     tol = 1e-5 if dtype == torch.float32 else 1e-3          # bf16: the stem's dz is re-rounded from sums that differ in the last bits
@@ -1401,7 +1406,8 @@ def test_conv_bnapply_pass_equals_bn_apply_on_the_stored_conv_output(shape, dtyp
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 9, 7, 64, 256), (3, 6, 6, 128, 96), (1, 14, 14, 256, 1024), (5, 5, 5, 32, 64), (4, 16, 16, 128, 512)], ids=str)
+@pytest.mark.parametrize("shape", [(2, 9, 7, 64, 256), (3, 56, 56, 64, 256), (2, 9, 7, 64, 128), (3, 6, 6, 128, 96), (1, 14, 14, 256, 1024), (5, 5, 5, 32, 64),
+                                   (4, 16, 16, 128, 512)], ids=str)
 def test_bn_backward_on_the_recomputed_conv_equals_the_backward_on_the_stored_output(shape, dtype):
     """[r3] mvf_conv2d_nhwc_fwd_bnbwd_sums / _apply (BatchNorm backward of bn3 without a stored z3) against mvf_bn_bwd_reduce / mvf_bn_bwd_apply_masked
     (mask mode 4) on the z3 the forward stored: dz3 BIT FOR BIT given the same dgamma / dbeta, the sums to fp32 summation order; and the
@@ -1430,7 +1436,13 @@ def test_bn_backward_on_the_recomputed_conv_equals_the_backward_on_the_stored_ou
     check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(x), None, P(wp), P(z3), P(part), None, P(ws), ws.numel(), None))
     check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(x), None, P(wp), None, P(part0), None, P(ws), ws.numel(), None))      # statistics only
     torch.cuda.synchronize()
-    assert torch.equal(part, part0)
+    if dtype == torch.bfloat16 and cin == 64 and cout in (128, 256):
+        # [r3] these two sum passes run on their own kernel (csrc/pw_sums.hip: channel = lane, one partial row per workgroup): same column sums,
+        # another summation order and partial layout
+        assert torch.isfinite(part0).all()
+        assert rel_err(part0.double().sum(1).cpu().numpy(), part.double().sum(1).cpu().numpy()) < 2e-6
+    else:
+        assert torch.equal(part, part0)
     # reference: reduce + apply on the stored z3
     bws = torch.empty(lib.mvf_bn_workspace_bytes(m, cout), dtype=torch.uint8, device="cuda")
     dg, db = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
