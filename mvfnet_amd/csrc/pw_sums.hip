@@ -44,7 +44,10 @@ __global__ __launch_bounds__(256, 3) void pw_sums_kernel(KArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int N = NB * 32, PITCH = N * 2;                  // slab row = one pixel's gradients of this workgroup's N channels
-    const int nhalf = a.N / N, chalf = blockIdx.x % nhalf, wg = blockIdx.x / nhalf, nwg = gridDim.x / nhalf;
+    // workgroup -> (pixel-block walker wg, channel half): the halves of one walker sit 8 workgroup ids apart = on the SAME XCD (ids round-robin
+    // over the 8 XCDs), so the second half's read of the conv input is served by that XCD's L2 instead of HBM
+    const int nhalf = a.N / N, nwg = gridDim.x / nhalf;
+    const int chalf = (blockIdx.x >> 3) % nhalf, wg = (blockIdx.x / (8 * nhalf)) * 8 + (blockIdx.x & 7);
     const int cb = chalf * N;                                   // first output channel of this workgroup
     // ---- weights: fragment (channel block nb, k-step ks) = 8 input channels of output channel 32 nb + (lane & 31) ----
     bf16x8 wf[NB][4];
@@ -215,6 +218,8 @@ int pw_sums_launch(const PwSumsArgs& s, hipStream_t st) {
     int nwg = (int)std::min<long>((nblocks + 3) / 4, per_cu * cus / nhalf);      // resident workgroups per CU, every wave walks its blocks
     if (nwg > s.rows) nwg = s.rows;                                 // one partial row per workgroup (and channel half)
     if (nwg < 1) return -1;
+    nwg = nwg / 8 * 8;                                              // whole groups of 8 (see the XCD pairing in the kernel)
+    if (nwg < 8) return -1;
     const int grid = nwg * nhalf;
     KArgs a = {};
     a.a = (const char*)s.a; a.w = (const char*)s.w; a.g = (const char*)s.g; a.bits = s.bits; a.c0 = s.c0; a.c1 = s.c1;
