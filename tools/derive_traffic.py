@@ -17,10 +17,10 @@ def main():
     out = {}
     for f, key in zip(sys.argv[1::2], sys.argv[2::2]):
         d = json.load(open(f))
-        conv = lambda k: k.startswith("conv_igemm") or k.startswith("conv_streamk") or k.startswith("conv3x3_c64") or k.startswith("stem_direct")          # noqa: E731
+        conv = lambda k: k.startswith("conv_igemm") or k.startswith("conv_streamk") or k.startswith("conv3x3_c64") or k.startswith("stem_direct") or k.startswith("pw_sums")          # noqa: E731
         wg = lambda k: k.startswith("wgrad_bf16_kernel") or k.startswith("wgrad_kernel") or k.startswith("wgrad_bf16_p4_kernel")     # noqa: E731
         out[key], n = weighted(d, conv)
-        out["source_" + key] = "%s: dispatch-weighted (2*FETCH_SIZE + WRITE_SIZE)*1024 over %d conv_igemm* / conv_streamk / conv3x3_c64 / stem_direct dispatches (separate --pmc passes, gfx950 x2 FETCH correction)" % (f, n)
+        out["source_" + key] = "%s: dispatch-weighted (2*FETCH_SIZE + WRITE_SIZE)*1024 over %d conv_igemm* / conv_streamk / conv3x3_c64 / stem_direct / pw_sums dispatches (separate --pmc passes, gfx950 x2 FETCH correction)" % (f, n)
         w, nw = weighted(d, wg)
         if w:
             out[key + "_wgrad"] = w
