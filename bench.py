@@ -275,7 +275,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
             u()
         eng.overlap_wgrad = overlap
     ovh = event_pair_overhead_ms()
-    r = _roof(tot["igemm"], reps, dtype, ovh, dtype + "_train", "conv_igemm_* (conv_tile instantiations: lowk / glds / p4 / streamk, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct (the direct kernels of layer1's 3x3 + its data gradient and of the stem)")
+    r = _roof(tot["igemm"], reps, dtype, ovh, dtype + "_train", "conv_igemm_* (conv_tile instantiations: lowk / glds / p4 / streamk, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct / pw_sums (the direct kernels of layer1's 3x3 + its data gradient, of the stem, and the sum-only passes of layer1's conv3)")
     groups = {"wgrad": _roof(tot["wgrad"], reps, dtype, ovh, dtype + "_train_wgrad", "wgrad_*_kernel + wgrad_reduce_kernel (csrc/wgrad_nhwc.hip)"),
               "bn": _roof(tot["bn"], reps, dtype, ovh, dtype + "_train_bn", "bn_apply / bn_bwd_reduce / bn_bwd_apply kernels (csrc/train_ops.hip)"),
               "mvf": _roof(tot["mvf"], reps, dtype, ovh, dtype + "_train_mvf", "mvf_nhwc_apply (stencil and transposed stencil, csrc/mvf_nhwc.hip)")}
