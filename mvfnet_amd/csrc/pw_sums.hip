@@ -8,7 +8,7 @@
 // the accumulators sit pixel = lane, channels in registers (D^T, the layout the STORE wants), so every column sum is a cross-lane
 // reduction through LDS.  Nothing is stored here, so the product is taken the other way round -- channel = lane, 16 pixels of a 32-pixel
 // block in the registers -- and a channel's sums are plain per-lane accumulations: 2 VGPRs per 32 channels for the whole launch, the
-// BatchNorm constants one register each, one cross-lane step (the two pixel halves) and one partial row per WORKGROUP at the very end.
+// BatchNorm constants one register each, one cross-lane step (the two pixel halves) and two partial rows (value + remainder of the fp64 sum) per WORKGROUP at the very end.
 //   * a wave owns 32-pixel blocks: the operand fragments of its pixels are four 16-byte global loads per lane (no LDS), the whole weight
 //     matrix (N x 64) is 16 VGPRs per 32 output channels;
 //   * MODE 1: g arrives pixel-major; the wave gates its [32 pixel][N] tile with the sign bits in registers, writes it to a private LDS
@@ -175,8 +175,13 @@ __global__ __launch_bounds__(256, 3) void pw_sums_kernel(KArgs a) {
     for (int c = tid; c < N; c += 256) {
         const double2 p0 = red[c], p1 = red[N + c], p2 = red[2 * N + c], p3 = red[3 * N + c];
         float2* dst = reinterpret_cast<float2*>(a.part) + (long)(cb + c) * a.rows;
-        dst[wg] = make_float2((float)((p0.x + p1.x) + (p2.x + p3.x)), (float)((p0.y + p1.y) + (p2.y + p3.y)));
-        for (int r = nwg + wg; r < a.rows; r += nwg) dst[r] = make_float2(0.f, 0.f);
+        // the workgroup's fp64 sums leave as TWO fp32 partial rows (value and remainder): the finalize adds all rows in fp64, so the channel's
+        // statistic keeps the precision of the per-tile partials of the implicit-GEMM path (and its invariance under a permutation of the clips)
+        const double t1 = (p0.x + p1.x) + (p2.x + p3.x), t2 = (p0.y + p1.y) + (p2.y + p3.y);
+        const float h1 = (float)t1, h2 = (float)t2;
+        dst[wg] = make_float2(h1, h2);
+        dst[nwg + wg] = make_float2((float)(t1 - (double)h1), (float)(t2 - (double)h2));
+        for (int r = 2 * nwg + wg; r < a.rows; r += nwg) dst[r] = make_float2(0.f, 0.f);
     }
 }
 
@@ -216,7 +221,7 @@ int pw_sums_launch(const PwSumsArgs& s, hipStream_t st) {
     const char* wpc = getenv("MVF_PW_SUMS_WGS");
     const long per_cu = wpc ? atoi(wpc) : 3;
     int nwg = (int)std::min<long>((nblocks + 3) / 4, per_cu * cus / nhalf);      // resident workgroups per CU, every wave walks its blocks
-    if (nwg > s.rows) nwg = s.rows;                                 // one partial row per workgroup (and channel half)
+    if (nwg > s.rows / 2) nwg = s.rows / 2;                         // two partial rows per workgroup (and channel half)
     if (nwg < 1) return -1;
     nwg = nwg / 8 * 8;                                              // whole groups of 8 (see the XCD pairing in the kernel)
     if (nwg < 8) return -1;
