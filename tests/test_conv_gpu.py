@@ -192,6 +192,15 @@ def test_conv3x3_c64_direct_vs_oracle_and_the_implicit_gemm(shape):
             os.environ.pop("MVF_CONV3X3_DIRECT", None)
 
     r1, r0 = run(True), run(False)
+    # workgroups whose band ranges straddle frames (5 bands each; a frame has h / 4 or h / 8): same outputs bit for bit, sums to summation order
+    os.environ["MVF_CONV3X3_BPW"] = "5"
+    try:
+        r5 = run(True)
+    finally:
+        os.environ.pop("MVF_CONV3X3_BPW", None)
+    for a_, b_ in zip((r5[0], r5[2], r5[3], r5[4]), (r1[0], r1[2], r1[3], r1[4])):
+        assert torch.equal(a_, b_)
+    assert rel_err(r5[1].cpu().numpy(), r1[1].cpu().numpy()) < 1e-5 and rel_err(r5[5].cpu().numpy(), r1[5].cpu().numpy()) < 1e-5
     nchw = lambda t: t.float().cpu().reshape(n, h, w, 64).permute(0, 3, 1, 2).numpy()
     for z, st, y2, y4, dx, bs in (r1, r0):
         assert rel_err(nchw(z), ref.numpy()) < 6e-3 and rel_err(nchw(y2), ref.numpy()) < 6e-3
@@ -252,6 +261,12 @@ def test_stem_direct_conv_vs_oracle_and_the_implicit_gemm(shape):
 
     z1, st1, y1 = run(True)
     z0, st0, y0 = run(False)
+    os.environ["MVF_STEM_TPW"] = "3"                  # workgroups that walk 3 tiles (ranges straddle frames): same outputs, sums to summation order
+    try:
+        z3, st3, y3 = run(True)
+    finally:
+        os.environ.pop("MVF_STEM_TPW", None)
+    assert torch.equal(z3, z1) and torch.equal(y3, y1) and rel_err(st3.cpu().numpy(), st1.cpu().numpy()) < 1e-5
     nchw = lambda t: t.float().cpu().reshape(n, ho, wo, 64).permute(0, 3, 1, 2).numpy()
     for z, st, y in ((z1, st1, y1), (z0, st0, y0)):
         assert rel_err(nchw(z), ref.numpy()) < 6e-3
