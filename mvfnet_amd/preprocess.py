@@ -99,3 +99,95 @@ class FramePipeline(object):
                                      int(self.to_rgb), int(self.div_255), pad, wp, out.data_ptr(), None, _DT[dtype],
                                      torch.cuda.current_stream().cuda_stream), "mvf_frames_prep_u8")
         return out
+
+
+# ---- frame-index arithmetic (host side; reference codes/datasets/pipelines/loading.py:11-131) ------------------------------------
+def _train_offsets(total_frames, span, num_clips, rng):
+    """SampleFrames._sample_clips (loading.py:35-60): start offsets of `num_clips` training clips of `span = clip_len * frame_interval`
+    source frames.  Three cases, in the reference's order: equal segments with one random shift each; sorted random starts when the
+    segments would be empty but the video is longer than max(num_clips, span); otherwise every clip starts at frame 0.
+    Draws: ONE `randint(high, size=num_clips)` call in the first two cases, none in the third."""
+    import numpy as np
+    room = total_frames - span + 1
+    seg = room // num_clips
+    if seg > 0:
+        return np.arange(num_clips, dtype=np.int64) * seg + np.asarray(rng.randint(seg, size=num_clips), dtype=np.int64)
+    if total_frames > max(num_clips, span):
+        return np.sort(np.asarray(rng.randint(room, size=num_clips), dtype=np.int64))
+    return np.zeros(num_clips, dtype=np.int64)
+
+
+def _test_offsets(total_frames, span, num_clips, sth_samples, rng):
+    """SampleFrames._test_sample_clips (loading.py:62-94).  sth_samples 1: segment centres int(tick / 2 + tick * k) (zeros when
+    tick <= 0); 2: the centres followed by the segment starts int(tick * k), no tick test; 10: ten training draws in a row; any other
+    value s: the centres, then s - 1 rows of k * floor(room / num_clips) + randint(floor(room / num_clips))."""
+    import numpy as np
+    room = total_frames - span + 1
+    tick = room / float(num_clips)
+    centres = [int(tick / 2.0 + tick * k) for k in range(num_clips)]
+    if sth_samples == 1:
+        return np.array(centres, dtype=np.int64) if tick > 0 else np.zeros(num_clips, dtype=np.int64)
+    if sth_samples == 2:
+        return np.array(centres + [int(tick * k) for k in range(num_clips)], dtype=np.int64)
+    if sth_samples == 10:
+        return np.concatenate([_train_offsets(total_frames, span, num_clips, rng) for _ in range(10)])
+    seg = room // num_clips                                   # the reference's `// float(num_clips)`: same value, as a float
+    rows = [np.array(centres, dtype=np.int64)]
+    for _ in range(sth_samples - 1):
+        rows.append(np.arange(num_clips, dtype=np.int64) * seg + np.asarray(rng.randint(float(seg), size=num_clips), dtype=np.int64))
+    return np.concatenate(rows)
+
+
+def sample_frame_inds(total_frames, clip_len, frame_interval=1, num_clips=1, test_mode=False, temporal_jitter=False, sth_samples=1, rng=None):
+    """The frame indices `SampleFrames(clip_len, frame_interval, num_clips, temporal_jitter, sth_samples)` writes to
+    results['frame_inds'] (loading.py:96-116): clip-major, frame-minor int64 array of len(offsets) * clip_len entries --
+    offset + frame * frame_interval (+ ONE jitter draw `randint(frame_interval, size=clip_len)` shared by all clips when
+    temporal_jitter), clamped to total_frames - 1.  `rng`: numpy.random (default, the reference's global generator) or a RandomState."""
+    import numpy as np
+    rng = rng if rng is not None else np.random
+    span = clip_len * frame_interval
+    if test_mode:
+        offs = _test_offsets(total_frames, span, num_clips, sth_samples, rng)
+    else:
+        offs = _train_offsets(total_frames, span, num_clips, rng)
+    inds = offs[:, None] + np.arange(clip_len, dtype=np.int64)[None, :] * frame_interval
+    if temporal_jitter:
+        inds = inds + np.asarray(rng.randint(frame_interval, size=clip_len), dtype=np.int64)[None, :]
+    return np.minimum(inds.reshape(-1), total_frames - 1).astype(np.int64)
+
+
+class SampleFrames(object):
+    """Pipeline step with the reference's name, constructor and result keys (loading.py:11-131); `total_frames` must be in `results`
+    (the reference's fallback opens the video with mmcv.VideoReader: decoding stays on the host, out of this repo's scope)."""
+
+    def __init__(self, clip_len, frame_interval=1, num_clips=1, temporal_jitter=False, sth_samples=1):
+        self.clip_len, self.frame_interval, self.num_clips = clip_len, frame_interval, num_clips
+        self.temporal_jitter, self.sth_samples = temporal_jitter, sth_samples
+
+    def __call__(self, results):
+        if "total_frames" not in results:
+            raise KeyError("SampleFrames: results['total_frames'] is required (video probing is not part of this build)")
+        results["frame_inds"] = sample_frame_inds(results["total_frames"], self.clip_len, self.frame_interval, self.num_clips,
+                                                  bool(results["test_mode"]), self.temporal_jitter, self.sth_samples)
+        results["clip_len"], results["frame_interval"] = self.clip_len, self.frame_interval
+        results["num_clips"], results["sth_samples"] = self.num_clips, self.sth_samples
+        return results
+
+
+class Normalize(object):
+    """Pipeline step with the reference's name, constructor and result keys (augmentations.py:343-376) over the device kernel: here
+    `img_group` is a CUDA uint8 tensor (..., H, W, 3) of decoded frames and the result is the (n, 3, H, W) fp32 tensor the reference's
+    Normalize + FormatShape('NCHW') produce -- float32(img) [/ 255] -> channel swap when to_rgb -> subtract float32(mean) -> multiply by
+    float32(1 / float64(std)), each a single rounded fp32 operation (mvf_frames_prep_u8)."""
+
+    def __init__(self, mean, std, div_255=False, to_rgb=False):
+        import numpy as np
+        self.mean, self.std = np.array(mean, dtype=np.float32), np.array(std, dtype=np.float32)
+        self.div_255, self.to_rgb = div_255, to_rgb
+
+    def __call__(self, results):
+        f = results["img_group"]
+        pipe = FramePipeline(self.mean.tolist(), self.std.tolist(), to_rgb=self.to_rgb, div_255=self.div_255, crop_size=(f.shape[-2], f.shape[-3]))
+        results["img_group"] = pipe.to_nchw(f)
+        results["img_norm_cfg"] = dict(mean=self.mean, std=self.std, div_255=self.div_255, to_rgb=self.to_rgb)
+        return results

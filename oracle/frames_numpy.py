@@ -10,13 +10,22 @@ Follows, step by step:
               each step rounded to float32 (cv2.subtract / cv2.multiply on a CV_32F image with a scalar)
   * stacking  codes/datasets/pipelines/formating.py:146-160: per frame HWC -> CHW, np.stack over frames
 
-PARITY STATUS: FormatShape is pinned by a golden vector from the reference's own class (tests/golden/make_frames_golden.py).
-[r3] The crop / flip DECISIONS -- ThreeCrop's three boxes and their order, the crop-major / frame-minor order of the oversampled
-group, CenterCrop's box, Flip's `np.random.rand() < flip_ratio` draw -- are the reference's own code and are pinned by
-tests/golden/crops_cases.npz, recorded from those classes through logging stand-ins for `mmcv.imcrop` / `mmcv.imflip`
-(tests/golden/make_crops_golden.py; tests/test_frames_cpu.py).  What stays **parity unpinned** is third-party pixel arithmetic only:
-`mmcv.imcrop` / `imflip` themselves (mmcv 0.4.3: a slice, a reversed view) and cv2's cvtColor / subtract / multiply inside Normalize
-(restated from their documented fp32 behaviour) -- neither library is installed in the build container."""
+PARITY STATUS: every step that is the REFERENCE's own code is pinned by golden vectors recorded from its own classes:
+  * FormatShape                      tests/golden/make_frames_golden.py (frames_cases.npz)
+  * ThreeCrop / CenterCrop / Flip    [r3] boxes, crop order, oversample stacking order, the flip draw -- recorded through logging stand-ins
+                                     for `mmcv.imcrop` / `mmcv.imflip` (make_crops_golden.py, crops_cases.npz)
+  * SampleFrames                     [r4] `sample_frame_inds` below against the reference's SampleFrames for 69 (case, seed) pairs: the three
+                                     branches of _sample_clips, _test_sample_clips for sth_samples 1 / 2 / 10 / generic, temporal jitter,
+                                     the `minimum(total_frames - 1)` clamp, the shipped 8x8 / 16x4 / 10-clip test recipes, and the NUMBER
+                                     of random draws (make_sampling_golden.py, sampling_cases.npz)
+  * Normalize                        [r4] `imnormalize` below against the reference's Normalize (augmentations.py:343-386 is the reference's own
+                                     class): call order cvtColor -> subtract -> multiply, in place, the float64 (1,3) scalar operands
+                                     float64(float32(mean)) and 1 / float64(float32(std)), `div_255` (uint8 / 255 in fp32 before the call),
+                                     `to_rgb`, img_norm_cfg -- recorded through logging stand-ins for the three cv2 primitives
+                                     (make_normalize_golden.py, normalize_cases.npz); outputs bit-equal.
+What stays **parity unpinned** is third-party pixel arithmetic only: `mmcv.imcrop` / `imflip` themselves (mmcv 0.4.3: a slice, a reversed
+view) and cv2's cvtColor / subtract / multiply on a CV_32F image with a scalar operand (one rounded fp32 operation per element, the scalar
+converted to fp32) -- restated from their documented behaviour; neither library is installed in the build container."""
 import numpy as np
 
 
@@ -71,3 +80,42 @@ def frames_to_nchw(frames_u8, window, h, w, mean, std, to_rgb=True, div_255=Fals
             img = img[:, ::-1]
         out[i] = imnormalize(img, mean, std, to_rgb, div_255).transpose(2, 0, 1)
     return out
+
+
+def sample_frame_inds(total_frames, clip_len, frame_interval, num_clips, test_mode, temporal_jitter=False, sth_samples=1, rng=np.random):
+    """SampleFrames._get_frame_inds (codes/datasets/pipelines/loading.py:96-116) with _sample_clips (:35-60) and _test_sample_clips
+    (:62-94) written out statement by statement; `rng` supplies `randint` (the reference uses the global np.random)."""
+    ori_clip_len = clip_len * frame_interval
+
+    def sample_clips():                                            # loading.py:47-60
+        avg_interval = (total_frames - ori_clip_len + 1) // num_clips
+        if avg_interval > 0:
+            return np.arange(num_clips) * avg_interval + rng.randint(avg_interval, size=num_clips)
+        if total_frames > max(num_clips, ori_clip_len):
+            return np.sort(rng.randint(total_frames - ori_clip_len + 1, size=num_clips))
+        return np.zeros((num_clips,))
+
+    if test_mode:                                                  # loading.py:62-94
+        tick = (total_frames - ori_clip_len + 1) / float(num_clips)
+        if sth_samples == 1:
+            clip_offsets = np.array([int(tick / 2.0 + tick * x) for x in range(num_clips)]) if tick > 0 else np.zeros((num_clips,))
+        elif sth_samples == 2:
+            clip_offsets = np.array([int(tick / 2.0 + tick * x) for x in range(num_clips)] + [int(tick * x) for x in range(num_clips)])
+        elif sth_samples == 10:
+            offsets = []
+            for _ in range(10):
+                offsets += sample_clips().tolist()
+            clip_offsets = np.array(offsets)
+        else:
+            rows = [np.array([int(tick / 2.0 + tick * x) for x in range(num_clips)])]
+            avg_duration = (total_frames - ori_clip_len + 1) // float(num_clips)
+            for _ in range(sth_samples - 1):
+                rows.append(np.multiply(list(range(num_clips)), avg_duration) + rng.randint(avg_duration, size=num_clips))
+            clip_offsets = np.stack(rows).reshape(-1)
+    else:
+        clip_offsets = sample_clips()
+    frame_inds = clip_offsets[:, None] + np.arange(clip_len)[None, :] * frame_interval          # loading.py:103-104
+    if temporal_jitter:                                                                          # :105-110 one draw, shared by the clips
+        frame_inds = frame_inds + rng.randint(frame_interval, size=clip_len)[None, :]
+    frame_inds = np.concatenate(frame_inds)
+    return np.minimum(frame_inds, total_frames - 1).astype(np.int64)                             # :115

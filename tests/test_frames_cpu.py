@@ -109,3 +109,73 @@ def test_flip_decision_is_one_draw_below_the_ratio():
             assert flip_flag(ratio, np.random.RandomState(seed)) == bool(flag), tag
             seen.add((ratio, flag))
     assert {(0.5, 0), (0.5, 1), (0.0, 0), (1.0, 1)} <= seen
+
+
+# ------------------------------------------------------------------------------------------------ [r4] SampleFrames / Normalize vs the reference's classes
+GS = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampling_cases.npz"))
+GN = np.load(os.path.join(os.path.dirname(__file__), "golden", "normalize_cases.npz"))
+
+
+def _sampling_cases():
+    return sorted({k.rsplit("/", 1)[0] for k in GS.files})
+
+
+def test_sample_frame_inds_match_the_reference_sampleframes():
+    """oracle/frames_numpy.sample_frame_inds AND mvfnet_amd.preprocess.sample_frame_inds / SampleFrames against what the reference's
+    SampleFrames returned (tests/golden/make_sampling_golden.py): indices bit-equal, and the same NUMBER of random draws (the next
+    draw of the seeded generator after the call is the recorded one)."""
+    from mvfnet_amd import preprocess as P
+    cases = _sampling_cases()
+    assert len(cases) == 69
+    branches = set()
+    for c in cases:
+        total, clip_len, interval, num_clips, test_mode, jitter, sth, seed = (int(v) for v in GS[c + "/args"])
+        want = GS[c + "/frame_inds"]
+        assert want.dtype == np.int64 and want.max() <= total - 1      # (sth_samples = 2 on a too-short video yields NEGATIVE indices in the reference: kept)
+        for fn in (F.sample_frame_inds, P.sample_frame_inds):
+            np.random.seed(seed)
+            got = fn(total, clip_len, interval, num_clips, bool(test_mode), bool(jitter), sth)
+            assert got.dtype == np.int64 and np.array_equal(got, want), (c, fn.__module__)
+            assert np.random.randint(1 << 30) == int(GS[c + "/next_draw"]), (c, "number of draws")
+        # the pipeline-step form writes the same keys as the reference's __call__
+        np.random.seed(seed)
+        res = P.SampleFrames(clip_len, interval, num_clips, bool(jitter), sth)(dict(total_frames=total, test_mode=bool(test_mode)))
+        assert np.array_equal(res["frame_inds"], want)
+        assert [res["clip_len"], res["frame_interval"], res["num_clips"], res["sth_samples"]] == GS[c + "/keys"].tolist()
+        # an explicit RandomState gives the same stream as the seeded global generator
+        got = P.sample_frame_inds(total, clip_len, interval, num_clips, bool(test_mode), bool(jitter), sth, rng=np.random.RandomState(seed))
+        assert np.array_equal(got, want)
+        span = clip_len * interval
+        if not test_mode:
+            branches.add(1 if (total - span + 1) // num_clips > 0 else (2 if total > max(num_clips, span) else 3))
+    assert branches == {1, 2, 3}                  # every branch of _sample_clips is in the fixture
+    # the C5 recipe: 10 clips x 8 frames x interval 8 of a 300-frame video -> 80 indices, clip-major
+    c5 = GS["test_c5_10x8x8_300/seed0/frame_inds"]
+    assert c5.shape == (80,) and np.array_equal(np.diff(c5.reshape(10, 8), axis=1), np.full((10, 7), 8))
+
+
+def test_normalize_matches_the_reference_class_call_by_call():
+    """The reference's Normalize (augmentations.py:343-386) run over recording stand-ins of the three cv2 primitives
+    (tests/golden/make_normalize_golden.py): the recorded call order / operands are what oracle/frames_numpy.imnormalize restates,
+    and its output equals the class's output bit for bit."""
+    tags = sorted({k.split("/")[0] for k in GN.files})
+    assert tags == ["all_values", "div255_bgr", "div255_rgb", "k400_bgr", "k400_rgb"]
+    for tag in tags:
+        fr = GN[tag + "/frames"]
+        div, rgb = (bool(v) for v in GN[tag + "/cfg_flags"])
+        mean, std = GN[tag + "/cfg_mean"], GN[tag + "/cfg_std"]
+        assert mean.dtype == np.float32 and std.dtype == np.float32          # Normalize.__init__: np.array(..., dtype=np.float32)
+        per_img = [0, 1, 2] if rgb else [1, 2]                               # cvtColor BEFORE subtract BEFORE multiply, per image
+        assert GN[tag + "/calls"].tolist() == per_img * fr.shape[0]
+        assert int(GN[tag + "/inplace"]) == 1 and int(GN[tag + "/scalars_constant"]) == 1
+        # operands: float64 (1, 3): float64(float32(mean)), 1 / float64(float32(std))
+        assert GN[tag + "/sub_scalar"].dtype == np.float64 and GN[tag + "/sub_scalar"].shape == (1, 3)
+        assert np.array_equal(GN[tag + "/sub_scalar"], np.float64(mean.reshape(1, -1)))
+        assert np.array_equal(GN[tag + "/mul_scalar"], 1 / np.float64(std.reshape(1, -1)))
+        # div_255: the image enters imnormalize as float32 (uint8 / 255 in fp32), otherwise as uint8
+        assert GN[tag + "/in_dtype"].tolist() == [1 if div else 0] * fr.shape[0]
+        got = np.stack([F.imnormalize(f, mean, std, rgb, div) for f in fr])
+        assert got.dtype == np.float32 and np.array_equal(got, GN[tag + "/out"]), tag
+        # and through the stacking step
+        nchw = F.frames_to_nchw(fr, None, fr.shape[1], fr.shape[2], mean, std, to_rgb=rgb, div_255=div)
+        assert np.array_equal(nchw, GN[tag + "/out"].transpose(0, 3, 1, 2))

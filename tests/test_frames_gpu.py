@@ -130,3 +130,23 @@ def test_recognizer_api_with_uint8_frames_matches_fp32_input():
     l0 = float(m(x, lab)["loss_cls"].detach())
     l1 = float(m(fr_t, lab, window=win_t)["loss_cls"].detach())
     assert l1 == pytest.approx(l0, rel=1e-5)
+
+
+def test_normalize_kernel_bit_exact_vs_the_reference_class_golden():
+    """[r4] mvf_frames_prep_u8 (and the Normalize pipeline step over it) against the images the REFERENCE's Normalize class returned
+    (tests/golden/normalize_cases.npz, make_normalize_golden.py): bit-equal for K400's mean / std with and without to_rgb, the div_255
+    convention, and every uint8 value in every channel."""
+    import os
+    from mvfnet_amd.preprocess import FramePipeline, Normalize
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "normalize_cases.npz"))
+    for tag in sorted({k.split("/")[0] for k in G.files}):
+        fr = G[tag + "/frames"]
+        div, rgb = (bool(v) for v in G[tag + "/cfg_flags"])
+        mean, std = G[tag + "/cfg_mean"], G[tag + "/cfg_std"]
+        want = G[tag + "/out"].transpose(0, 3, 1, 2)
+        pipe = FramePipeline(mean.tolist(), std.tolist(), to_rgb=rgb, div_255=div, crop_size=(fr.shape[2], fr.shape[1]))
+        got = pipe.to_nchw(torch.from_numpy(fr).cuda(), None).cpu().numpy()
+        assert np.array_equal(got, want), tag
+        res = Normalize(mean, std, div_255=div, to_rgb=rgb)(dict(img_group=torch.from_numpy(fr).cuda()))
+        assert np.array_equal(res["img_group"].cpu().numpy(), want), tag
+        assert np.array_equal(res["img_norm_cfg"]["mean"], mean) and res["img_norm_cfg"]["to_rgb"] == rgb
