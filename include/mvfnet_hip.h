@@ -137,7 +137,9 @@ int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void*
  * applies the BatchNorm whose batch statistics the first pass (mvf_conv2d_nhwc_fwd_stats) produced: the accumulators are rounded to the storage
  * type (= the z3 that first pass stored), out = relu(bn_scale * z3 + bn_shift + r), r = residual or -- a downsample block -- res_scale * residual
  * + res_shift (that branch's BatchNorm applied to its raw conv output); sign_bits [n*ho*wo][cout/4] bytes as mvf_bn_apply_bits writes them.
- * Same result as mvf_bn_apply_bits on the stored z3, bit for bit, without reading z3.  d->relu = 0, in_dil <= 1. */
+ * Same result as mvf_bn_apply_bits on the z3 THIS entry point's first pass (mvf_conv2d_nhwc_fwd_stats through the same kernel) stored, bit for bit,
+ * without reading z3; a statistics pass through another kernel (csrc/pw_sums.hip) may have seen individual z3 elements one storage-type ulp away.
+ * d->relu = 0, in_dil <= 1. */
 int mvf_conv2d_nhwc_fwd_bnapply(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bn_scale,
                                 const float* bn_shift, const void* residual, const float* res_scale, const float* res_shift, void* out,
                                 unsigned char* sign_bits, void* ws, size_t ws_bytes, void* stream);

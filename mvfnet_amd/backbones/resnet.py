@@ -71,7 +71,9 @@ class Bottleneck(nn.Module):
         tr = getattr(self, "_trainer", None)
         if tr is None or tr.tdtype != x.dtype:
             from ..train_engine import BlockTrainer
-            tr = BlockTrainer(self, dtype=x.dtype)
+            # rehome=False: the block's parameters stay where they are (they may be views of a model-level TrainEngine's flat buffer,
+            # which the optimizer keeps updating); only the gradient buffer is the trainer's own, and backward() hands out copies
+            tr = BlockTrainer(self, dtype=x.dtype, rehome=False)
             object.__setattr__(self, "_trainer", tr)
         return _BlockFn.apply(tr, x, *list(self.parameters()))
 

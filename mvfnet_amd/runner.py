@@ -131,7 +131,11 @@ class EngineSGD(object):
                                   params=list(model.parameters()))]
 
     def zero_grad(self):
-        pass                          # the engine's backward overwrites the whole flat gradient every step
+        """The engine's backward overwrites the whole flat gradient every step, so nothing is zeroed there; the `.grad` copies that
+        autograd hands to the parameters under the hook flow (dist._engine_backed_iter: loss.backward()) are dropped so that they do
+        not pile up as an ever-growing sum (torch.optim's set_to_none behaviour)."""
+        for p in self.model.parameters():
+            p.grad = None
 
     def step(self, lr=None):
         g = self.param_groups[0]
@@ -257,11 +261,15 @@ class DevicePrefetcher(object):
                 self._consumed[cur_slot] = done
 
 
-def build_dataloader(dataset, videos_per_gpu, workers_per_gpu=0, dist_mode=False, shuffle=True, drop_last=False, pin_memory=False):
+def build_dataloader(dataset, videos_per_gpu, workers_per_gpu=0, dist_mode=False, shuffle=True, drop_last=False, pin_memory=None):
     """A torch DataLoader over `dataset` (items: dict(img_group=tensor, label=tensor)): DistributedSampler (rank::world, as the
     reference's sampler.py:62-78 deals videos) when distributed.  Like the reference's build_dataloader (datasets/builder.py) the
     last, partial batch of an epoch is kept (drop_last=False: the engine's buffers are keyed by shape) -- the iteration count that
-    drives the warm-up is the reference's.  Datasets / decode pipelines themselves are out of scope."""
+    drives the warm-up is the reference's.  pin_memory defaults to the reference's True (datasets/loader/build_loader.py:22) whenever a GPU
+    is present: DevicePrefetcher then uploads straight from the loader's pinned batch (no staging memcpy).  Datasets / decode pipelines
+    themselves are out of scope."""
+    if pin_memory is None:
+        pin_memory = torch.cuda.is_available()
     if isinstance(dataset, (torch.utils.data.DataLoader, list, tuple)) or not hasattr(dataset, "__getitem__"):
         return dataset                                     # already a loader / a list or iterable of ready batches
     sampler = None

@@ -244,7 +244,10 @@ class _TConv(object):
 
     def forward_apply(self, x, n, h, w, bn, residual, rbn=None):
         """[r3] The block's last conv AGAIN, with bn's apply + residual + ReLU + sign bits as its epilogue (mvf_conv2d_nhwc_fwd_bnapply): the
-        same `out` / bits as bn.apply(z3, residual, rbn, bits=True), bit for bit, reading the conv's narrow input instead of z3."""
+        same `out` / bits as bn.apply(z3, residual, rbn, bits=True) reading the conv's narrow input instead of z3 -- bit for bit when the
+        z3 that was stored came from the SAME kernel (same summation order: tests/test_conv_gpu.py).  In a z3-free block the statistics pass
+        may be another kernel (pw_sums.hip: MFMA operands the other way round), so individual recomputed z3 elements can differ from the
+        ones the statistics saw by one storage-type ulp: numerically benign, covered by test_z3_free_block_gradients_match_stored_z3_block."""
         ho, wo = self.out_hw(h, w)
         d = self.desc(n, h, w, ho, wo, self.cin)
         m = n * ho * wo
@@ -570,7 +573,11 @@ class _TBlock(object):
 class _ParamStore(object):
     """Flat fp32 parameter / gradient / momentum buffers for a module; its nn.Parameters become views."""
 
-    def _init_store(self, model, dtype=torch.float32):
+    def _init_store(self, model, dtype=torch.float32, rehome=True):
+        """rehome=True: the parameters become views of this store's flat buffer (the optimizer kernel and the gradient exchange work on
+        it).  rehome=False (Bottleneck.forward as a stand-alone autograd node): the parameters stay where they are -- possibly views of
+        a MODEL engine's flat buffer, which must keep aliasing them -- and only the gradient buffer is private; every kernel reads the
+        parameters through the module's own tensors, so nothing is copied; apply_sgd is not available on such a store."""
         if dtype not in (torch.float32, torch.bfloat16):
             raise TypeError("training dtype must be float32 or bfloat16 (activation storage; weights/statistics/gradients stay fp32)")
         self.tdtype = dtype
@@ -585,29 +592,35 @@ class _ParamStore(object):
         n = sum(p.numel() for p in params)
         pad = lambda k: (k + 3) // 4 * 4
         total = sum(pad(p.numel()) for p in params)
-        self.flat_params = torch.zeros(total, device=dev)
+        self.rehomed = bool(rehome)
+        self.flat_params = torch.zeros(total, device=dev) if rehome else None
         self.flat_grads = torch.zeros(total, device=dev)
-        self.flat_mom = torch.zeros(total, device=dev)
+        self.flat_mom = torch.zeros(total, device=dev) if rehome else None
         self._grad_view = {}
         off = 0
         with torch.no_grad():
             for p in params:
                 k = p.numel()
-                v = self.flat_params[off:off + k].view(p.shape)
-                v.copy_(p.data.float())
-                p.data = v
+                if rehome:
+                    v = self.flat_params[off:off + k].view(p.shape)
+                    v.copy_(p.data.float())
+                    p.data = v
+                elif p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                    raise TypeError("stand-alone block: parameters must be contiguous float32 tensors on %s" % dev)
                 gv = self.flat_grads[off:off + k].view(p.shape)
                 self._grad_view[id(p)] = gv
                 off += pad(k)
         self.n_params = n
-        for m_ in model.modules():                      # cached inference engines hold packed copies of the old storage
-            if hasattr(m_, "invalidate_engine"):
-                m_.invalidate_engine()
+        if rehome:
+            for m_ in model.modules():                  # cached inference engines / block trainers hold (packed copies of) the old storage
+                if hasattr(m_, "invalidate_engine"):
+                    m_.invalidate_engine()
         self._ws = None
         self.norm_out = torch.zeros(2, device=dev)
         self.steps = 0
         self._ones = {}
         self._bufs = {}
+        self._caps = {}
 
     def grad_of(self, p):
         return self._grad_view[id(p)]
@@ -617,10 +630,25 @@ class _ParamStore(object):
         nothing goes through the caching allocator inside a step (torch.empty + record_stream bookkeeping cost ~60 us per
         call here and made the host the bottleneck at 36 ms/step)."""
         dt = dtype or self.tdtype
-        k = (key, tuple(shape), dt)
+        shape = tuple(shape)
+        k = (key, shape, dt)
         t = self._bufs.get(k)
         if t is None:
-            t = torch.empty(tuple(shape), device=self.device, dtype=dt)
+            # One allocation per call site, sized for the LARGEST shape seen there; other shapes (the partial last batch of an epoch:
+            # drop_last=False as in the reference) are views of it instead of a second resident set of activation buffers.
+            n = 1
+            for v in shape:
+                n *= int(v)
+            ck = (key, dt)
+            flat = self._caps.get(ck)
+            if flat is None or flat.numel() < n:
+                if flat is not None:                   # a larger batch arrived: side-stream kernels may still read the old storage
+                    self._side_keep.append(flat)
+                    for kk in [kk for kk in self._bufs if kk[0] == key and kk[2] == dt]:
+                        del self._bufs[kk]
+                flat = torch.empty(max(n, 1), device=self.device, dtype=dt)
+                self._caps[ck] = flat
+            t = flat[:n].view(shape)
             self._bufs[k] = t
         return t
 
@@ -732,7 +760,7 @@ class _ParamStore(object):
         flags = [p.requires_grad for p in params]
         k = flags.index(True) if True in flags else len(flags)
         self._scattered_frozen = not all(flags[k:])
-        return self._grad_view[id(params[k])].storage_offset() if k < len(params) else self.flat_params.numel()
+        return self._grad_view[id(params[k])].storage_offset() if k < len(params) else self.flat_grads.numel()
 
     nesterov = True
     param_options = None       # {id(param): (lr_mult, decay_mult)}: build_optimizer's paramwise_options (see set_param_options)
@@ -764,6 +792,8 @@ class _ParamStore(object):
 
     def apply_sgd(self, lr=None, world=1):
         """clip_grad_norm_(max_norm) + SGD on the flat buffers (gradient scaled by 1 / world): one fused launch sequence."""
+        if not self.rehomed:
+            raise RuntimeError("apply_sgd: this store does not own its parameters (stand-alone Bottleneck.forward); use the model's train engine or a torch optimizer")
         off = self.trainable_offset()
         n = self.flat_params.numel() - off
         if n <= 0:
@@ -831,8 +861,8 @@ class _ParamStore(object):
 class BlockTrainer(_ParamStore):
     """Train-mode forward/backward of ONE mvfnet_amd Bottleneck (with or without MVF) -- used by the parity tests."""
 
-    def __init__(self, block, dtype=torch.float32):
-        self._init_store(block, dtype)
+    def __init__(self, block, dtype=torch.float32, rehome=True):
+        self._init_store(block, dtype, rehome)
         self.blk = _TBlock(block, self)
 
     def forward(self, x_nchw):

@@ -1463,3 +1463,114 @@ def test_bn_backward_on_the_recomputed_conv_equals_the_backward_on_the_stored_ou
         assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
     else:           # fp32: the two kernels contract a * (g - d0 - (z - mu) * kx) into fused multiply-adds differently (last-bit differences)
         assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ [r4] advisor findings of round 3
+def test_standalone_block_call_inside_a_model_leaves_the_models_engine_in_charge():
+    """A block of a model that already has a train engine, called on its own (feature hooks, debugging): the block's trainer must not
+    re-home the parameters -- they stay views of the MODEL engine's flat buffer, the next optimizer step still moves what the block
+    reads, and the block's gradients are copies (the model engine's flat gradient is untouched by the stand-alone call)."""
+    m = _model(50, 4, dropout=0.0)
+    eng = m.train_engine()
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+    eng.train_step(imgs, labels)
+    blk = m.backbone.layer1[1]
+    lo, hi = eng.flat_params.data_ptr(), eng.flat_params.data_ptr() + eng.flat_params.numel() * 4
+    before = [p.data_ptr() for p in blk.parameters()]
+    grads_before = eng.flat_grads.clone()
+    x = torch.randn(8, 256, 16, 16, device="cuda", requires_grad=True)
+    y = blk(x)
+    y.sum().backward()
+    torch.cuda.synchronize()
+    assert [p.data_ptr() for p in blk.parameters()] == before and all(lo <= a < hi for a in before)
+    assert torch.equal(eng.flat_grads, grads_before)                      # the stand-alone backward wrote its own buffer
+    assert all(p.grad is not None and p.grad.data_ptr() != eng.grad_of(p).data_ptr() for p in blk.parameters())
+    w0 = blk.conv2.weight.detach().clone()
+    y0 = blk(x.detach()).detach().clone()
+    eng.train_step(imgs, labels)                                          # the model's optimizer still owns the block's weights
+    torch.cuda.synchronize()
+    assert not torch.equal(blk.conv2.weight.detach(), w0)
+    assert not torch.equal(blk(x.detach()).detach(), y0)                  # and the stand-alone forward reads the UPDATED weights
+    with pytest.raises(RuntimeError):
+        blk._trainer.apply_sgd()                                          # a store that does not own its parameters has no optimizer
+
+
+def test_engine_backed_optimizer_zero_grad_drops_the_autograd_copies():
+    from mvfnet_amd.runner import EngineSGD
+    m = _model(50, 4, dropout=0.0)
+    opt = EngineSGD(m, lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 64, 64)).cuda()
+    labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+    norms = []
+    for _ in range(2):
+        opt.zero_grad()
+        assert all(p.grad is None for p in m.parameters())
+        loss = m(imgs, labels, return_loss=True)["loss_cls"]
+        loss.backward()
+        norms.append(float(m.backbone.conv1.weight.grad.norm()))
+        opt.step()
+    assert norms[1] < 1.9 * norms[0]              # .grad is this step's gradient, not the running sum of all steps
+
+
+def test_trailing_partial_batch_reuses_the_engines_buffers():
+    """drop_last=False (the reference's loader): the epoch's last, smaller batch must not allocate a second resident set of activation
+    buffers, and its gradients equal a fresh engine's on the same clips (the small-M launches take the direct-kernel fallbacks)."""
+    for dtype in (torch.float32, torch.bfloat16):
+        m = _model(50, 4, dropout=0.0)
+        eng = m.train_engine(dtype=dtype)
+        imgs = torch.from_numpy(synth.synth_clip_batch(3, 4, 96, 96)).cuda()
+        labels = torch.from_numpy(synth.synth_labels(3)).cuda()
+        eng.forward(imgs, labels)
+        eng.backward()
+        torch.cuda.synchronize()
+        n_alloc = len(eng._caps)
+        mem = torch.cuda.memory_allocated()
+        l2 = eng.forward(imgs[:1], labels[:1])
+        eng.backward()
+        torch.cuda.synchronize()
+        g2 = eng.flat_grads.clone()
+        assert len(eng._caps) == n_alloc                                   # every call site re-used its allocation
+        assert torch.cuda.memory_allocated() - mem < 64 << 20
+        l3 = eng.forward(imgs, labels)                                     # and the full batch again, in the same storage
+        eng.backward()
+        torch.cuda.synchronize()
+        assert len(eng._caps) == n_alloc and torch.isfinite(l3).all()
+        m1 = _model(50, 4, dropout=0.0)
+        e1 = m1.train_engine(dtype=dtype)
+        l1 = e1.forward(imgs[:1], labels[:1])
+        e1.backward()
+        torch.cuda.synchronize()
+        # (the first engine's running means have moved: its statistics sums are shifted by another constant -> last-bit differences,
+        # which a 1-clip batch-statistics network amplifies; bf16 rounding flips on top)
+        tol = 2e-3 if dtype == torch.float32 else 0.5
+        assert abs(float(l1) - float(l2)) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(float(l1))
+        assert rel_l2(g2.cpu().numpy(), e1.flat_grads.cpu().numpy()) < tol
+
+
+def test_z3_free_block_gradients_match_stored_z3_block():
+    """[r3 advisor] The z3-free path takes bn3's statistics from one kernel's rounded z3 (pw_sums.hip) and apply / backward from the
+    recomputed conv's: individual z3 elements may differ by one bf16 ulp between the passes.  End to end on layer1's bf16 block shape
+    (256 -> 64 -> 256, 56 x 56) the gradients of z3_free = 1 and = 0 agree to the bf16 noise floor."""
+    from mvfnet_amd.backbones.resnet import Bottleneck
+    from mvfnet_amd.train_engine import BlockTrainer
+    res = {}
+    for z3f in (0, 1):
+        torch.manual_seed(3)
+        blk = Bottleneck(256, 64).cuda().train()
+        with torch.no_grad():
+            for bn in (blk.bn1, blk.bn2, blk.bn3):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0, 0.2)
+        tr = BlockTrainer(blk, dtype=torch.bfloat16)
+        tr.z3_free = z3f
+        assert tr.blk.z3_free(tr) == bool(z3f)
+        x = torch.randn(8, 256, 56, 56, device="cuda")
+        dy = torch.randn(8, 256, 56, 56, device="cuda")
+        y = tr.forward(x).float().clone()
+        dx = tr.backward(dy).float().clone()
+        torch.cuda.synchronize()
+        res[z3f] = (y, dx, tr.flat_grads.clone())
+    assert rel_l2(res[1][0].cpu().numpy(), res[0][0].cpu().numpy()) < 4e-3          # out: bf16 ulp flips of single elements
+    assert rel_l2(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) < 1e-2
+    assert rel_l2(res[1][2].cpu().numpy(), res[0][2].cpu().numpy()) < 1e-2
