@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--clips", type=int, default=32, help="clips per GPU per step")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-overlap", action="store_true",
                     help="train mode: keep the weight-gradient GEMMs on the launch stream (profiling: every kernel runs alone, as in "
                          "the roofline pass)")
@@ -182,7 +182,7 @@ def roofline_infer(model, imgs, dtype, per_layer):
     finally:
         undo()
         model.backbone.engine().streams = streams
-    return _roof(tot, reps, dtype, event_pair_overhead_ms(), dtype + "_infer", "conv_igemm_* (conv_tile instantiations, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct (the direct kernels of layer1's 3x3 and the stem)")
+    return _roof(tot, reps, dtype, event_pair_overhead_ms(), dtype + "_infer", pmc_group="conv", kernel="conv_igemm_* (conv_tile instantiations, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct (the direct kernels of layer1's 3x3 and the stem)")
 
 
 def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
@@ -261,6 +261,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
     timers = (("igemm", tc), ("wgrad", tw), ("bn", tb), ("mvf", tm))
     try:
         tot = {k: [0.0, 0.0, 0.0, 0] for k, _ in timers}
+        tot["igemm_required"], tot["igemm_recompute"] = [0.0, 0.0, 0.0, 0], [0.0, 0.0, 0.0, 0]
         reps = 2
         for i in range(reps):
             for _, t in timers:
@@ -270,25 +271,41 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
             torch.cuda.synchronize()
             for k, t in timers:
                 tot[k] = [a + b for a, b in zip(tot[k], _summ(t.rec, per_layer and i == reps - 1, k, PEAK_TFLOPS[dtype]))]
+            rec = [r_ for r_ in tc.rec if r_[3].startswith(RECOMPUTE_TAGS)]
+            req = [r_ for r_ in tc.rec if not r_[3].startswith(RECOMPUTE_TAGS)]
+            tot["igemm_recompute"] = [a + b for a, b in zip(tot["igemm_recompute"], _summ(rec, False, "", PEAK_TFLOPS[dtype]))]
+            tot["igemm_required"] = [a + b for a, b in zip(tot["igemm_required"], _summ(req, False, "", PEAK_TFLOPS[dtype]))]
     finally:
         for u in undo:
             u()
         eng.overlap_wgrad = overlap
     ovh = event_pair_overhead_ms()
-    r = _roof(tot["igemm"], reps, dtype, ovh, dtype + "_train", "conv_igemm_* (conv_tile instantiations: lowk / glds / p4 / streamk, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct / pw_sums (the direct kernels of layer1's 3x3 + its data gradient, of the stem, and the sum-only passes of layer1's conv3)")
-    groups = {"wgrad": _roof(tot["wgrad"], reps, dtype, ovh, dtype + "_train_wgrad", "wgrad_*_kernel + wgrad_reduce_kernel (csrc/wgrad_nhwc.hip)"),
-              "bn": _roof(tot["bn"], reps, dtype, ovh, dtype + "_train_bn", "bn_apply / bn_bwd_reduce / bn_bwd_apply kernels (csrc/train_ops.hip)"),
-              "mvf": _roof(tot["mvf"], reps, dtype, ovh, dtype + "_train_mvf", "mvf_nhwc_apply (stencil and transposed stencil, csrc/mvf_nhwc.hip)")}
+    key = dtype + "_train"
+    conv_kernels = ("conv_igemm_* (conv_tile instantiations: lowk / glds / p4 / streamk, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct / pw_sums (the direct "
+                    "kernels of layer1's 3x3 + its data gradient, of the stem, and the sum-only passes of layer1's conv3)")
+    r = _roof(tot["igemm"], reps, dtype, ovh, key, conv_kernels, "conv")
+    # the family with and without the RECOMPUTE passes (conv3 run again instead of re-reading z3: bn3's apply, backward sums, backward
+    # apply as epilogues of a second / third / fourth pass).  Their bytes / flops are booked as algorithmic above because they replace
+    # BatchNorm passes that moved MORE bytes; `required` is the like-for-like family (one forward + one data gradient per conv).
+    r["required"] = _roof(tot["igemm_required"], reps, dtype, ovh, kernel="forward convs (incl. statistics-only first passes) + data gradients: one each per conv")
+    r["recompute"] = _roof(tot["igemm_recompute"], reps, dtype, ovh, kernel="conv3 second passes: fwd+bn (bn3 apply + residual + ReLU), bwd-sums, bwd-apply (z3-free blocks)")
+    groups = {"wgrad": _roof(tot["wgrad"], reps, dtype, ovh, key, "wgrad_*_kernel + wgrad_reduce_kernel (csrc/wgrad_nhwc.hip) [+ the fused BatchNorm-backward-apply + weight-gradient kernels, csrc/bnbwd_wgrad.hip, where the step uses them]", "wgrad"),
+              "bn": _roof(tot["bn"], reps, dtype, ovh, key, "bn_apply / bn_bwd_reduce / bn_bwd_apply kernels (csrc/train_ops.hip)", "bn"),
+              "mvf": _roof(tot["mvf"], reps, dtype, ovh, key, "mvf_nhwc_apply (stencil and transposed stencil, csrc/mvf_nhwc.hip)", "mvf")}
     for k, g in groups.items():
         r[k] = g
     # whole step against the fully fused floor: every conv input / output read / written exactly once, forward + two backward GEMMs
     from mvfnet_amd.arch import fused_activation_elems_per_image
     clips, t = imgs.shape[0], imgs.shape[1]
     floor = 3.0 * fused_activation_elems_per_image(eng_depth(eng), imgs.shape[-1]) * t * clips * esz
-    moved = sum(tot[k][2] for k in tot) / reps
+    moved = sum(tot[k][2] for k, _ in timers) / reps
+    counter, csrc = _pmc_traffic(key, "step_total")
     r["step"] = {"ms_per_step": round(ms_step, 3), "fused_floor_bytes": int(floor), "fused_floor_ms_at_peak": round(floor / PEAK_HBM_GBS / 1e6, 3),
                  "step_hbm_frac": round(floor / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                  "alg_bytes_of_timed_groups": int(moved), "alg_bytes_frac_of_peak": round(moved / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                 "counter_bytes": counter, "counter_bytes_over_fused_floor": (round(counter / floor, 3) if counter else None),
+                 "counter_hbm_frac": (round(counter / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if counter else None),
+                 "counter_source": ("STATIC, not measured in this run: " + csrc) if (counter and csrc) else None,
                  "note": "fused_floor = 3 x (conv-in + conv-out elements) x esz x frames (SURVEY 8d: 348 MB bf16 per R50 8-frame clip and pass); "
                          "alg_bytes_of_timed_groups = what the un-fused launches of the four groups move by their shapes"}
     return r
@@ -298,31 +315,44 @@ def eng_depth(eng):
     return eng.model.backbone.depth
 
 
+RECOMPUTE_TAGS = ("fwd+bn", "bwd-sums", "bwd-apply")     # launch tags (roofline_train) of the conv3 passes that recompute z3
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured ceiling)
 
 
-def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None, kernel=None):
+def _pmc_traffic(pmc_key, group):
+    """HBM bytes PER STEP of a kernel group from the PMC counters (profiles/pmc_traffic_per_step.json, written by tools/derive_traffic.py
+    from separate --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 FETCH correction).  STATIC: collected once per round on the
+    round's final kernels, not in this run."""
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic_per_step.json")
+    if not (pmc_key and os.path.exists(pmc)):
+        return None, None
+    try:
+        d = json.load(open(pmc)).get(pmc_key) or {}
+        return d.get("bytes_per_step", {}).get(group), d.get("source")
+    except Exception:
+        return None, None
+
+
+def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None, kernel=None, pmc_group=None):
     """One kernel group's roofline object.  Time = the GROSS sum of the HIP-event brackets (no overhead subtraction: rocprofv3's kernel
     durations agree with the gross figure, profiles/README.md); `event_pair_overhead_us` is printed for information only.
     fp32: the conv GEMMs are MFMA-bound (94 FLOP/B fused vs ~20 machine balance).  bf16: the same network is HBM-bound even when
     perfectly fused (188 FLOP/B vs ~310), so `frac` is algorithmic bytes/s over the HBM peak; both fractions
-    are always printed (`hbm_frac`, `mfma_frac`)."""
+    are always printed (`hbm_frac`, `mfma_frac`).  `traffic` (counter HBM bytes) is per LAUNCH like `alg_bytes_per_launch`;
+    `traffic_per_step` / `alg_bytes_per_step` are the same two figures per step and `traffic_over_algorithmic` their ratio."""
     ms, fl, by, n = tot
     ms = max(ms, 1e-6)
     n = max(n, 1)
     tflops = fl / (ms * 1e-3) / 1e12
     gbs = by / (ms * 1e-3) / 1e9
     peak = PEAK_TFLOPS[dtype]
-    traffic, source = None, None
-    pmc = os.path.join(REPO, "profiles", "pmc_conv_bytes_per_launch.json")
-    if pmc_key and os.path.exists(pmc):
-        try:
-            d = json.load(open(pmc))
-            traffic, source = d.get(pmc_key), d.get("source_" + pmc_key)
-        except Exception:
-            traffic = None
-    common = {"kernel": kernel, "traffic": traffic,
-              "traffic_source": ("STATIC, not measured in this run: " + source) if (traffic and source) else None,
+    per_step, source = _pmc_traffic(pmc_key, pmc_group)
+    launches = max(n // reps, 1)
+    alg_step = by / reps
+    common = {"kernel": kernel, "traffic": (round(per_step / launches) if per_step else None),
+              "traffic_per_step": per_step, "alg_bytes_per_step": round(alg_step),
+              "traffic_over_algorithmic": (round(per_step / alg_step, 3) if (per_step and alg_step) else None),
+              "traffic_source": ("STATIC, not measured in this run: " + source) if (per_step and source) else None,
               "alg_bytes_per_launch": round(by / n), "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
               "event_pair_overhead_us": round(event_overhead_ms * 1e3, 2), "flop_per_launch": round(fl / n),
               "ms_per_step": round(ms / reps, 3), "tflops": round(tflops, 2), "mfma_frac": round(tflops / peak, 4),
@@ -371,40 +401,71 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=None):
                 sd[k] = v
         return loss
 
-    clips = 4 if not train else 2
-    imgs = torch.from_numpy(synth.synth_clip_batch(clips, T_FRAMES, SIZE, SIZE, seed=7))
-    labels = torch.from_numpy(synth.synth_labels(clips))
-    best = None
-    # oneDNN with one thread per hardware thread (256 here) thrashes for minutes; 8-16 threads measured best on this host
-    cands = sorted(set(t for t in ((8, 16) if train else (8, 16, 32)) if t <= cores) or {cores})
-    for thr in cands:
-        torch.set_num_threads(thr)
-        sd, mom = make_sd("cpu"), {}
-        t0 = time.perf_counter()
-        one_step(sd, imgs, labels, mom)                # warm-up (also bounds a pathological setting)
-        if time.perf_counter() - t0 > seconds:
-            continue
-        t0 = time.perf_counter()
-        n = 0
-        while True:
-            one_step(sd, imgs, labels, mom)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > seconds / len(cands) or n >= 50:
+    def cpu_model():
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+        except Exception:
+            pass
+        return "unknown"
+
+    def median_rate(fn, clips_, budget):
+        """median of 5 after 2 warm-ups (fewer when the wall-clock budget runs out); -> (clips/s, timed runs)."""
+        t_start = time.perf_counter()
+        for _ in range(2):
+            fn()
+            if time.perf_counter() - t_start > budget:
                 break
-        rate = clips * n / el
-        if best is None or rate > best[0]:
-            best = (rate, thr, n, el)
+        ts = []
+        while len(ts) < 5 and (len(ts) < 3 or time.perf_counter() - t_start < budget):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return clips_ / ts[len(ts) // 2], len(ts)
+
+    # SURVEY 8(d): C1 exact (BASELINE configs[0]: R50 4x16, 2 clips of 224^2, forward), the C2 shape at N = 2 (R50 8x8 forward), and the
+    # metric's own step (C3 shape at N = 2: fwd+bwd+clip+SGD, fp32 -- the CPU has no bf16 path worth timing) -- every one at every candidate
+    # thread count.  torch.set_num_threads(os.cpu_count()) as the survey wrote it thrashes oneDNN for minutes on this 256-thread host
+    # (measured in round 1), so the candidates are 8 / 16 / 32 and the best per entry is reported with its thread count.
+    entries = {"C1 configs[0]: R50 4x16, 2 clips, 224^2, fp32 forward": dict(t=4, clips=2, train=False),
+               "C2 shape at N=2: R50 8x8, 2 clips, 224^2, fp32 forward": dict(t=8, clips=2, train=False),
+               "C3 shape at N=2: R50 8x8, 2 clips, 224^2, fp32 train step (fwd+bwd+clip+SGD)": dict(t=8, clips=2, train=True)}
+    if mode != "train":
+        entries.pop("C3 shape at N=2: R50 8x8, 2 clips, 224^2, fp32 train step (fwd+bwd+clip+SGD)")
+    cands = sorted(set(t for t in (8, 16, 32) if t <= cores) or {cores})
+    results = {k: None for k in entries}
+    per_entry_budget = seconds / max(len(entries) * len(cands), 1)
+    global T_FRAMES
+    t_keep = T_FRAMES
+    try:
+        for thr in cands:
+            torch.set_num_threads(thr)
+            for name, e in entries.items():
+                T_FRAMES = e["t"]
+                sd, mom = make_sd("cpu") if e["train"] else {k: torch.from_numpy(vals[pre + k]) for k in shp}, {}
+                imgs = torch.from_numpy(synth.synth_clip_batch(e["clips"], e["t"], SIZE, SIZE, seed=7))
+                labels = torch.from_numpy(synth.synth_labels(e["clips"]))
+                if e["train"]:
+                    fn = lambda: one_step(sd, imgs, labels, mom)                                   # noqa: E731
+                else:
+                    def fn():
+                        with torch.no_grad():
+                            return net_torch.forward_test(imgs, sd, depth, e["t"], None)
+                rate, n = median_rate(fn, e["clips"], per_entry_budget)
+                if results[name] is None or rate > results[name]["value"]:
+                    results[name] = {"value": round(rate, 2), "unit": "clips/s", "threads": thr, "timed_runs": n,
+                                     "ms_per_clip": round(1e3 / rate, 1)}
+    finally:
+        T_FRAMES = t_keep
     eager = eager_compare if isinstance(eager_compare, dict) else None
-    what = "fp32 train step (fwd+bwd+clip+SGD)" if train else "fp32 eval forward"
-    if best is None:
-        return {"value": None, "unit": "clips/s", "cores": cores, "kind": "port", "torch_eager_gpu": eager,
-                "sample": "no thread count finished in %.0f s" % seconds}
-    rate, thr, n, el = best
-    return {"value": round(rate, 2), "unit": "clips/s", "cores": thr, "kind": "port", "host_hw_threads": cores,
-            "torch_eager_gpu": eager,
-            "sample": "%d x %d clips of %dx3x%dx%d, %s, torch CPU (oneDNN) %d threads (best of %s), %.1f s" % (
-                n, clips, T_FRAMES, SIZE, SIZE, what, thr, cands, el)}
+    head_key = [k for k in entries if k.startswith("C3" if train else "C2")][0]
+    head = results[head_key]
+    return {"value": head["value"], "unit": "clips/s", "cores": head["threads"], "kind": "port", "host_hw_threads": cores, "cpu_model": cpu_model(),
+            "entries": results, "torch_eager_gpu": eager,
+            "sample": "%s; median of <= 5 runs after 2 warm-ups per entry and thread count, oracle/net_torch.py on torch CPU (oneDNN), best of %s threads "
+                      "(%d hardware threads on the host; all of them at once thrash oneDNN), %.0f s budget" % (head_key, cands, cores, seconds)}
 
 
 def eager_comparators(depth, clips, frames, size, seconds, engine_value, dtype):
@@ -434,6 +495,16 @@ def eager_comparators(depth, clips, frames, size, seconds, engine_value, dtype):
     f32 = out.get("f32")
     if isinstance(f32, dict) and f32.get("eager_clips_per_s"):
         res["engine_over_eager_fp32_reference_precision"] = round(engine_value / f32["eager_clips_per_s"], 2)
+    # HEADLINE ratio: against MIOpen's best (cudnn.benchmark=True: an exhaustive kernel search of 240 s for bf16, too long for a default bench
+    # run).  STATIC figures measured once on an MI355X of this pool (profiles/r03_eager_bf16_cudnn_benchmark.txt: 479.9 clips/s bf16; fp32 234 after a
+    # 3-25 minute search); the ratio uses the larger of that and this run's own eager number.
+    best_known = {"bf16": 479.92, "f32": 234.0}
+    if depth == 50 and clips == 32 and frames == 8 and size == 224 and dtype in best_known:
+        here = same.get("eager_clips_per_s") if isinstance(same, dict) else None
+        ref = max(best_known[dtype], here or 0.0)
+        res["headline_engine_over_eager_miopen_best"] = {"ratio": round(engine_value / ref, 2), "eager_clips_per_s": ref,
+                                                         "note": "eager with cudnn.benchmark=True, STATIC (measured offline, profiles/r03_eager_bf16_cudnn_benchmark.txt) unless this run's "
+                                                                 "benchmark=False number is higher; `engine_over_eager_same_dtype` is the in-run benchmark=False ratio"}
     return res
 
 
@@ -484,7 +555,8 @@ def other_configs(seconds):
     """BASELINE.json's other single-GPU configurations, each as a short run of THIS script in a child process (after the headline's timed
     region; same JSON contract, 5 timed steps): so that the driver's record carries them, not only the builder's notes."""
     import subprocess
-    runs = {"C2 configs[1]: R50 8x8, 32 clips, fp32, forward only": ["--mode", "infer", "--dtype", "f32"],
+    runs = {"C3 in fp32 (the reference's shipped training precision): R50 8x8, 32 clips, fp32 train step": ["--mode", "train", "--dtype", "f32"],
+            "C2 configs[1]: R50 8x8, 32 clips, fp32, forward only": ["--mode", "infer", "--dtype", "f32"],
             "C4 configs[3]: R101 16x4, 16 clips/GPU, bf16 train step": ["--mode", "train", "--dtype", "bf16", "--depth", "101", "--frames", "16", "--clips", "16"],
             "C5 configs[4]: R50 8x8, one video = 10 clips x 3 crops of 256^2, fcn_testing, fp32": ["--mode", "video", "--dtype", "f32"],
             "C5 in bf16": ["--mode", "video", "--dtype", "bf16"]}
@@ -651,6 +723,14 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args.depth, args.cpu_seconds, args.mode, args.clips, eager)
         if world == 1 and train and args.depth == 50 and T_FRAMES == 8 and args.clips == 32 and not args.no_other_configs:
             res["other_configs"] = other_configs(args.other_seconds)
+            # the fp32 engine against the eager fp32 comparator of THIS run (the reference's shipped precision, like for like)
+            try:
+                f32 = next(v for k, v in res["other_configs"].items() if k.startswith("C3 in fp32"))
+                eag = res["cpu_baseline"]["torch_eager_gpu"]["torch_eager_gpu_clips_per_s"]["f32"]
+                if isinstance(eag, (int, float)) and eag > 0 and "value" in f32:
+                    f32["engine_over_eager_fp32"] = round(f32["value"] / eag, 2)
+            except Exception:
+                pass
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -165,3 +165,128 @@ def test_exchanged_gradient_is_the_mean_of_the_oracles_per_rank_gradients(tmp_pa
     assert d_mean < 1.25 * max(d_local) + 1e-3 and d_mean < 4e-2, (d_mean, d_local)
     assert np.median(per) < 4e-2 and per.max() < 8e-2, (np.median(per), per.max())
     assert d_wrong > 10 * d_mean
+
+
+# ------------------------------------------------------------------------------------------------ [r4] the distributed ENTRY POINTS, executed
+class _Videos(torch.utils.data.Dataset):
+    """An odd number of tiny synthetic videos with the item layout the reference's datasets emit (img_group [T, 3, H, W], label [1])."""
+
+    def __init__(self, n=5, t=4, size=64):
+        from mvfnet_amd import synth
+        self.items = [dict(img_group=torch.from_numpy(synth.synth_clip_batch(1, t, size, size, seed=100 + i))[0],
+                           label=torch.from_numpy(synth.synth_labels(1, seed=100 + i))[0].reshape(1)) for i in range(n)]
+        self.video_infos = [dict(label=int(it["label"][0])) for it in self.items]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _synth_model():
+    import mvfnet_amd
+    from mvfnet_amd import synth
+    m = mvfnet_amd.build_recognizer(mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0), None, dict(average_clips="prob"))
+    sd = m.state_dict()
+    vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in sd}, strict=True)
+    return m
+
+
+def _worker_entry_points(rank, world, port, work_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import numpy as np
+    from mvfnet_amd.runner import Config, build_dataloader, multi_gpu_test, single_gpu_test, train_network
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = _Videos(5)
+    m = _synth_model()
+    if rank == 1:                         # rank 1 starts from DIFFERENT weights: the wrapper's broadcast must overwrite them (distributed.py:40-52)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.mul_(1.5)
+    cfg = Config(optimizer=dict(type="SGD", lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True),
+                 optimizer_config=dict(grad_clip=dict(max_norm=40, norm_type=2)),
+                 lr_config=dict(policy="step", step=[90, 130], warmup="linear", warmup_iters=4, warmup_ratio=0.1),
+                 checkpoint_config=dict(interval=1), log_config=dict(interval=1), total_epochs=2, work_dir=work_dir,
+                 data=dict(videos_per_gpu=1, workers_per_gpu=0), resume_from=None, load_from=None)
+    logs = []
+    run = train_network(m, ds, cfg, distributed=True, validate=False, logger=logs.append)       # reference train.py:159-212 (_dist_train)
+    torch.cuda.synchronize()
+    dist.barrier()
+    info = dict(epoch=run.epoch, iter=run.iter, logs=len(logs))
+    bits = run.engine.flat_params.view(torch.int32).to(torch.int64)
+    chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum()]).cpu()
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    info["replicas_equal"] = bool(torch.equal(allc[0], allc[1]))
+    # resume on BOTH ranks from rank 0's checkpoint, one more epoch
+    m2 = _synth_model()
+    cfg2 = Config(dict(cfg, resume_from=os.path.join(work_dir, "latest.pth"), total_epochs=3))
+    run2 = train_network(m2, ds, cfg2, distributed=True, logger=logs.append)
+    torch.cuda.synchronize()
+    bits = run2.engine.flat_params.view(torch.int32).to(torch.int64)
+    chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum()]).cpu()
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    info.update(epoch2=run2.epoch, iter2=run2.iter, replicas_equal2=bool(torch.equal(allc[0], allc[1])),
+                finite=bool(torch.isfinite(run2.engine.flat_params).all()))
+    # multi_gpu_test + collect_results on the odd-sized dataset (reference test.py:42-89, 147-185): rank 0's ordered rows == one process scoring all
+    loader = build_dataloader(ds, 1, 0, dist_mode=True, shuffle=False)
+    rows = multi_gpu_test(m2, loader, size=len(ds))
+    if rank == 0:
+        full = single_gpu_test(m2, build_dataloader(ds, 1, 0, dist_mode=False, shuffle=False))
+        info["rows"] = len(rows)
+        info["max_abs_diff"] = float(max(np.abs(np.asarray(a, dtype=np.float64).reshape(-1) - np.asarray(b, dtype=np.float64).reshape(-1)).max()
+                                         for a, b in zip(rows, full)))
+        info["argmax_equal"] = all(int(np.argmax(a)) == int(np.argmax(b)) for a, b in zip(rows, full))
+    else:
+        info["rows"] = rows
+    torch.save(info, os.path.join(work_dir, "info_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_dist_train_and_multi_gpu_test_entry_points_run_with_two_ranks(tmp_path):
+    """reference core/train.py:159-212 (`_dist_train`) and core/test.py:42-89 / 147-185, EXECUTED with two real ranks on one MI355X
+    (gloo carrying the CUDA tensors): train_network(distributed=True) for two epochs over an odd-sized dataset (DistributedSampler pads
+    5 videos to 3 per rank), the wrapper's broadcast overwrites rank 1's different start, replicas stay bit-identical, rank 0 writes the
+    checkpoints, both ranks resume from them for a third epoch; then multi_gpu_test + collect_results: rank 0 receives the 5 rows in
+    dataset order, equal to one process scoring all five."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_entry_points, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    i0, i1 = (torch.load(str(tmp_path / ("info_rank%d.pt" % r)), weights_only=False) for r in range(2))
+    assert i0["epoch"] == i1["epoch"] == 2 and i0["iter"] == i1["iter"] == 6          # ceil(5 / 2) = 3 iterations per epoch and rank
+    assert i0["logs"] > 0 and i1["logs"] == 0                                          # only rank 0 logs
+    assert i0["replicas_equal"] and i0["replicas_equal2"] and i0["finite"]
+    assert i0["epoch2"] == i1["epoch2"] == 3 and i0["iter2"] == i1["iter2"] == 9
+    assert os.path.exists(str(tmp_path / "epoch_3.pth")) and os.path.islink(str(tmp_path / "latest.pth"))
+    assert i1["rows"] is None and i0["rows"] == 5
+    assert i0["argmax_equal"] and i0["max_abs_diff"] < 1e-6                            # same weights, same kernels, per-video batches
+
+
+@pytest.mark.timeout(600)
+def test_bench_runs_its_rccl_path_with_one_rank():
+    """BENCH_FORCE_DIST=1: bench.py initialises the nccl (= RCCL) process group on this box, runs the two-bucket exchange with world = 1,
+    verifies its replicas and reports how much of the all-reduce is exposed -- so RCCL initialisation and the communication-stream
+    choreography execute wherever the GPU tests run."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "2", "--warmup", "1", "--clips", "8", "--no-cpu-baseline",
+                        "--no-other-configs", "--no-eager-compare"], capture_output=True, text=True, timeout=500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rep = d["replicas"]
+    assert rep["backend"] == "nccl" and rep["rccl_ranks"] == 1 and rep["params_bit_identical_across_ranks"]
+    assert rep["allreduce_ms"]["tail_bucket_overlapped_with_backward"] > 0 and d["value"] > 0
