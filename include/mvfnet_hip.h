@@ -263,6 +263,29 @@ int mvf_bn_bwd_pair(const void* g, int g_pitch, const void* z_a, const void* z_b
                     const float* gamma_a, const float* mean_a, const float* invstd_a, float* dgamma_a, float* dbeta_a,
                     const float* gamma_b, const float* mean_b, const float* invstd_b, float* dgamma_b, float* dbeta_b,
                     void* dz_a, void* dz_b, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* [r4] BatchNorm backward APPLY fused with the weight gradient of the pointwise (1x1, stride 1) conv that produced the BatchNorm's input
+ * (autograd of Bottleneck.forward, resnet.py:213-244: z = conv(x); out = relu(bn(z) [+ identity])): the pass that forms
+ * dz = gamma * invstd * (gm - dbeta / m - xhat * dgamma / m) also contracts it with the conv input, dW[co][ci] = sum_m dz[m][co] * x[m][ci],
+ * so dz is read once afterwards (by the data gradient) instead of twice.  dz is BIT-identical to mvf_bn_bwd_apply_masked; the weight gradient
+ * is left as `splits` fp32 partial slabs [splits][c][k] that mvf_wgrad_slab_reduce sums in fixed order into dw (c, k, 1, 1) -- on any stream
+ * that is ordered behind this call.  dgamma / dbeta must be final (mvf_bn_bwd_reduce / mvf_bn_bwd_finalize ran).  bf16 storage only; built for
+ * the byte-bound shapes whose c x k accumulator fits one workgroup: mask_mode 4 (sign bits) with c % 256 == 0 and k = 64 / 128, mask_mode 2
+ * (gate = scale * z + shift > 0) with c = 64 / 128 / 256 and k % 256 == 0; mvf_bn_bwd_wgrad_splits returns 0 for every other shape (use the
+ * separate calls).  nbn = 1 here, 2 for the paired form below. */
+int mvf_bn_bwd_wgrad_splits(long m, int c, int k, int nbn, int mask_mode);
+size_t mvf_bn_bwd_wgrad_slab_bytes(long m, int c, int k, int nbn, int mask_mode);
+int mvf_bn_bwd_apply_wgrad(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* gamma, const float* mean,
+                           const float* invstd, const float* scale, const float* shift, const float* dgamma, const float* dbeta, int mask_mode,
+                           void* dz, const void* x, int x_pitch, int k, float* slabs, size_t slab_bytes, int dtype, void* stream);
+/* [r4] The same for the PAIRED backward of a downsample block (mvf_bn_bwd_pair: sums of both BatchNorms, then both dz): dz_a / dz_b are
+ * contracted with x_a (conv3's input) / x_b (the downsample conv's input = the block input; stride 1 only).  x_b = NULL: only conv a's weight
+ * gradient is fused (k = 128; a stride-2 downsample conv keeps its GEMM).  ws: 2 x mvf_bn_workspace_bytes(m, c); slabs_*: slab_bytes each. */
+int mvf_bn_bwd_pair_wgrad(const void* g, int g_pitch, const void* z_a, const void* z_b, const unsigned char* sign_bits, long m, int c,
+                          const float* gamma_a, const float* mean_a, const float* invstd_a, float* dgamma_a, float* dbeta_a,
+                          const float* gamma_b, const float* mean_b, const float* invstd_b, float* dgamma_b, float* dbeta_b,
+                          void* dz_a, void* dz_b, const void* x_a, int xa_pitch, const void* x_b, int xb_pitch, int k,
+                          float* slabs_a, float* slabs_b, size_t slab_bytes, void* ws, size_t ws_bytes, int dtype, void* stream);
+int mvf_wgrad_slab_reduce(const float* slabs, int nsplit, int cout, int k, float* dw_oihw, void* stream);
 /* stem: y = maxpool3x3/2(relu(z*scale+shift)) (resnet.py:482-484).  argmax (optional, one byte per element of y) receives
  * the window position dy*3+dx of the first maximum; the backward routes g to it: ga = dL/d relu(bn(z)). */
 int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,

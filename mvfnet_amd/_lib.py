@@ -136,6 +136,17 @@ def _load():
     lib.mvf_conv2d_nhwc_fwd_mvf.argtypes = [cp, vp, vp, fp, fp, i32, i32, i32, vp, vp, sz, vp]
     lib.mvf_bn_bwd_pair.restype = i32
     lib.mvf_bn_bwd_pair.argtypes = [vp, i32, vp, vp, vp, i64, i32, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp, vp, vp, sz, i32, vp]
+    lib.mvf_bn_bwd_wgrad_splits.restype = i32
+    lib.mvf_bn_bwd_wgrad_splits.argtypes = [i64, i32, i32, i32, i32]
+    lib.mvf_bn_bwd_wgrad_slab_bytes.restype = sz
+    lib.mvf_bn_bwd_wgrad_slab_bytes.argtypes = [i64, i32, i32, i32, i32]
+    lib.mvf_bn_bwd_apply_wgrad.restype = i32
+    lib.mvf_bn_bwd_apply_wgrad.argtypes = [vp, i32, vp, vp, i64, i32, fp, fp, fp, fp, fp, fp, fp, i32, vp, vp, i32, i32, fp, sz, i32, vp]
+    lib.mvf_bn_bwd_pair_wgrad.restype = i32
+    lib.mvf_bn_bwd_pair_wgrad.argtypes = [vp, i32, vp, vp, vp, i64, i32, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp, vp, vp, i32, vp, i32, i32,
+                                          fp, fp, sz, vp, sz, i32, vp]
+    lib.mvf_wgrad_slab_reduce.restype = i32
+    lib.mvf_wgrad_slab_reduce.argtypes = [fp, i32, i32, i32, fp, vp]
     lib.mvf_ce_loss.restype = i32
     lib.mvf_ce_loss.argtypes = [fp, ll, i32, i32, fp, fp, fp, vp]
     lib.mvf_head_train_bwd.restype = i32

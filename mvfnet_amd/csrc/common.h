@@ -120,6 +120,25 @@ struct PwSumsArgs {
     int rows, mode, M, N, K, xps;
 };
 namespace mvf_internal {
+// BatchNorm backward apply fused with the pointwise conv's weight gradient (bnbwd_wgrad.hip); index 0 / 1 = the one or two BatchNorms
+// (1 = the downsample branch of a paired backward) that share g and the sign bits
+struct BnBwdWgradArgs {
+    const void* g;              // (M, g_pitch >= C) bf16 gradient of the BatchNorm output(s) before the ReLU gate
+    const void* z[2];           // (M, C) bf16 BatchNorm inputs = conv outputs
+    const void* bits;           // mask mode 4: sign bits of the block output, (M, C / 4) bytes
+    const float *gamma[2], *mean[2], *invstd[2], *dgamma[2], *dbeta[2];
+    const float *scale, *shift; // mask mode 2: folded coefficients of BatchNorm 0 (gate = scale * z + shift > 0)
+    void* dz[2];                // (M, C) bf16 out
+    const void* x[2];           // (M, xps >= K) bf16 conv inputs, channels [0, K); x[1] may be NULL (that conv is not contracted here)
+    int xps[2];
+    float* part[2];             // partial slabs [nsplit][C][K] fp32
+    int g_pitch, M, C, K;
+    int rows_per_split, nsplit, ctiles, ktiles;
+};
+bool bnbwd_wgrad_tile(int c, int k, int nbn, int mask_mode, int* ct, int* kt);
+int bnbwd_wgrad_plan(long m, int c, int k, int nbn, int mask_mode, int* rows_per_split, int* ctiles, int* ktiles);
+int bnbwd_wgrad_launch(const BnBwdWgradArgs& a, int nbn, int mask_mode, hipStream_t st);
+int wgrad_slab_reduce_launch(const float* part, int nsplit, int cout, int k, float* dw_oihw, hipStream_t st);
 int stem_direct_launch(const StemDirectArgs& a, hipStream_t st);
 int conv3x3_c64_launch(const Conv3x3C64Args& a, hipStream_t st);
 int pw_sums_launch(const PwSumsArgs& a, hipStream_t st);

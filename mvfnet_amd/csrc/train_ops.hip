@@ -1539,6 +1539,89 @@ int mvf_bn_bwd_pair(const void* g, int g_pitch, const void* z_a, const void* z_b
     return MVF_OK;
 }
 
+// ---- BatchNorm backward apply fused with the pointwise conv's weight gradient (csrc/bnbwd_wgrad.hip) ----
+int mvf_bn_bwd_wgrad_splits(long m, int c, int k, int nbn, int mask_mode) {
+    int rows, ct, kt;
+    if (m <= 0 || c <= 0 || k <= 0 || m * (long)std::max(c, k) * 2 >= 0x7ffffff0L) return 0;
+    return mvf_internal::bnbwd_wgrad_plan(m, c, k, nbn, mask_mode, &rows, &ct, &kt);
+}
+
+size_t mvf_bn_bwd_wgrad_slab_bytes(long m, int c, int k, int nbn, int mask_mode) {
+    return align_up((size_t)mvf_bn_bwd_wgrad_splits(m, c, k, nbn, mask_mode) * c * k * sizeof(float), 256);
+}
+
+static int bnwg_fill(mvf_internal::BnBwdWgradArgs& a, long m, int c, int k, int nbn, int mask_mode, size_t slab_bytes) {
+    a.M = (int)m; a.C = c; a.K = k;
+    a.nsplit = mvf_internal::bnbwd_wgrad_plan(m, c, k, nbn, mask_mode, &a.rows_per_split, &a.ctiles, &a.ktiles);
+    MVF_REQUIRE(a.nsplit > 0, MVF_EUNSUPPORTED, "bn backward + weight gradient: shape c=%d k=%d (BatchNorms %d, mask mode %d) is not built; use the separate calls", c, k, nbn, mask_mode);
+    MVF_REQUIRE(slab_bytes >= (size_t)a.nsplit * c * k * sizeof(float), MVF_EWS, "bn backward + weight gradient: slab buffer too small (mvf_bn_bwd_wgrad_slab_bytes)");
+    return MVF_OK;
+}
+
+int mvf_bn_bwd_apply_wgrad(const void* g, int g_pitch, const void* z, const void* ymask, long m, int c, const float* gamma, const float* mean,
+                           const float* invstd, const float* scale, const float* shift, const float* dgamma, const float* dbeta, int mask_mode,
+                           void* dz, const void* x, int x_pitch, int k, float* slabs, size_t slab_bytes, int dtype, void* stream) {
+    MVF_REQUIRE(g && z && gamma && mean && invstd && dgamma && dbeta && dz && x && slabs && m > 0 && c > 0 && k > 0 && g_pitch >= c && x_pitch >= k,
+                MVF_EINVAL, "bn_bwd_apply_wgrad: bad argument");
+    MVF_REQUIRE(dtype == MVF_BF16, MVF_EUNSUPPORTED, "bn_bwd_apply_wgrad: bf16 storage only");
+    MVF_REQUIRE(mask_mode == 2 || mask_mode == 4, MVF_EUNSUPPORTED, "bn_bwd_apply_wgrad: mask mode 2 (scale * z + shift > 0) or 4 (sign bits)");
+    MVF_REQUIRE(mask_mode == 2 ? (scale && shift) : (ymask != nullptr), MVF_EINVAL, "bn_bwd_apply_wgrad: the mask operand of mode %d is missing", mask_mode);
+    MVF_REQUIRE(g_pitch % 8 == 0 && x_pitch % 8 == 0 && al16(g) && al16(z) && al16(dz) && al16(x) && ((uintptr_t)ymask & 1) == 0 &&
+                    m * (long)std::max(g_pitch, x_pitch) * 2 < 0x7ffffff0L, MVF_ESHAPE, "bn_bwd_apply_wgrad: alignment / 2 GB addressing");
+    mvf_internal::BnBwdWgradArgs a = {};
+    if (int rc = bnwg_fill(a, m, c, k, 1, mask_mode, slab_bytes)) return rc;
+    a.g = g; a.g_pitch = g_pitch; a.z[0] = z; a.bits = ymask;
+    a.gamma[0] = gamma; a.mean[0] = mean; a.invstd[0] = invstd; a.dgamma[0] = dgamma; a.dbeta[0] = dbeta;
+    a.scale = scale; a.shift = shift;
+    a.dz[0] = dz; a.x[0] = x; a.xps[0] = x_pitch; a.part[0] = slabs;
+    return mvf_internal::bnbwd_wgrad_launch(a, 1, mask_mode, (hipStream_t)stream);
+}
+
+int mvf_bn_bwd_pair_wgrad(const void* g, int g_pitch, const void* z_a, const void* z_b, const unsigned char* sign_bits, long m, int c,
+                          const float* gamma_a, const float* mean_a, const float* invstd_a, float* dgamma_a, float* dbeta_a,
+                          const float* gamma_b, const float* mean_b, const float* invstd_b, float* dgamma_b, float* dbeta_b,
+                          void* dz_a, void* dz_b, const void* x_a, int xa_pitch, const void* x_b, int xb_pitch, int k,
+                          float* slabs_a, float* slabs_b, size_t slab_bytes, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    MVF_REQUIRE(g && z_a && z_b && sign_bits && gamma_a && mean_a && invstd_a && dgamma_a && dbeta_a && gamma_b && mean_b && invstd_b && dgamma_b && dbeta_b &&
+                    dz_a && dz_b && x_a && slabs_a && (!x_b || slabs_b) && m > 0 && c > 0 && k > 0 && g_pitch >= c && xa_pitch >= k && (!x_b || xb_pitch >= k),
+                MVF_EINVAL, "bn_bwd_pair_wgrad: bad argument");
+    MVF_REQUIRE(dtype == MVF_BF16, MVF_EUNSUPPORTED, "bn_bwd_pair_wgrad: bf16 storage only");
+    MVF_REQUIRE(ws && ws_bytes >= 2 * mvf_bn_workspace_bytes(m, c), MVF_EWS, "bn_bwd_pair_wgrad: workspace too small (2 x mvf_bn_workspace_bytes)");
+    MVF_REQUIRE(g_pitch % 8 == 0 && xa_pitch % 8 == 0 && (!x_b || xb_pitch % 8 == 0) && al16(g) && al16(z_a) && al16(z_b) && al16(dz_a) && al16(dz_b) &&
+                    al16(x_a) && (!x_b || al16(x_b)) && ((uintptr_t)sign_bits & 1) == 0 &&
+                    m * (long)std::max(g_pitch, std::max(xa_pitch, x_b ? xb_pitch : 0)) * 2 < 0x7ffffff0L, MVF_ESHAPE, "bn_bwd_pair_wgrad: alignment / 2 GB addressing");
+    mvf_internal::BnBwdWgradArgs a = {};
+    if (int rc = bnwg_fill(a, m, c, k, 2, 4, slab_bytes)) return rc;
+    MVF_REQUIRE(x_b || a.ktiles == 1, MVF_EUNSUPPORTED, "bn_bwd_pair_wgrad: k tiles");
+    int kt_, ct_;
+    MVF_REQUIRE(mvf_internal::bnbwd_wgrad_tile(c, k, 2, 4, &ct_, &kt_) && (!x_b || kt_ == 64), MVF_EUNSUPPORTED,
+                "bn_bwd_pair_wgrad: both convs are contracted for k = 64 only (k = 128: pass x_b = NULL)");
+    hipStream_t st = (hipStream_t)stream;
+    float* part_a = (float*)ws;
+    float* part_b = (float*)((char*)ws + mvf_bn_workspace_bytes(m, c));
+    {   // the sums: exactly mvf_bn_bwd_pair's reduce + finalize
+        const bool wide = false;
+        const int gy = col_plan(m, c, 4).gy;
+        MVF_BN_DISPATCH(bn_bwd_reduce2_kernel, wide, 2048, (const ET*)g, g_pitch, (const ET*)z_a, (const ET*)z_b, (const void*)sign_bits, m, c, mean_a, invstd_a,
+                        mean_b, invstd_b, p.cqb, p.rows, part_a, part_b);
+        MVF_LAUNCH_CHECK();
+        const int gA = (c + kFinCh - 1) / kFinCh;
+        hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(2 * gA), dim3(256), 0, st, c, gy, part_a, part_b, dgamma_a, dbeta_a, dgamma_b, dbeta_b);
+        MVF_LAUNCH_CHECK();
+    }
+    a.g = g; a.g_pitch = g_pitch; a.z[0] = z_a; a.z[1] = z_b; a.bits = sign_bits;
+    a.gamma[0] = gamma_a; a.mean[0] = mean_a; a.invstd[0] = invstd_a; a.dgamma[0] = dgamma_a; a.dbeta[0] = dbeta_a;
+    a.gamma[1] = gamma_b; a.mean[1] = mean_b; a.invstd[1] = invstd_b; a.dgamma[1] = dgamma_b; a.dbeta[1] = dbeta_b;
+    a.dz[0] = dz_a; a.dz[1] = dz_b; a.x[0] = x_a; a.x[1] = x_b; a.xps[0] = xa_pitch; a.xps[1] = xb_pitch;
+    a.part[0] = slabs_a; a.part[1] = slabs_b;
+    return mvf_internal::bnbwd_wgrad_launch(a, 2, 4, st);
+}
+
+int mvf_wgrad_slab_reduce(const float* slabs, int nsplit, int cout, int k, float* dw_oihw, void* stream) {
+    MVF_REQUIRE(slabs && dw_oihw && nsplit > 0 && cout > 0 && k > 0, MVF_EINVAL, "wgrad_slab_reduce: bad argument");
+    return mvf_internal::wgrad_slab_reduce_launch(slabs, nsplit, cout, k, dw_oihw, (hipStream_t)stream);
+}
+
 int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const float* scale, const float* shift, void* y,
                             unsigned char* argmax, int dtype, void* stream) {
     MVF_REQUIRE(z && y && scale && shift && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool_bn_relu_fwd: bad argument");

@@ -913,6 +913,17 @@ WgTile pick_tile(int cout, int K) {
 
 }  // namespace
 
+namespace mvf_internal {
+// the fixed-order sum of [nsplit][cout][k] fp32 partial slabs of a pointwise conv's weight gradient into dw (cout, k, 1, 1): the tail of
+// mvf_conv2d_nhwc_wgrad, also behind the fused BatchNorm-backward + weight-gradient kernels (bnbwd_wgrad.hip)
+int wgrad_slab_reduce_launch(const float* part, int nsplit, int cout, int k, float* dw_oihw, hipStream_t st) {
+    const long total = (long)cout * k;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, part, nsplit, cout, k, 1, 1, 1, k, dw_oihw);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+}  // namespace mvf_internal
+
 extern "C" {
 
 // the 256 x 256 eight-wave tile (bf16, LDS-DMA): shape eligibility (pointer alignment is checked at launch) and its pixel split --

@@ -447,7 +447,10 @@ def single_gpu_test(model, loader):
     results = []
     with torch.no_grad():
         for data in loader:
-            results.append(model(return_loss=False, img_group=data["img_group"]))
+            img = data["img_group"]
+            if not img.is_cuda:          # a DataLoader's host batch: the reference's MMDataParallel scatters it to the device (test.py:24-27)
+                img = img.cuda(non_blocking=True)
+            results.append(model(return_loss=False, img_group=img))
     return results
 
 

@@ -232,7 +232,12 @@ def _worker_entry_points(rank, world, port, work_dir):
     dist.all_gather(allc, chk)
     info.update(epoch2=run2.epoch, iter2=run2.iter, replicas_equal2=bool(torch.equal(allc[0], allc[1])),
                 finite=bool(torch.isfinite(run2.engine.flat_params).all()))
-    # multi_gpu_test + collect_results on the odd-sized dataset (reference test.py:42-89, 147-185): rank 0's ordered rows == one process scoring all
+    # multi_gpu_test + collect_results on the odd-sized dataset (reference test.py:42-89, 147-185): rank 0's ordered rows == one process scoring all.
+    # As test_recognizer.py does, every rank first loads rank 0's checkpoint: BatchNorm running statistics are per rank during training (no
+    # SyncBN in the reference either), only the parameters are kept identical by the gradient exchange.
+    from mvfnet_amd.checkpoint import load_checkpoint
+    dist.barrier()
+    load_checkpoint(m2, os.path.join(work_dir, "epoch_3.pth"), map_location="cpu", strict=True)
     loader = build_dataloader(ds, 1, 0, dist_mode=True, shuffle=False)
     rows = multi_gpu_test(m2, loader, size=len(ds))
     if rank == 0:

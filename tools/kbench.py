@@ -118,8 +118,75 @@ def bench_bn(dt=1):
             del z, r, g, out, dz, bits
 
 
+def bench_bnwg():
+    """[r4] BatchNorm backward apply + weight gradient in one pass (mvf_bn_bwd_apply_wgrad / mvf_bn_bwd_pair_wgrad) against the two kernels it
+    replaces (mvf_bn_bwd_apply_masked / mvf_bn_bwd_pair + mvf_conv2d_nhwc_wgrad), each alone on the stream, at the C3 shapes of layer1 / layer2."""
+    from mvfnet_amd._lib import ConvDesc
+    dev, bf = "cuda", torch.bfloat16
+    # (name, pixels, c = channels of dz, k = conv input channels, mask mode, BatchNorms, both convs fused)
+    shapes = [("l1.c3 (plain)", 256 * 56 * 56, 256, 64, 4, 1, True), ("l1.0 c3 + downsample (pair)", 256 * 56 * 56, 256, 64, 4, 2, True),
+              ("l2.c3 (plain)", 256 * 28 * 28, 512, 128, 4, 1, True), ("l2.0 c3 (pair, downsample apart)", 256 * 28 * 28, 512, 128, 4, 2, False),
+              ("l1.c1 (x 256 wide)", 256 * 56 * 56, 64, 256, 2, 1, True), ("l2.c1 (x 512 wide)", 256 * 28 * 28, 128, 512, 2, 1, True),
+              ("l2.0 c1 (x 256 wide)", 256 * 56 * 56, 128, 256, 2, 1, True)]
+    for name, m, c, k, mode, nbn, both in shapes:
+        g = torch.randn(m, c, device=dev).to(bf)
+        z = [(torch.randn(m, c, device=dev) * 1.3).to(bf) for _ in range(nbn)]
+        x = [torch.randn(m, k, device=dev).to(bf) for _ in range(nbn)]
+        bits = torch.randint(0, 16, (m, c // 4), device=dev, dtype=torch.uint8)
+        par = [[(torch.rand(c, device=dev) + 0.5) for _ in range(7)] for _ in range(nbn)]      # gamma mean invstd scale shift dgamma dbeta
+        dz = [torch.empty(m, c, device=dev, dtype=bf) for _ in range(nbn)]
+        ws = torch.empty(2 * lib.mvf_bn_workspace_bytes(m, c), dtype=torch.uint8, device=dev)
+        d = ConvDesc(1, m, 1, k, c, 1, 1, 1, 0, m, 1, k, 1, 0, 0, 0, 0, 0)
+        wsz = lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d))
+        wws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+        dw = [torch.empty(c, k, device=dev) for _ in range(nbn)]
+        ns = lib.mvf_bn_bwd_wgrad_splits(m, c, k, nbn, mode)
+        nb = lib.mvf_bn_bwd_wgrad_slab_bytes(m, c, k, nbn, mode)
+        slabs = [torch.empty(nb // 4, device=dev) for _ in range(nbn)]
+        ym = bits if mode == 4 else None
+
+        def apply_only():
+            if nbn == 1:
+                p = par[0]
+                check(lib.mvf_bn_bwd_apply_masked(P(g), c, P(z[0]), P(ym), m, c, P(p[0]), P(p[1]), P(p[2]), P(p[3]), P(p[4]), P(p[5]), P(p[6]), mode, P(dz[0]), 1, None))
+            else:
+                a, b = par
+                check(lib.mvf_bn_bwd_pair(P(g), c, P(z[0]), P(z[1]), P(bits), m, c, P(a[0]), P(a[1]), P(a[2]), P(a[5]), P(a[6]), P(b[0]), P(b[1]), P(b[2]), P(b[5]), P(b[6]),
+                                          P(dz[0]), P(dz[1]), P(ws), ws.numel(), 1, None))
+
+        def wgrads():
+            for i in range(nbn if both else 1):
+                check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), P(dz[i]), P(x[i]), None, 1, k, 1, k, P(dw[i]), P(wws), wsz, None))
+
+        def fused():
+            if nbn == 1:
+                p = par[0]
+                check(lib.mvf_bn_bwd_apply_wgrad(P(g), c, P(z[0]), P(ym), m, c, P(p[0]), P(p[1]), P(p[2]), P(p[3]), P(p[4]), P(p[5]), P(p[6]), mode, P(dz[0]),
+                                                 P(x[0]), k, k, P(slabs[0]), nb, 1, None))
+            else:
+                a, b = par
+                check(lib.mvf_bn_bwd_pair_wgrad(P(g), c, P(z[0]), P(z[1]), P(bits), m, c, P(a[0]), P(a[1]), P(a[2]), P(a[5]), P(a[6]), P(b[0]), P(b[1]), P(b[2]), P(b[5]), P(b[6]),
+                                                P(dz[0]), P(dz[1]), P(x[0]), k, P(x[1]) if both else None, k, k, P(slabs[0]), P(slabs[1]) if both else None, nb,
+                                                P(ws), ws.numel(), 1, None))
+
+        def reduces():
+            for i in range(nbn if both else 1):
+                check(lib.mvf_wgrad_slab_reduce(P(slabs[i]), ns, c, k, P(dw[i]), None))
+
+        ta, tw, tf, tr = timeit(apply_only), timeit(wgrads), timeit(fused), timeit(reduces)
+        nx = nbn if both else 1
+        by_f = 2 * m * c * (1 + 2 * nbn) + (m * c // 4 if mode == 4 else 0) + 2 * m * k * nx        # g + z + dz (+ bits) + x
+        if nbn == 2:
+            by_f += 2 * m * c * 3 + m * c // 4                                                     # the pair's reduce pass: g, z_a, z_b, bits
+        print("%-36s M %7d c %4d k %4d  apply %6.1f + wgrad %6.1f = %6.1f us | fused %6.1f + slab reduce %5.1f us (%d splits)  %5.2f TB/s  saves %6.1f us" % (
+            name, m, c, k, ta, tw, ta + tw, tf, tr, ns, by_f / tf / 1e6, ta + tw - tf - tr))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "bn"
+    if what == "bnwg":
+        bench_bnwg()
+        sys.exit(0)
     if what == "bn":
         bench_bn(1)
     elif what == "conv":
