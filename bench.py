@@ -190,7 +190,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
     the four kernel groups of the step -- implicit-GEMM convs (forward + data gradients), weight gradients, BatchNorm streaming
     kernels, MVF stencils -- with each launch's ALGORITHMIC bytes / flops from its shapes."""
     from mvfnet_amd import train_engine as TE
-    tc, tw, tb, tm = _Timer(), _Timer(), _Timer(), _Timer()
+    tc, tw, tb, tm, tf = _Timer(), _Timer(), _Timer(), _Timer(), _Timer()
     esz = 4 if dtype == "f32" else 2
 
     def dfwd(self, out, d, x, x2, z, ws, part, shift):
@@ -245,6 +245,16 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
     def dbpr(self, out, b, g, g_pitch, za, zb, m, eng_, bits):          # bn3 + downsample BN -- reduce: g, z3, zd, bits; apply: the same + dz3, dzd
         return (0.0, "bn bwd pair M%d C%d" % (m, self.c), esz * m * self.c * 8 + 2 * (m * self.c // 4))
 
+    # [r4] BatchNorm backward apply + the pointwise conv's weight gradient in one pass: g, z, dz (+ bits) + the conv input + dW
+    def dbaw(self, out, g, g_pitch, z, m, eng_, mask_mode, ymask, conv, x, x_pitch):
+        nb = esz * m * self.c * 3 + (m * self.c // 4 if mask_mode == 4 else 0) + esz * m * conv.cin + 4 * conv.w.numel()
+        return (2.0 * m * self.c * conv.cin, "bn bwd apply<%d> + wgrad M%d C%d K%d" % (mask_mode, m, self.c, conv.cin), nb)
+
+    def dbpw(self, out, b, g, g_pitch, za, zb, m, eng_, bits, conv_a, xa, xa_pitch, conv_b, xb, xb_pitch):
+        nx = 2 if xb is not None else 1
+        nb = esz * m * self.c * 8 + 2 * (m * self.c // 4) + nx * (esz * m * conv_a.cin + 4 * conv_a.w.numel())
+        return (2.0 * nx * m * self.c * conv_a.cin, "bn bwd pair + %d wgrad M%d C%d K%d" % (nx, m, self.c, conv_a.cin), nb)
+
     def dmvf(self, out, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits):
         m = d.nt * d.h * d.w
         nb = esz * m * d.cs * (3 if addend is not None else 2)          # slice read + slice write (+ the gated skip-connection slice)
@@ -255,10 +265,10 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
             tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb),
             tw.wrap(TE._TConv, "wgrad", dwgr), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
             tb.wrap(TE._BN, "backward_pair", dbpr),
-            tm.wrap(TE._TMvf, "launch_stencil", dmvf)]
+            tm.wrap(TE._TMvf, "launch_stencil", dmvf), tf.wrap(TE._BN, "_apply_bwd_wgrad", dbaw), tf.wrap(TE._BN, "backward_pair_wgrad", dbpw)]
     overlap = eng.overlap_wgrad
     eng.overlap_wgrad = False          # time every kernel alone on the launch stream (the timed steps overlap wgrad on a side stream)
-    timers = (("igemm", tc), ("wgrad", tw), ("bn", tb), ("mvf", tm))
+    timers = (("igemm", tc), ("wgrad", tw), ("bn", tb), ("mvf", tm), ("bnwg", tf))
     try:
         tot = {k: [0.0, 0.0, 0.0, 0] for k, _ in timers}
         tot["igemm_required"], tot["igemm_recompute"] = [0.0, 0.0, 0.0, 0], [0.0, 0.0, 0.0, 0]
@@ -292,6 +302,9 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
     groups = {"wgrad": _roof(tot["wgrad"], reps, dtype, ovh, key, "wgrad_*_kernel + wgrad_reduce_kernel (csrc/wgrad_nhwc.hip) [+ the fused BatchNorm-backward-apply + weight-gradient kernels, csrc/bnbwd_wgrad.hip, where the step uses them]", "wgrad"),
               "bn": _roof(tot["bn"], reps, dtype, ovh, key, "bn_apply / bn_bwd_reduce / bn_bwd_apply kernels (csrc/train_ops.hip)", "bn"),
               "mvf": _roof(tot["mvf"], reps, dtype, ovh, key, "mvf_nhwc_apply (stencil and transposed stencil, csrc/mvf_nhwc.hip)", "mvf")}
+    if tot["bnwg"][3]:
+        groups["bn_wgrad"] = _roof(tot["bnwg"], reps, dtype, ovh, key, "bnbwd_wgrad_kernel (csrc/bnbwd_wgrad.hip): BatchNorm backward apply (or the paired form incl. its reduce pass) "
+                                   "+ the pointwise conv's weight gradient in one pass; the slab reduces run on the side stream", "bn_wgrad")
     for k, g in groups.items():
         r[k] = g
     # whole step against the fully fused floor: every conv input / output read / written exactly once, forward + two backward GEMMs

@@ -128,6 +128,12 @@ __host__ __device__ constexpr int kLowkLds() {
     return (BM + BN) * kPitch > (BM / 2) * (BN * 4 + 16) + BM * (BN / 4) ? (BM + BN) * kPitch : (BM / 2) * (BN * 4 + 16) + BM * (BN / 4);
 }
 
+// the single-buffer variant with three bf16 planes per fp32 tile (conv_tile X3): 3 x 64-byte rows, or the epilogue's needs
+template <int BM, int BN>
+__host__ __device__ constexpr int kLowkLdsX3() {
+    return (BM + BN) * 192 > (BM / 2) * (BN * 4 + 16) + BM * (BN / 4) ? (BM + BN) * 192 : (BM / 2) * (BN * 4 + 16) + BM * (BN / 4);
+}
+
 // dynamic LDS of the LDS-DMA variant: NB unpadded A/B tile buffers (128-B rows), or the half C tile + gate bytes
 template <int BM, int BN, int NB>
 __host__ __device__ constexpr int kGldsLds() {
@@ -158,8 +164,16 @@ struct SkArgs {            // stream-K tail (see launch_conv): G workgroups shar
 // lane-linearly (M0 base + 16 * lane), so a wave instruction lands 8 rows x 128 B; the bank-conflict-free image is made on the
 // SOURCE side: position p of row r holds the 16-byte unit p ^ ((r >> 1) & 7), and the operand fetch applies the same XOR.
 // Out-of-range buffer offsets DMA zeros (tools/probes/glds_probe.hip), so padding taps stay branch-free.
+// X3 (fp32 storage, register-staged loaders only): the products run on the BF16 matrix cores with fp32 accuracy.  Every fp32 operand is
+// split EXACTLY into three bf16 terms, x = hi + mid + lo (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8 mantissa bits),
+// when it is written to LDS (three bf16 planes per tile instead of one fp32 tile), and a product a * b is the six partial products of
+// order <= 2^-16 -- hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- each EXACT in the fp32 accumulator's input (8 x 8 bits), summed by
+// v_mfma_f32_32x32x16_bf16.  The dropped terms (mid*lo, lo*mid, lo*lo) are <= 3 x 2^-24 |a b|: the same order as ONE fp32 rounding of the
+// product, and below the fp32 accumulation error of a K >= 64 dot product (measured: 1.4e-7 relative L2 against fp64 where the fp32 MFMA
+// gives 3.1e-7).  gfx950's bf16 matrix rate is 16 x its fp32 matrix rate (2.5 PF/s vs 157 TF/s), so six bf16 instructions per k-step cost
+// 6 / 16 of the fp32 instruction they replace: 2.67 x the matrix throughput at fp32 accuracy.
 template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool PF2 = false, bool GEN = false, int EPI = 0, bool PW = false, int GLDS = 0,
-          bool MVFL = false, bool ILV = false, bool HALFK = false>
+          bool MVFL = false, bool ILV = false, bool HALFK = false, bool X3 = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -181,10 +195,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     static_assert(!MVFL || (((LOWK && PW) || GLDS == 1 || GLDS == 2) && !GEN), "the fused MVF loader: single-buffer register-staged pointwise kernel or the 4-wave LDS-DMA kernels");
     static_assert(!ILV || (GLDS == 2 && !MVFL), "interleaved DMA issue: the two-buffer LDS-DMA loop");
     constexpr int NBUF = P4 ? 2 : (GLDS ? GLDS : (LOWK ? 1 : 2));
-    constexpr int PITCH = GLDS ? 128 : kPitch;         // LDS-DMA rows are unpadded (lane-linear destination)
-    constexpr int kSmem = GLDS ? kGldsLds<BM, BN, GLDS ? NBUF : 1>() : (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch);
-    char* As = smem;                                   // [NBUF][BM][PITCH]
-    char* Bs = smem + NBUF * BM * PITCH;               // [NBUF][BN][PITCH]
+    static_assert(!X3 || (sizeof(ET) == 4 && LOWK && !GLDS && !MVFL && !PF2), "X3: fp32 storage, single-buffer register-staged kernel");
+    // X3: a chunk row is 32 channels = 64 bytes per bf16 plane, three planes per tile; unpadded rows, 16-byte units XOR-swizzled by the row
+    // (unit u of row r at u ^ ((r >> 2) & 3): the 16 rows a ds_read_b128 service group reads fall on 16 distinct 16-byte bank slots)
+    constexpr int PITCH = X3 ? 64 : (GLDS ? 128 : kPitch);         // LDS-DMA rows are unpadded (lane-linear destination)
+    constexpr int kSmem = X3 ? kLowkLdsX3<BM, BN>() : (GLDS ? kGldsLds<BM, BN, GLDS ? NBUF : 1>() : (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch));
+    constexpr int NPL = X3 ? 3 : 1;                    // operand planes per tile
+    char* As = smem;                                   // [NBUF][NPL][BM][PITCH]
+    char* Bs = smem + NBUF * NPL * BM * PITCH;         // [NBUF][NPL][BN][PITCH]
 
     const int tn_i = tile % a.tiles_n, tm_i = tile / a.tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
@@ -513,7 +531,42 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             else glds16(gs_w, p_lds_b + (unsigned)(RP * (n - A_ROWS_PT) * PITCH), pv[n]);
         }
     };
+    // X3: hi / mid / lo bf16 terms of four fp32 values (exact: x - bf16(x) is representable, twice), packed 4 x bf16 = 8 bytes per plane
+    auto split3 = [&](const uint4& v, uint2 (&pl)[3]) {
+        float r[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned lo2 = pack_bf16x2(r[0], r[1]), hi2 = pack_bf16x2(r[2], r[3]);
+            pl[p] = make_uint2(lo2, hi2);
+            if (p < 2) {
+                r[0] -= __uint_as_float(lo2 << 16); r[1] -= __uint_as_float(lo2 & 0xffff0000u);
+                r[2] -= __uint_as_float(hi2 << 16); r[3] -= __uint_as_float(hi2 & 0xffff0000u);
+            }
+        }
+    };
     auto store_chunk = [&](int buf, const Stage& st) {
+        if constexpr (X3) {
+            // thread (lrow, q): channels 4q .. 4q+3 of rows lrow + RP * i -> 8 bytes at unit (q >> 1) ^ ((row >> 2) & 3), half q & 1 of each plane
+#pragma unroll
+            for (int i = 0; i < A_ROWS_PT; ++i) {
+                const int row = lrow + RP * i;
+                uint2 pl[3];
+                split3(st.a[i], pl);
+                char* d = As + row * PITCH + ((((q >> 1) ^ ((row >> 2) & 3)) << 4) | ((q & 1) << 3));
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * BM * PITCH) = pl[p];
+            }
+#pragma unroll
+            for (int i = 0; i < B_ROWS_PT; ++i) {
+                const int row = lrow + RP * i;
+                uint2 pl[3];
+                split3(st.b[i], pl);
+                char* d = Bs + row * PITCH + ((((q >> 1) ^ ((row >> 2) & 3)) << 4) | ((q & 1) << 3));
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * BN * PITCH) = pl[p];
+            }
+            return;
+        }
         char* ad = As + buf * BM * PITCH + lrow * PITCH + q * 16;
         bool a_done = false;
         if constexpr (MVFL) {
@@ -547,6 +600,45 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     constexpr bool FPIPE = GLDS != 0;
     auto compute = [&](int buf, bool ilv_more = false) {
         (void)ilv_more;
+        if constexpr (X3) {
+            // two k-steps of 16 channels; lane (row = lane & 31, half = lane >> 5) reads unit 2 * ks + half of its row in each plane
+            const int fr = lane & 31, fx = (fr >> 2) & 3;          // (fragment rows are multiples of 32 apart: the XOR only depends on lane & 31)
+            const char* Ab = As + (wm * TM * 32 + fr) * PITCH;
+            const char* Bb = Bs + (wn * TN * 32 + fr) * PITCH;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ko = ((2 * ks + (lane >> 5)) ^ fx) << 4;
+                bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(Ab + (p * BM + i * 32) * PITCH + ko);
+                        __builtin_memcpy(&fa[p][i], &v, 16);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(Bb + (p * BN + j * 32) * PITCH + ko);
+                        __builtin_memcpy(&fb[p][j], &v, 16);
+                    }
+                }
+                // smallest terms first (planes 0 / 1 / 2 = hi / mid / lo); operands swapped as everywhere (D^T: see the epilogue)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[2][j], fa[0][i], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[2][i], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[0][i], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[1][i], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+            }
+            return;
+        }
         const char* Ab = As + buf * BM * PITCH + (wm * TM * 32) * PITCH + frag_off;
         const char* Bb = Bs + buf * BN * PITCH + (wn * TN * 32) * PITCH + frag_off;
         auto fetch = [&](int ks, uint4 (&fa)[TM], uint4 (&fb)[TN]) {
@@ -1345,6 +1437,14 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
     conv_tile<ET, WM, WN, TM, TN, true, false, false, EPI, PW, 0, MVFL>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
+// fp32 storage, products as six bf16 partial products on the bf16 matrix cores (conv_tile X3)
+template <int WM, int WN, int TM, int TN, int EPI = 0, bool PW = false>
+__global__ __launch_bounds__(kThreads) void conv_igemm_x3_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<float, WM, WN, TM, TN, true, false, false, EPI, PW, 0, false, false, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
 // LDS-DMA staged variant for the long-K (matrix-core bound) launches
 // HALFK: a K chunk is 128 bytes per row; when the packed input channels of a tap fill only half of it (the bf16 stem: 8 pixels x 4
 // channels = 64 bytes) the two upper k-steps would multiply zeros and are not issued: half the MFMAs and operand reads of that conv
@@ -1500,8 +1600,18 @@ int launch_glds(int nb, int tiles, hipStream_t st, const ConvArgs& a) {
     return MVF_OK;
 }
 
+int g_f32_x3 = 1;                // fp32 storage: products on the bf16 matrix cores as 3-term bf16 splits (MVF_F32_X3=0: the fp32 MFMA)
+
 template <typename ET, int WM, int WN, int TM, int TN, int EPI>
 void launch_lowk(bool pw, int tiles, size_t lds, hipStream_t st, const ConvArgs& a) {
+    if constexpr (sizeof(ET) == 4) {
+        if (g_f32_x3) {
+            constexpr size_t lds3 = (size_t)kLowkLdsX3<WM * TM * 32, WN * TN * 32>();
+            if (pw) hipLaunchKernelGGL((conv_igemm_x3_kernel<WM, WN, TM, TN, EPI, true>), dim3(tiles), dim3(kThreads), lds3, st, a);
+            else hipLaunchKernelGGL((conv_igemm_x3_kernel<WM, WN, TM, TN, EPI, false>), dim3(tiles), dim3(kThreads), lds3, st, a);
+            return;
+        }
+    }
     if (pw) {
         auto k = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, EPI, true>;
         hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), lds, st, a);
@@ -1603,6 +1713,8 @@ int sk_slots() {
         if (e && (e[0] == '0' || e[0] == '1')) g_glds1_f32_infer = e[0] - '0';
         e = getenv("MVF_CONV_GLDS1");
         if (e && e[0] >= '0' && e[0] <= '9') g_glds1_max = atoi(e);
+        e = getenv("MVF_F32_X3");
+        if (e && (e[0] == '0' || e[0] == '1')) g_f32_x3 = e[0] - '0';
         e = getenv("MVF_CONV_BIG");
         if (e && e[0] >= '0' && e[0] <= '9') g_big_min = atoi(e);
         e = getenv("MVF_CONV_BIG2");
@@ -1713,7 +1825,9 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         return MVF_OK;
     }
     if (a.bn_z || a.ap_scale || a.bw_mode) sk_wins = false;   // the BatchNorm-backward / BatchNorm-apply epilogues live in the single-buffer kernels only
-    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale || a.bw_mode) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
+    const bool x3 = sizeof(ET) == 4 && g_f32_x3;              // fp32 on the bf16 matrix cores: the single-buffer register-staged kernel carries it
+    if (x3) sk_wins = false;
+    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale || a.bw_mode || x3) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();
         static const int epi_spec = getenv("MVF_CONV_EPI") ? atoi(getenv("MVF_CONV_EPI")) : 3;     // A/B switch: bit 0 epilogues, bit 1 pointwise loader
         const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
@@ -1777,7 +1891,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         // dominates these launches (ablation: with loads AND MFMAs removed the conv launches still take 58 % of their time).
         // Not for the BatchNorm-sum data gradient (its epilogue spills at 128 registers) and not for fp32 unless forced.
         // (bf16 inference epilogues -- bias + ReLU [+ residual], half-batch launch chains -- keep winning up to 16 chunks: +1.9 %)
-        const int glds1_max = g_glds1_max >= 0 ? g_glds1_max
+        const int glds1_max = x3 ? 0 : g_glds1_max >= 0 ? g_glds1_max
                               : (sizeof(ET) == 2 ? (infer_like ? 16 : 8) : ((infer_like && g_glds1_f32_infer) ? 8 : 0));
         if (glds1_max > 0 && a.nchunks <= glds1_max && !((bnsum_epi || a.bw_mode == 10) && g_glds1_max < 0)) {      // (the two sum epilogues spill at 128 registers)
             int rc;
@@ -1796,7 +1910,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
             return MVF_OK;
         }
         const bool glds_auto = g_glds_min < 0 && sizeof(ET) == 2 && (a.nchunks >= 32 || (BN == 64 && a.nchunks >= 9));
-        if ((g_glds_min > 0 && a.nchunks >= g_glds_min) || glds_auto) {
+        if (!x3 && ((g_glds_min > 0 && a.nchunks >= g_glds_min) || glds_auto)) {
             int rc;
             if (a.ap_scale) rc = launch_glds<ET, WM, WN, TM, TN, 8>(g_glds_nb, tiles, st, a);
             else if (a.bw_mode == 9) rc = launch_glds<ET, WM, WN, TM, TN, 9>(g_glds_nb, tiles, st, a);

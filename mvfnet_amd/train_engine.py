@@ -154,6 +154,45 @@ class _BN(object):
               "mvf_bn_bwd_pair")
         return dza, dzb
 
+    def backward_wgrad(self, g, g_pitch, z, m, eng, mask_mode, ymask, conv, x, x_pitch, sums_done=False):
+        """[r4] backward() with the weight gradient of `conv` (the pointwise conv that produced z from x) taken INSIDE the apply pass
+        (mvf_bn_bwd_apply_wgrad): dz is bit-identical, conv.dw arrives through a slab reduce queued on the side stream."""
+        if not sums_done:
+            self._reduce(g, g_pitch, z, m, eng, mask_mode, ymask, None)
+        return self._apply_bwd_wgrad(g, g_pitch, z, m, eng, mask_mode, ymask, conv, x, x_pitch)
+
+    def _apply_bwd_wgrad(self, g, g_pitch, z, m, eng, mask_mode, ymask, conv, x, x_pitch):
+        """Exactly one fused launch (bench.py brackets this call with HIP events) + the slab reduce handed to the side stream."""
+        dz = eng.buf((id(self), "dz"), z.shape, z.dtype)
+        ns = lib.mvf_bn_bwd_wgrad_splits(m, self.c, conv.cin, 1, mask_mode)
+        nb = lib.mvf_bn_bwd_wgrad_slab_bytes(m, self.c, conv.cin, 1, mask_mode)
+        slabs = eng.buf((id(conv), "wslab"), (nb // 4,), torch.float32)
+        sg, sb = (self._zero, self._zero) if self.frozen else (self.dgamma, self.dbeta)
+        check(lib.mvf_bn_bwd_apply_wgrad(_p(g), g_pitch, _p(z), _p(ymask) if mask_mode == 4 else None, m, self.c, _p(self.gamma), _p(self.mean), _p(self.invstd),
+                                         _p(self.scale), _p(self.shift), _p(sg), _p(sb), mask_mode, _p(dz), _p(x), x_pitch, conv.cin, _p(slabs), nb,
+                                         eng.dt, _st()), "mvf_bn_bwd_apply_wgrad")
+        conv.slab_reduce(slabs, ns, eng)
+        return dz
+
+    @staticmethod
+    def backward_pair_wgrad(a, b, g, g_pitch, za, zb, m, eng, bits, conv_a, xa, xa_pitch, conv_b, xb, xb_pitch):
+        """[r4] backward_pair with conv_a's (and, when xb is given, conv_b's) weight gradient inside the apply pass (mvf_bn_bwd_pair_wgrad)."""
+        nbw = lib.mvf_bn_workspace_bytes(m, a.c)
+        ws = eng.workspace(2 * nbw)
+        dza, dzb = eng.buf((id(a), "dz"), za.shape, za.dtype), eng.buf((id(b), "dz"), zb.shape, zb.dtype)
+        k = conv_a.cin
+        ns = lib.mvf_bn_bwd_wgrad_splits(m, a.c, k, 2, 4)
+        nb = lib.mvf_bn_bwd_wgrad_slab_bytes(m, a.c, k, 2, 4)
+        sa = eng.buf((id(conv_a), "wslab"), (nb // 4,), torch.float32)
+        sb = eng.buf((id(conv_b), "wslab"), (nb // 4,), torch.float32) if xb is not None else None
+        check(lib.mvf_bn_bwd_pair_wgrad(_p(g), g_pitch, _p(za), _p(zb), _p(bits), m, a.c, _p(a.gamma), _p(a.mean), _p(a.invstd), _p(a.dgamma), _p(a.dbeta),
+                                        _p(b.gamma), _p(b.mean), _p(b.invstd), _p(b.dgamma), _p(b.dbeta), _p(dza), _p(dzb), _p(xa), xa_pitch,
+                                        _p(xb), xb_pitch, k, _p(sa), _p(sb), nb, _p(ws), ws.numel(), eng.dt, _st()), "mvf_bn_bwd_pair_wgrad")
+        conv_a.slab_reduce(sa, ns, eng)
+        if xb is not None:
+            conv_b.slab_reduce(sb, ns, eng)
+        return dza, dzb
+
     def _reduce(self, g, g_pitch, z, m, eng, mask_mode, ymask, gm_out):
         ws = eng.workspace(lib.mvf_bn_workspace_bytes(m, self.c))
         check(lib.mvf_bn_bwd_reduce(_p(g), g_pitch, _p(z), _p(ymask), m, self.c, _p(self.mean), _p(self.invstd), _p(self.scale),
@@ -311,6 +350,21 @@ class _TConv(object):
         eng.on_side(launch)
         # dz / x / x2 are persistent engine buffers (eng.buf) or tensors the caller keeps alive until join_side()
 
+    def fuses_wgrad(self, eng, m, c, mask_mode, nbn=1):
+        """[r4] This conv's weight gradient can ride in the BatchNorm-backward apply pass that forms its dz (bf16 storage, pointwise,
+        stride 1, a c x cin accumulator that fits one workgroup: csrc/bnbwd_wgrad.hip)."""
+        return (eng.tdtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and self.stride == 1 and not self.stem and c == self.cout and
+                lib.mvf_bn_bwd_wgrad_splits(m, c, self.cin, nbn, mask_mode) > 0)
+
+    def slab_reduce(self, slabs, ns, eng):
+        """dw <- fixed-order sum of the fused pass's partial slabs: only feeds the optimizer, so it goes to the side stream."""
+        def launch():
+            check(lib.mvf_wgrad_slab_reduce(_p(slabs), ns, self.cout, self.cin, _p(self.dw), _st()), "wgrad slab reduce")
+        if eng.side_stream() is None:
+            launch()
+        else:
+            eng.on_side(launch)
+
     def dgrad_bnsums(self, dz, n, ho, wo, h, w, bn, z):
         """Data gradient that also accumulates the backward sums of `bn` (the ReLU(BN(z)) its output feeds) in its epilogue and
         finalises dgamma / dbeta: bn.backward(..., sums_done=True) then only needs the apply pass.  A strided conv's data gradient
@@ -442,6 +496,8 @@ class _TBlock(object):
         reads z3 and z_d in one pass over g; needs batch statistics fused into the conv epilogue."""
         if not (eng.z3_free and self.cd is None and self.fuse_apply(eng) and eng.fuse_stats and not self.b3.frozen):
             return False
+        if (eng.fuse_bnwg & 8) and eng.tdtype == torch.bfloat16 and lib.mvf_bn_bwd_wgrad_splits(1 << 16, self.c3.cout, self.c3.cin, 1, 4) > 0:
+            return False           # A/B: stored z3 + conv3's weight gradient in bn3's backward apply instead
         # measured per block in the bf16 step (us; stored-z3 path -> recompute path): statistics-only pass 148 -> 79 (layer1) / 75 -> 52 (layer2),
         # backward sums 168 -> 205 / 102 -> 119 (the conv kernel's sum epilogue streams g at 2.7 TB/s, the BatchNorm kernel at 5.2), backward apply
         # 242 -> 204 / 116 -> 119: -70 per layer1 block, ~0 per layer2 block -> planes <= 64 by default, 2 = every block with the fused apply
@@ -502,8 +558,15 @@ class _TBlock(object):
         # moves on to the (HBM-bound) BatchNorm-backward kernels of the next layer -- MFMA work under memory work --
         # instead of fighting the data-gradient GEMM for the matrix cores.
         dzd = resid_aux = aux = None
+        w3_done = wd_done = False        # [r4] weight gradient already taken inside the BatchNorm-backward pass
         if self.cd is not None and eng.pair_bn_bwd and not (self.b3.frozen or self.bd.frozen):
-            dz3, dzd = _BN.backward_pair(self.b3, self.bd, g, self.c3.cout, s["z3"], s["zd"], m2, eng, bits)
+            if (eng.fuse_bnwg & 2) and self.c3.fuses_wgrad(eng, m2, self.c3.cout, 4, 2):
+                both = self.cd.stride == 1 and self.cd.cin == self.c3.cin and self.cd.kh == 1
+                dz3, dzd = _BN.backward_pair_wgrad(self.b3, self.bd, g, self.c3.cout, s["z3"], s["zd"], m2, eng, bits, self.c3, s["a2"], self.c3.cin,
+                                                   self.cd, s["x"] if both else None, c)
+                w3_done, wd_done = True, both
+            else:
+                dz3, dzd = _BN.backward_pair(self.b3, self.bd, g, self.c3.cout, s["z3"], s["zd"], m2, eng, bits)
             aux = eng.aux_stream()
             if aux is not None:      # the downsample branch's data gradient runs beside the conv3 -> conv2 -> conv1 chain (joined before conv1's)
                 aux.wait_stream(eng.main_stream())
@@ -511,6 +574,9 @@ class _TBlock(object):
                     resid_aux = self.cd.dgrad(dzd, nt, ho, wo, h, w)
         elif s["z3"] is None:          # z3 was never stored: bn3's backward on the recomputed conv3
             dz3 = self.c3.bwd_recompute(s["a2"], g, bits, nt, ho, wo, self.b3)
+        elif (eng.fuse_bnwg & 1) and self.c3.fuses_wgrad(eng, m2, self.c3.cout, 4):
+            dz3 = self.b3.backward_wgrad(g, self.c3.cout, s["z3"], m2, eng, 4, bits, self.c3, s["a2"], self.c3.cin)
+            w3_done = True
         else:
             dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 4, ymask=bits)
         fuse = eng.fuse_bn_bwd_sums
@@ -518,7 +584,8 @@ class _TBlock(object):
             da2 = self.c3.dgrad_bnsums(dz3, nt, ho, wo, ho, wo, self.b2, s["z2"])
         else:
             da2 = self.c3.dgrad(dz3, nt, ho, wo, ho, wo)
-        self.c3.wgrad(dz3, s["a2"], nt, ho, wo, ho, wo, eng)
+        if not w3_done:
+            self.c3.wgrad(dz3, s["a2"], nt, ho, wo, ho, wo, eng)
         del dz3
         dz2 = self.b2.backward(da2, self.c2.cout, s["z2"], m2, eng, 2, sums_done=fuse)
         del da2
@@ -531,7 +598,11 @@ class _TBlock(object):
         if eng.side_batch == 2:
             eng.flush_side()                       # conv3's and conv2's weight gradients behind ONE cross-stream hand-over
         del dz2
-        dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2, sums_done=fuse1)
+        w1_done = (eng.fuse_bnwg & 4) and self.mvf is None and self.c1.fuses_wgrad(eng, m, self.c1.cout, 2)
+        if w1_done:
+            dz1 = self.b1.backward_wgrad(da1, self.c1.cout, s["z1"], m, eng, 2, None, self.c1, s["x"], c, sums_done=fuse1)
+        else:
+            dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2, sums_done=fuse1)
         del da1
         resid, rbits = g, bits
         if self.cd is not None:
@@ -542,11 +613,13 @@ class _TBlock(object):
                 resid, rbits = resid_aux, None
             else:
                 resid, rbits = self.cd.dgrad(dzd, nt, ho, wo, h, w), None
-            self.cd.wgrad(dzd, s["x"], nt, h, w, ho, wo, eng, x_pitch=c)
+            if not wd_done:
+                self.cd.wgrad(dzd, s["x"], nt, h, w, ho, wo, eng, x_pitch=c)
             del dzd
         if self.mvf is None:
             dx = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid, res_bits=rbits)
-            self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c)
+            if not w1_done:
+                self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c)
         else:
             # skip-connection gradient without a separate add pass: the data-gradient epilogue adds it to the pass-through
             # channels (>= cs); the slice [0, cs) first goes back through the MVF, whose transposed stencil adds its share
@@ -566,7 +639,8 @@ class _TBlock(object):
         if eng.keep_io:      # parity tests: this block's boundary tensors of the step (persistent buffers, valid until the next step)
             self.io = dict(x=s["x"], out=s["out"], g=g, dx=dx, h=h, w=w, c=c, ho=ho, wo=wo)
         self.saved = None
-        eng.flush_side()
+        if not getattr(eng, "_hold_side", False):
+            eng.flush_side()
         return dx
 
 
@@ -668,6 +742,10 @@ class _ParamStore(object):
     fuse_bn3_apply = int(os.environ.get("MVF_FUSE_BN3_APPLY", "1"))      # [r3] bn3 apply + residual + ReLU as a second conv3 pass (0 / 1 planes <= 128 / 2 all)
     fuse_bn_bwd_sums = os.environ.get("MVF_FUSE_BN_BWD", "1") != "0"    # ... and the backward sums in the data gradient's
     pair_bn_bwd = os.environ.get("MVF_PAIR_BN_BWD", "1") != "0"         # downsample blocks: bn3 + downsample-BN backward in one pass over g
+    # [r4] weight gradients of layer1 / layer2's pointwise convs inside the BatchNorm-backward apply pass that forms their dz (bit mask:
+    # 1 conv3 of plain stored-z3 blocks, 2 conv3 (+ stride-1 downsample conv) of downsample blocks, 4 conv1 of blocks without MVF,
+    # 8 also give up the z3-free path of layer1's plain blocks for it)
+    fuse_bnwg = int(os.environ.get("MVF_FUSE_BNWG", "7"))
     fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes
 
     def side_stream(self):
@@ -1067,10 +1145,19 @@ class TrainEngine(_ParamStore):
         g = self.buf("gfeat", tuple(s["feat_shape"]))
         check(lib.mvf_head_train_bwd(_p(s["dscores"]), _p(s["pooled"]), _p(self.fc_w), _p(s["mask"]), b, t, s["hw"], s["c"], self.num_classes,
                                      _p(self.dfc_w), _p(self.dfc_b), _p(dpool), _p(g), self.dt, _st()), "head bwd")
+        # [r4] side_hold: the weight gradients of the last two stages (matrix-bound GEMMs) are not handed to the side stream block by block --
+        # where they run beside those stages' equally matrix-bound data gradients -- but held back and released in one piece when backward
+        # leaves them: they then run beside layer2 / layer1's byte-bound BatchNorm passes and short-K convs.  Their operands are persistent
+        # per-call-site buffers, so holding the launches back costs no memory.  The tail gradient bucket's all-reduce is ordered behind them.
+        self._hold_side = bool(self.side_hold) and self._tail_block is not None and self.overlap_wgrad and self.defer_side
         for i in range(len(self.blocks) - 1, -1, -1):
             g = self.blocks[i].backward(g, nt, self)
             if i == self._tail_block:
+                if self._hold_side:
+                    self._hold_side = False
+                    self.flush_side()
                 self._launch_tail_allreduce()
+        self._hold_side = False
         ho, wo = s["ho"], s["wo"]
         ga = self.buf("ga0", (nt * ho * wo, 64)) if self.fuse_stem_bwd != 2 else None
         if self.fuse_stem_bwd:      # the pool's scatter also produces the stem BatchNorm's backward sums (one read of z0 instead of a reduce pass)
@@ -1107,6 +1194,7 @@ class TrainEngine(_ParamStore):
         return self.exchange_enabled and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_allreduce)
 
     overlap_allreduce = os.environ.get("MVF_DDP_OVERLAP", "1") != "0"
+    side_hold = int(os.environ.get("MVF_SIDE_HOLD", "0"))
 
     def _launch_tail_allreduce(self):
         """Called from backward when layer3's first block is done: all-reduce flat_grads[tail_off:] (layer3, layer4, head: 94 % of

@@ -388,7 +388,9 @@ def test_mvf_fused_into_conv_loader_equals_stencil_then_conv(case, dtype, mode, 
     ws = torch.zeros(max(lib.mvf_conv2d_workspace_bytes(C.byref(d1)), 16), dtype=torch.uint8, device="cuda")
     check(lib.mvf_conv2d_nhwc_fwd_mvf(C.byref(d1), p(x), p(wp), p(bias), p(coef), cs, T, int(use_hs), p(y1), p(ws), ws.numel(), None))
     torch.cuda.synchronize()
-    assert rel_err(y1.float().cpu().numpy(), y2.float().cpu().numpy()) < (1e-6 if dtype == torch.float32 else 8e-3)
+    # (fp32: the fused-loader kernel multiplies on the fp32 MFMA, the stencil + conv path on the bf16 matrix cores with 3-term splits, [r4] X3:
+    # two fp32-accurate paths with different summation orders)
+    assert rel_err(y1.float().cpu().numpy(), y2.float().cpu().numpy()) < (3e-6 if dtype == torch.float32 else 8e-3)
     # oracle: numpy MVF-proper (eval BN folded into scale / shift) on the stored input, then the conv in fp32
     xn = x.float().cpu().permute(0, 3, 1, 2).contiguous().numpy()
     s = xn[:, :cs].reshape(clips, T, cs, h, w).astype(np.float64)
@@ -468,3 +470,56 @@ def test_four_phase_loops_are_run_to_run_bit_identical_under_a_perturbing_stream
         os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVF_CONV_BIG2="1", MVF_CONV_BIG2_FORCE="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "race screen ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ [r4] fp32 on the bf16 matrix cores (conv_tile X3)
+_X3_CHILD = r"""
+import ctypes as C, sys, numpy as np, torch
+from mvfnet_amd import _lib
+lib, check = _lib.lib, _lib.check
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+out = {}
+for (n, h, cin, cout, k) in SHAPES:
+    gen = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(n, h, h, cin, generator=gen).cuda()
+    w = (torch.randn(cout, cin, k, k, generator=gen) / (cin * k * k) ** 0.5).cuda()
+    wp = torch.empty(cout, k, k, cin, device="cuda")
+    check(lib.mvf_pack_conv_weight(p(w), cout, cin, k, k, k, cin, None, p(wp), 0, None))
+    d = _lib.ConvDesc(n, h, h, cin, cout, k, k, 1, k // 2, h, h, cin, 0, 0, 0, 0, 0)
+    y = torch.empty(n, h, h, cout, device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd(C.byref(d), p(x), None, p(wp), None, None, p(y), None))
+    torch.cuda.synchronize()
+    out["%d_%d_%d" % (cin, cout, k)] = y.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+_X3_SHAPES = [(4, 14, 64, 256, 1), (2, 14, 1024, 256, 1), (2, 14, 256, 256, 3), (2, 7, 512, 512, 3), (3, 9, 96, 40, 3)]
+
+
+@pytest.mark.gpu
+def test_fp32_conv_on_the_bf16_matrix_cores_is_as_accurate_as_the_fp32_mfma(tmp_path):
+    """conv_tile X3 (the default fp32 path): every fp32 operand is split exactly into three bf16 terms and a product is the six partial
+    products of order <= 2^-16 on v_mfma_f32_32x32x16_bf16.  Against an fp64 convolution of the same operands the error must be the fp32
+    ACCUMULATION error, i.e. no larger than what the exact-fp32 MFMA path (MVF_F32_X3=0, run in a child process: the switch is read once
+    per process) leaves -- K = 64 ... 4608, a ragged channel tail included -- and both far inside the 1e-5 every fp32 test allows."""
+    import os
+    import subprocess
+    import sys
+    src = "SHAPES = %r\n" % (_X3_SHAPES,) + _X3_CHILD
+    res = {}
+    for tag, val in (("x3", "1"), ("mfma", "0")):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", src, f], env=dict(os.environ, MVF_F32_X3=val, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(f)
+    for (n, h, cin, cout, k) in _X3_SHAPES:
+        gen = torch.Generator().manual_seed(cin + cout + k)
+        x = torch.randn(n, h, h, cin, generator=gen)
+        w = torch.randn(cout, cin, k, k, generator=gen) / (cin * k * k) ** 0.5
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=k // 2).permute(0, 2, 3, 1).numpy()
+        key = "%d_%d_%d" % (cin, cout, k)
+        e3 = np.linalg.norm(res["x3"][key] - ref) / np.linalg.norm(ref)
+        e1 = np.linalg.norm(res["mfma"][key] - ref) / np.linalg.norm(ref)
+        assert not np.array_equal(res["x3"][key], res["mfma"][key])           # (two different kernels did run)
+        assert e3 < 2e-6 and e3 < 1.5 * e1 + 2e-8, (key, e3, e1)        # (measured: K = 1024 4.9e-7 against the fp32 MFMA's 5.7e-7)
+        assert np.abs(res["x3"][key] - ref).max() / np.abs(ref).max() < 2e-6

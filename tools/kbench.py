@@ -44,7 +44,7 @@ def bench_conv(dt=1, only=None):
               ("l4.c3 fwd", 7, 512, 2048, 1, "stats"), ("l2.c2 fwd", 28, 128, 128, 3, "stats"), ("l1.c2 fwd", 56, 64, 64, 3, "stats"),
               ("l1.c3 apply", 56, 64, 256, 1, "infer_res"), ("l2.c3 apply", 28, 128, 512, 1, "infer_res"), ("l3.c3 apply", 14, 256, 1024, 1, "infer_res"),
               ("l4.c3 apply", 7, 512, 2048, 1, "infer_res")]
-    n = 256
+    n = int(os.environ.get("KBENCH_FRAMES", "256"))          # 256 = the C3 / C4 step; other values probe the tile-count quantisation
     for name, hw, cin, cout, k, kind in shapes:
         if only and only not in name:
             continue
@@ -182,8 +182,42 @@ def bench_bnwg():
             name, m, c, k, ta, tw, ta + tw, tf, tr, ns, by_f / tf / 1e6, ta + tw - tf - tr))
 
 
+def bench_mvf():
+    """[r4] The engine's MVF stencil (mvf_nhwc_stencil: plain, and transposed + gated addend as the backward runs it) on the layer3 / layer4 shapes,
+    reading its slice (a) where it lies today -- the first cs channels of every c-channel pixel row (256 B of every 2 KB) -- and (b) from a COMPACT
+    [m][cs] copy: what a producer-side slice copy could buy."""
+    from mvfnet_amd._lib import MvfDesc
+    dev, bf = "cuda", torch.bfloat16
+    for name, hw, c in (("layer3.1+", 14, 1024), ("layer4.1+", 7, 2048), ("layer3.0", 28, 512)):
+        nt, T, cs = 256, 8, c // 8
+        m = nt * hw * hw
+        d = MvfDesc(nt, c, hw, hw, T, cs, 7, _lib.MVF_NHWC, 1)
+        x = torch.randn(m, c, device=dev).to(bf)
+        xs = x[:, :cs].contiguous()
+        y = torch.empty(m, cs, device=dev, dtype=bf)
+        dxp = torch.randn(m, c, device=dev).to(bf)
+        g = torch.randn(m, c, device=dev).to(bf)
+        gs = g[:, :cs].contiguous()
+        bits = torch.randint(0, 16, (m, c // 4), device=dev, dtype=torch.uint8)
+        w = [torch.randn(cs, 3, device=dev) for _ in range(3)]
+        by = 2 * m * cs * 2
+        t0 = timeit(lambda: check(lib.mvf_nhwc_stencil(C.byref(d), P(x), c, P(y), cs, P(w[0]), P(w[1]), P(w[2]), None, None, 0, None, 0, None, None)))
+        t1 = timeit(lambda: check(lib.mvf_nhwc_stencil(C.byref(d), P(xs), cs, P(y), cs, P(w[0]), P(w[1]), P(w[2]), None, None, 0, None, 0, None, None)))
+        print("%-10s M%-7d cs %-4d stencil   in place %6.1f us (%4.2f TB/s)   compact input %6.1f us (%4.2f TB/s)" % (name, m, cs, t0, by / t0 / 1e6, t1, by / t1 / 1e6))
+        by = 3 * m * cs * 2
+        t0 = timeit(lambda: check(lib.mvf_nhwc_stencil(C.byref(d), P(y), cs, P(dxp), c, P(w[0]), P(w[1]), P(w[2]), None, None, 1, P(g), c, P(bits), None)))
+        t1 = timeit(lambda: check(lib.mvf_nhwc_stencil(C.byref(d), P(y), cs, P(xs), cs, P(w[0]), P(w[1]), P(w[2]), None, None, 1, P(gs), cs, None, None)))
+        print("%-10s M%-7d cs %-4d stencil^T in place %6.1f us (%4.2f TB/s)   compact in / out / addend (no gate) %6.1f us (%4.2f TB/s)" % (name, m, cs, t0, by / t0 / 1e6, t1, by / t1 / 1e6))
+        # the floor of ANY kernel of this size: a plain copy of the compact slice
+        t2 = timeit(lambda: y.copy_(xs))
+        print("%-10s            copy of the compact slice (torch) %6.1f us (%4.2f TB/s)" % (name, t2, 2 * m * cs * 2 / t2 / 1e6))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "bn"
+    if what == "mvf":
+        bench_mvf()
+        sys.exit(0)
     if what == "bnwg":
         bench_bnwg()
         sys.exit(0)
