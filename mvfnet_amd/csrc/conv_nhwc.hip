@@ -177,8 +177,8 @@ template <typename ET, int WM, int WN, int TM, int TN, bool LOWK = false, bool P
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const int tile, const int c_begin, const int c_end,
                                           const int mode, const SkArgs& sk, const int g_first, const int g_self) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    static_assert(BM == kBM || (BM == 2 * kBM && GLDS >= 2), "BM is 128 (256 for the 8-wave LDS-DMA tiles)");
-    static_assert(WM * WN == 4 || (WM * WN == 8 && GLDS >= 2), "4 waves (8 for the LDS-DMA experiments)");
+    static_assert(BM == kBM || (BM == 2 * kBM && (GLDS >= 2 || X3)), "BM is 128 (256 for the 8-wave LDS-DMA tiles and the 8-wave X3 tile)");
+    static_assert(WM * WN == 4 || (WM * WN == 8 && (GLDS >= 2 || X3)), "4 waves (8 for the LDS-DMA experiments and the X3 tile)");
     // P4 = the four-phase ping-pong main loop (see the loop itself): 2 x 4 waves of 128 x 64 outputs on a 256 x 256 tile
     constexpr bool P4 = GLDS == 4;
     static_assert(!P4 || (WM == 2 && WN == 4 && TM == 4 && TN == 2 && sizeof(ET) == 2 && !MVFL && !ILV && !HALFK), "the four-phase loop is written for the bf16 256 x 256 tile");
@@ -195,11 +195,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     static_assert(!MVFL || (((LOWK && PW) || GLDS == 1 || GLDS == 2) && !GEN), "the fused MVF loader: single-buffer register-staged pointwise kernel or the 4-wave LDS-DMA kernels");
     static_assert(!ILV || (GLDS == 2 && !MVFL), "interleaved DMA issue: the two-buffer LDS-DMA loop");
     constexpr int NBUF = P4 ? 2 : (GLDS ? GLDS : (LOWK ? 1 : 2));
-    static_assert(!X3 || (sizeof(ET) == 4 && LOWK && !GLDS && !MVFL && !PF2), "X3: fp32 storage, single-buffer register-staged kernel");
+    static_assert(!X3 || (sizeof(ET) == 4 && !GLDS && !MVFL && !PF2), "X3: fp32 storage, register-staged kernels (single- or double-buffered)");
     // X3: a chunk row is 32 channels = 64 bytes per bf16 plane, three planes per tile; unpadded rows, 16-byte units XOR-swizzled by the row
     // (unit u of row r at u ^ ((r >> 2) & 3): the 16 rows a ds_read_b128 service group reads fall on 16 distinct 16-byte bank slots)
     constexpr int PITCH = X3 ? 64 : (GLDS ? 128 : kPitch);         // LDS-DMA rows are unpadded (lane-linear destination)
-    constexpr int kSmem = X3 ? kLowkLdsX3<BM, BN>() : (GLDS ? kGldsLds<BM, BN, GLDS ? NBUF : 1>() : (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch));
+    constexpr int kSmem = X3 ? (LOWK ? kLowkLdsX3<BM, BN>() : 2 * (BM + BN) * 192) : (GLDS ? kGldsLds<BM, BN, GLDS ? NBUF : 1>() : (LOWK ? kLowkLds<BM, BN>() : 2 * (BM + BN) * kPitch));
     constexpr int NPL = X3 ? 3 : 1;                    // operand planes per tile
     char* As = smem;                                   // [NBUF][NPL][BM][PITCH]
     char* Bs = smem + NBUF * NPL * BM * PITCH;         // [NBUF][NPL][BN][PITCH]
@@ -552,7 +552,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 const int row = lrow + RP * i;
                 uint2 pl[3];
                 split3(st.a[i], pl);
-                char* d = As + row * PITCH + ((((q >> 1) ^ ((row >> 2) & 3)) << 4) | ((q & 1) << 3));
+                char* d = As + (buf * 3 * BM + row) * PITCH + ((((q >> 1) ^ ((row >> 2) & 3)) << 4) | ((q & 1) << 3));
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * BM * PITCH) = pl[p];
             }
@@ -561,7 +561,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 const int row = lrow + RP * i;
                 uint2 pl[3];
                 split3(st.b[i], pl);
-                char* d = Bs + row * PITCH + ((((q >> 1) ^ ((row >> 2) & 3)) << 4) | ((q & 1) << 3));
+                char* d = Bs + (buf * 3 * BN + row) * PITCH + ((((q >> 1) ^ ((row >> 2) & 3)) << 4) | ((q & 1) << 3));
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * BN * PITCH) = pl[p];
             }
@@ -603,8 +603,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         if constexpr (X3) {
             // two k-steps of 16 channels; lane (row = lane & 31, half = lane >> 5) reads unit 2 * ks + half of its row in each plane
             const int fr = lane & 31, fx = (fr >> 2) & 3;          // (fragment rows are multiples of 32 apart: the XOR only depends on lane & 31)
-            const char* Ab = As + (wm * TM * 32 + fr) * PITCH;
-            const char* Bb = Bs + (wn * TN * 32 + fr) * PITCH;
+            const char* Ab = As + (buf * 3 * BM + wm * TM * 32 + fr) * PITCH;
+            const char* Bb = Bs + (buf * 3 * BN + wn * TN * 32 + fr) * PITCH;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int ko = ((2 * ks + (lane >> 5)) ^ fx) << 4;
@@ -1600,13 +1600,83 @@ int launch_glds(int nb, int tiles, hipStream_t st, const ConvArgs& a) {
     return MVF_OK;
 }
 
+// X3 on a 256 x 128 tile computed by 8 waves (4 x 2, 64 x 64 each): the per-chunk fixed costs of the single-buffer loop (two barriers, the
+// LDS round trips, the store phase) are paid once per 2 x the matrix work, and a workgroup keeps two waves on every SIMD
+template <int EPI = 0, bool PW = false>
+__global__ __launch_bounds__(512) void conv_igemm_x3w_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<float, 4, 2, 2, 2, true, false, false, EPI, PW, 0, false, false, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+int g_x3_wide = 0;               // MVF_X3_WIDE=n: the 8-wave 256 x 128 X3 tile for launches with >= n tiles of that size (0 = off)
+
 int g_f32_x3 = 1;                // fp32 storage: products on the bf16 matrix cores as 3-term bf16 splits (MVF_F32_X3=0: the fp32 MFMA)
+int g_x3_db_min = 1 << 30;       // X3: double-buffered planes (one workgroup per CU, one barrier per chunk) from this many K chunks on (MVF_X3_DB)
+
+// X3 with two LDS buffers: chunk k + 1 is split and written to the other buffer behind the MFMAs of chunk k, one barrier per chunk
+template <int WM, int WN, int TM, int TN, int EPI = 0, bool PW = false>
+__global__ __launch_bounds__(kThreads) void conv_igemm_x3db_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SkArgs sk = {};
+    conv_tile<float, WM, WN, TM, TN, false, false, false, EPI, PW, 0, false, false, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
+}
+
+// MVF_F32_X3: 0 never, 1 always; diagnostics: 2 only launches with a forward epilogue (statistics / bias / BatchNorm apply), 3 only the others
+// (data gradients, plain forwards), 4 only 3x3 taps, 5 only pointwise, 6 only the stem's 7 x 1 view, 7 everything but the stem
+inline bool x3_on(const ConvArgs& a) {
+    const bool fwd_like = a.stats_part || a.bias || a.ap_scale || a.bw_mode;
+    switch (g_f32_x3) {
+        case 1: return true;
+        case 2: return fwd_like;
+        case 3: return !fwd_like;
+        case 4: return a.KH == 3;
+        case 5: return a.KH == 1 && a.KW == 1;
+        case 6: return a.KH == 7;
+        case 7: return a.KH != 7;
+        default: return false;
+    }
+}
 
 template <typename ET, int WM, int WN, int TM, int TN, int EPI>
 void launch_lowk(bool pw, int tiles, size_t lds, hipStream_t st, const ConvArgs& a) {
     if constexpr (sizeof(ET) == 4) {
-        if (g_f32_x3) {
+        if (x3_on(a)) {
             constexpr size_t lds3 = (size_t)kLowkLdsX3<WM * TM * 32, WN * TN * 32>();
+            if constexpr (WN * TN * 32 == 128 && EPI >= 1 && EPI <= 6) {
+                const int t_wide = ((a.M + 255) / 256) * a.tiles_n;
+                if (g_x3_wide > 0 && t_wide >= g_x3_wide) {
+                    ConvArgs b = a;
+                    b.tiles_m = (a.M + 255) / 256;
+                    constexpr size_t ldsw = (size_t)kLowkLdsX3<256, 128>();
+                    auto k0 = conv_igemm_x3w_kernel<EPI, false>;
+                    auto k1 = conv_igemm_x3w_kernel<EPI, true>;
+                    static bool attrw = false;
+                    if (!attrw) {
+                        (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+                        (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+                        attrw = true;
+                    }
+                    if (pw) hipLaunchKernelGGL(k1, dim3(t_wide), dim3(512), ldsw, st, b);
+                    else hipLaunchKernelGGL(k0, dim3(t_wide), dim3(512), ldsw, st, b);
+                    return;
+                }
+            }
+            if constexpr (EPI >= 1 && EPI <= 6) {
+                if (a.nchunks >= g_x3_db_min) {
+                    constexpr size_t ldsdb = (size_t)2 * (WM * TM * 32 + WN * TN * 32) * 192;
+                    auto k0 = conv_igemm_x3db_kernel<WM, WN, TM, TN, EPI, false>;
+                    auto k1 = conv_igemm_x3db_kernel<WM, WN, TM, TN, EPI, true>;
+                    static bool attr = false;
+                    if (!attr) {
+                        (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsdb);
+                        (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsdb);
+                        attr = true;
+                    }
+                    if (pw) hipLaunchKernelGGL(k1, dim3(tiles), dim3(kThreads), ldsdb, st, a);
+                    else hipLaunchKernelGGL(k0, dim3(tiles), dim3(kThreads), ldsdb, st, a);
+                    return;
+                }
+            }
             if (pw) hipLaunchKernelGGL((conv_igemm_x3_kernel<WM, WN, TM, TN, EPI, true>), dim3(tiles), dim3(kThreads), lds3, st, a);
             else hipLaunchKernelGGL((conv_igemm_x3_kernel<WM, WN, TM, TN, EPI, false>), dim3(tiles), dim3(kThreads), lds3, st, a);
             return;
@@ -1714,7 +1784,11 @@ int sk_slots() {
         e = getenv("MVF_CONV_GLDS1");
         if (e && e[0] >= '0' && e[0] <= '9') g_glds1_max = atoi(e);
         e = getenv("MVF_F32_X3");
-        if (e && (e[0] == '0' || e[0] == '1')) g_f32_x3 = e[0] - '0';
+        if (e && e[0] >= '0' && e[0] <= '7') g_f32_x3 = e[0] - '0';
+        e = getenv("MVF_X3_WIDE");
+        if (e && e[0] >= '0' && e[0] <= '9') g_x3_wide = atoi(e);
+        e = getenv("MVF_X3_DB");
+        if (e && e[0] >= '0' && e[0] <= '9') g_x3_db_min = atoi(e);
         e = getenv("MVF_CONV_BIG");
         if (e && e[0] >= '0' && e[0] <= '9') g_big_min = atoi(e);
         e = getenv("MVF_CONV_BIG2");
@@ -1825,7 +1899,8 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         return MVF_OK;
     }
     if (a.bn_z || a.ap_scale || a.bw_mode) sk_wins = false;   // the BatchNorm-backward / BatchNorm-apply epilogues live in the single-buffer kernels only
-    const bool x3 = sizeof(ET) == 4 && g_f32_x3;              // fp32 on the bf16 matrix cores: the single-buffer register-staged kernel carries it
+    // fp32 on the bf16 matrix cores: the single-buffer register-staged kernel carries it (x3_on)
+    const bool x3 = sizeof(ET) == 4 && x3_on(a);
     if (x3) sk_wins = false;
     if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale || a.bw_mode || x3) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();

@@ -566,31 +566,50 @@ def test_norm_eval_training_vs_reference_golden():
     assert abs(float(loss) - float(g["loss/0"])) < 2e-5 * float(g["loss/0"])
     eng.backward()
     params = dict(m.named_parameters())
+    # [r4] Gradient tolerances.  The reference's own fp32 run of this step equals its fp64 run to 1e-6 (tests/golden/make_normeval_fp64_golden.py),
+    # and with the exact-fp32 MFMA convs (MVF_F32_X3=0) the engine is within 5e-4 of both: 2e-3 asserted (the tight leg below runs that path in a
+    # child process).  The default fp32 convs (three-term bf16 split on the bf16 matrix cores) differ from the MFMA ones by ~1e-6 per conv output --
+    # both equally close to an fp64 convolution (test_fp32_conv_on_the_bf16_matrix_cores_is_as_accurate_as_the_fp32_mfma) -- which on THIS
+    # input flips ONE ReLU decision of layer4.0's bn2 (a 72 x 512 tensor at 96^2 input: one element is 1.2e-2 of its gradient's norm;
+    # tools/probes/normeval_blocks.py): every gradient upstream of it then moves by ~5e-3.  That is fp32 sign luck at a kink, not accuracy:
+    # the loose bound is asserted here, the conv- and block-level comparisons stay at 1e-6 / 2e-4.
+    import os
+    tight = os.environ.get("MVF_F32_X3", "1") == "0"
+    tol_n, tol_g = (2e-3, 2e-3) if tight else (1.5e-2, 2e-2)
     for nme, r in zip(list(g["grad_names"]), g["grad_norms"]):
         got = float(eng.grad_of(params[nme]).double().norm())
-        # (the MVF modules' BatchNorm / tap gradients sit behind hard-swish': a handful of elements changing side at its kinks under 1e-7
-        # perturbations -- another fp32 summation order -- move these small norms by a few 1e-3; [r4] measured 3.2e-3 on layer3.4.conv1.bn.weight
-        # between the fp32-MFMA convs and the bf16x3 ones, both equally close to an fp64 convolution)
-        tol = 6e-3 if ".conv1.bn." in nme or "_conv.weight" in nme else 2e-3
-        assert abs(got - r) < tol * max(r, 1e-6), (nme, got, r)
+        assert abs(got - r) < tol_n * max(r, 1e-6), (nme, got, r)
     for k in g.files:
         if k.startswith("grad/"):
-            tol = 6e-3 if ".conv1.bn." in k or "_conv.weight" in k else 2e-3       # (hard-swish' kinks, as above: measured 4.1e-3)
-            assert rel_err(eng.grad_of(params[k[5:]]).cpu().numpy(), g[k]) < tol, k
+            assert rel_err(eng.grad_of(params[k[5:]]).cpu().numpy(), g[k]) < tol_g, k
+    g64 = golden("normeval_fp64.npz")                      # the same step by the reference in DOUBLE precision
+    for k in g64.files:
+        if k.startswith("grad/"):
+            assert rel_err(eng.grad_of(params[k[5:]]).cpu().numpy().astype(np.float64), g64[k]) < tol_g, k
     norm = eng.step()
-    assert abs(float(norm[0]) - float(g["total_norm/0"])) < 1e-3 * float(g["total_norm/0"])
+    assert abs(float(norm[0]) - float(g["total_norm/0"])) < (1e-3 if tight else 5e-3) * float(g["total_norm/0"])
     loss1 = eng.forward(imgs, labels)
     assert abs(float(loss1) - float(g["loss/1"])) < 2e-3 * float(g["loss/1"])
     eng.backward()
     norm = eng.step()
-    assert abs(float(norm[0]) - float(g["total_norm/1"])) < 5e-3 * float(g["total_norm/1"])
+    assert abs(float(norm[0]) - float(g["total_norm/1"])) < (5e-3 if tight else 1e-2) * float(g["total_norm/1"])
     sd = m.state_dict()
     for k, v in before.items():
         assert torch.equal(sd[k], v), k                       # frozen statistics (and step counters) did not move
     for k in g.files:
         if k.startswith("after2/"):
             a = sd[k[7:]].detach().float().cpu().numpy().ravel()
-            assert rel_err(a[: g[k].size], g[k]) < 2e-3, k
+            assert rel_err(a[: g[k].size], g[k]) < (2e-3 if tight else 5e-3), k
+
+
+def test_norm_eval_training_vs_reference_golden_tight_on_the_exact_fp32_mfma():
+    """The tight leg of the test above: the same step in a child process with MVF_F32_X3=0 (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "test_norm_eval_training_vs_reference_golden and not tight",
+                        "-p", "no:cacheprovider"], env=dict(os.environ, MVF_F32_X3="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_norm_eval_training_bf16_close_to_fp32():
