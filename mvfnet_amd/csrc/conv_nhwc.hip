@@ -622,20 +622,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                         __builtin_memcpy(&fb[p][j], &v, 16);
                     }
                 }
-                // smallest terms first (planes 0 / 1 / 2 = hi / mid / lo); operands swapped as everywhere (D^T: see the epilogue)
+                // smallest terms first (planes 0 / 1 / 2 = hi / mid / lo); operands swapped as everywhere (D^T: see the epilogue).  The
+                // product term is the OUTER loop: consecutive matrix instructions go to different accumulators (a dependent one would wait
+                // for its predecessor's 8 passes + write-back -- the tile-by-tile order ran the loop at a third of the matrix rate)
+                constexpr int PA_[6] = {0, 2, 1, 0, 1, 0}, PB_[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        f32x16 c = acc[i][j];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[2][j], fa[0][i], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[2][i], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[0][i], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[1][i], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], c, 0, 0, 0);
-                        acc[i][j] = c;
-                    }
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB_[t]][j], fa[PA_[t]][i], acc[i][j], 0, 0, 0);
             }
             return;
         }
@@ -1439,7 +1436,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_lowk_kernel(ConvArgs a) {
 
 // fp32 storage, products as six bf16 partial products on the bf16 matrix cores (conv_tile X3)
 template <int WM, int WN, int TM, int TN, int EPI = 0, bool PW = false>
-__global__ __launch_bounds__(kThreads) void conv_igemm_x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(kThreads, 3) void conv_igemm_x3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SkArgs sk = {};
     conv_tile<float, WM, WN, TM, TN, true, false, false, EPI, PW, 0, false, false, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
