@@ -448,7 +448,7 @@ def single_gpu_test(model, loader):
     with torch.no_grad():
         for data in loader:
             img = data["img_group"]
-            if not img.is_cuda:          # a DataLoader's host batch: the reference's MMDataParallel scatters it to the device (test.py:24-27)
+            if torch.is_tensor(img) and not img.is_cuda and torch.cuda.is_available():      # a DataLoader's host batch: the reference's MMDataParallel scatters it to the device (test.py:24-27)
                 img = img.cuda(non_blocking=True)
             results.append(model(return_loss=False, img_group=img))
     return results

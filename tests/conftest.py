@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """The CPU oracle legs (torch / oneDNN on the host cores) with one thread per hardware thread of a 256-thread host thrash for minutes,
+    more so when other tenants share the host (the GPU suite was seen at 13 minutes instead of 4): 16 threads are enough for the test sizes."""
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

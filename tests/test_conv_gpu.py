@@ -508,8 +508,9 @@ def test_fp32_conv_on_the_bf16_matrix_cores_is_as_accurate_as_the_fp32_mfma(tmp_
     res = {}
     for tag, val in (("x3", "1"), ("mfma", "0")):
         f = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, "-c", src, f], env=dict(os.environ, MVF_F32_X3=val, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
-                           capture_output=True, text=True, timeout=600)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MVF_CONV_")}       # (a forced tile / loader policy of a parent test run would send both legs to one kernel)
+        env.update(MVF_F32_X3=val, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", src, f], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = np.load(f)
     for (n, h, cin, cout, k) in _X3_SHAPES:
