@@ -41,6 +41,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks (fp32-in / bf16)
+# fp32 convs run on the BF16 matrix cores as six bf16 partial products per fp32 product (conv_tile X3, the default; MVF_F32_X3=0 = the fp32
+# MFMA): their ceiling in fp32-EQUIVALENT flops is the bf16 peak / 6.  The fp32 weight gradients keep the fp32 MFMA (157.3).
+F32_X3 = os.environ.get("MVF_F32_X3", "1") != "0"
+F32_CONV_PEAK = PEAK_TFLOPS["bf16"] / 6.0 if F32_X3 else PEAK_TFLOPS["f32"]
 VIDEO = False
 T_FRAMES, SIZE = 8, 224     # overwritten from --frames / --mode video in main()
 
@@ -177,12 +181,12 @@ def roofline_infer(model, imgs, dtype, per_layer):
             del t.rec[:]
             model(imgs, None, return_loss=False, return_numpy=False)
             torch.cuda.synchronize()
-            r = _summ(t.rec, per_layer and i == reps - 1, "conv", PEAK_TFLOPS[dtype])
+            r = _summ(t.rec, per_layer and i == reps - 1, "conv", F32_CONV_PEAK if dtype == "f32" else PEAK_TFLOPS[dtype])
             tot = [a + b for a, b in zip(tot, r)]
     finally:
         undo()
         model.backbone.engine().streams = streams
-    return _roof(tot, reps, dtype, event_pair_overhead_ms(), dtype + "_infer", pmc_group="conv", kernel="conv_igemm_* (conv_tile instantiations, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct (the direct kernels of layer1's 3x3 and the stem)")
+    return _roof(tot, reps, dtype, event_pair_overhead_ms(), dtype + "_infer", pmc_group="conv", peak_tf=(F32_CONV_PEAK if dtype == "f32" else None), kernel="conv_igemm_* (conv_tile instantiations, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct (the direct kernels of layer1's 3x3 and the stem)")
 
 
 def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
@@ -280,7 +284,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
             eng.backward()
             torch.cuda.synchronize()
             for k, t in timers:
-                tot[k] = [a + b for a, b in zip(tot[k], _summ(t.rec, per_layer and i == reps - 1, k, PEAK_TFLOPS[dtype]))]
+                tot[k] = [a + b for a, b in zip(tot[k], _summ(t.rec, per_layer and i == reps - 1, k, F32_CONV_PEAK if (dtype == "f32" and k == "igemm") else PEAK_TFLOPS[dtype]))]
             rec = [r_ for r_ in tc.rec if r_[3].startswith(RECOMPUTE_TAGS)]
             req = [r_ for r_ in tc.rec if not r_[3].startswith(RECOMPUTE_TAGS)]
             tot["igemm_recompute"] = [a + b for a, b in zip(tot["igemm_recompute"], _summ(rec, False, "", PEAK_TFLOPS[dtype]))]
@@ -293,12 +297,13 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
     key = dtype + "_train"
     conv_kernels = ("conv_igemm_* (conv_tile instantiations: lowk / glds / p4 / streamk, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct / pw_sums (the direct "
                     "kernels of layer1's 3x3 + its data gradient, of the stem, and the sum-only passes of layer1's conv3)")
-    r = _roof(tot["igemm"], reps, dtype, ovh, key, conv_kernels, "conv")
+    cpeak = F32_CONV_PEAK if dtype == "f32" else None
+    r = _roof(tot["igemm"], reps, dtype, ovh, key, conv_kernels, "conv", peak_tf=cpeak)
     # the family with and without the RECOMPUTE passes (conv3 run again instead of re-reading z3: bn3's apply, backward sums, backward
     # apply as epilogues of a second / third / fourth pass).  Their bytes / flops are booked as algorithmic above because they replace
     # BatchNorm passes that moved MORE bytes; `required` is the like-for-like family (one forward + one data gradient per conv).
-    r["required"] = _roof(tot["igemm_required"], reps, dtype, ovh, kernel="forward convs (incl. statistics-only first passes) + data gradients: one each per conv")
-    r["recompute"] = _roof(tot["igemm_recompute"], reps, dtype, ovh, kernel="conv3 second passes: fwd+bn (bn3 apply + residual + ReLU), bwd-sums, bwd-apply (z3-free blocks)")
+    r["required"] = _roof(tot["igemm_required"], reps, dtype, ovh, kernel="forward convs (incl. statistics-only first passes) + data gradients: one each per conv", peak_tf=cpeak)
+    r["recompute"] = _roof(tot["igemm_recompute"], reps, dtype, ovh, kernel="conv3 second passes: fwd+bn (bn3 apply + residual + ReLU), bwd-sums, bwd-apply (z3-free blocks)", peak_tf=cpeak)
     groups = {"wgrad": _roof(tot["wgrad"], reps, dtype, ovh, key, "wgrad_*_kernel + wgrad_reduce_kernel (csrc/wgrad_nhwc.hip) [+ the fused BatchNorm-backward-apply + weight-gradient kernels, csrc/bnbwd_wgrad.hip, where the step uses them]", "wgrad"),
               "bn": _roof(tot["bn"], reps, dtype, ovh, key, "bn_apply / bn_bwd_reduce / bn_bwd_apply kernels (csrc/train_ops.hip)", "bn"),
               "mvf": _roof(tot["mvf"], reps, dtype, ovh, key, "mvf_nhwc_apply (stencil and transposed stencil, csrc/mvf_nhwc.hip)", "mvf")}
@@ -346,7 +351,7 @@ def _pmc_traffic(pmc_key, group):
         return None, None
 
 
-def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None, kernel=None, pmc_group=None):
+def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None, kernel=None, pmc_group=None, peak_tf=None):
     """One kernel group's roofline object.  Time = the GROSS sum of the HIP-event brackets (no overhead subtraction: rocprofv3's kernel
     durations agree with the gross figure, profiles/README.md); `event_pair_overhead_us` is printed for information only.
     fp32: the conv GEMMs are MFMA-bound (94 FLOP/B fused vs ~20 machine balance).  bf16: the same network is HBM-bound even when
@@ -358,7 +363,7 @@ def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None, kernel=None, pm
     n = max(n, 1)
     tflops = fl / (ms * 1e-3) / 1e12
     gbs = by / (ms * 1e-3) / 1e9
-    peak = PEAK_TFLOPS[dtype]
+    peak = peak_tf or PEAK_TFLOPS[dtype]
     per_step, source = _pmc_traffic(pmc_key, pmc_group)
     launches = max(n // reps, 1)
     alg_step = by / reps
@@ -373,7 +378,10 @@ def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None, kernel=None, pm
     if dtype == "bf16" or fl == 0.0:
         common.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
     else:
-        common.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4)})
+        common.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tflops / peak, 4)})
+        if peak_tf and abs(peak_tf - PEAK_TFLOPS["f32"]) > 1.0:
+            common["peak_note"] = ("fp32-equivalent flops on the bf16 matrix cores: six bf16 partial products per fp32 product (exact three-term split), "
+                                   "peak = 2500 / 6 TF/s; MVF_F32_X3=0 runs the fp32 MFMA (157.3)")
     return common
 
 

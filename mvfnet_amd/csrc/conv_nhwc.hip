@@ -538,9 +538,16 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         for (int p = 0; p < 3; ++p) {
             const unsigned lo2 = pack_bf16x2(r[0], r[1]), hi2 = pack_bf16x2(r[2], r[3]);
             pl[p] = make_uint2(lo2, hi2);
+#ifdef MVF_X3_ABLATE_SPLIT
+            if (false) {                     // timing ablation (wrong results): the three planes all hold bf16(x), no subtraction
+#else
             if (p < 2) {
-                r[0] -= __uint_as_float(lo2 << 16); r[1] -= __uint_as_float(lo2 & 0xffff0000u);
-                r[2] -= __uint_as_float(hi2 << 16); r[3] -= __uint_as_float(hi2 & 0xffff0000u);
+#endif
+                // scalar v_sub_f32 through asm: left alone hipcc SLP-packs the four into v_pk_add_f32, and packed fp32 VALU beside matrix instructions
+                // is an anti-lever on this chip (MI355X_MICROARCH.md; tools/probes/x3_gemm_probe.hip: +5 %)
+                auto sub1 = [](float x, float y) { float d; asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+                r[0] = sub1(r[0], __uint_as_float(lo2 << 16)); r[1] = sub1(r[1], __uint_as_float(lo2 & 0xffff0000u));
+                r[2] = sub1(r[2], __uint_as_float(hi2 << 16)); r[3] = sub1(r[3], __uint_as_float(hi2 & 0xffff0000u));
             }
         }
     };
