@@ -217,6 +217,52 @@ def test_conv3x3_c64_direct_vs_oracle_and_the_implicit_gemm(shape):
         assert (a_ != b_).float().mean().item() < 1e-3 and rel_err(a_.float().cpu().numpy(), b_.float().cpu().numpy()) < 1e-3
 
 
+def test_conv3x3_c64_direct_full_c3_size_oracle_rows():
+    """[r4] The direct 3x3 kernel at the FULL C3 launch (256 frames x 56 x 56 x 64: `conv3x3_c64_kernel<.., 56, 4>` with every workgroup walking its
+    14 bands of many frames) against the oracle on whole frames -- the first two, one in the middle (a workgroup's frame boundary) and the last (tail bands) --
+    for the forward + statistics epilogue and for the data gradient + BatchNorm-backward sums; statistics against the stored output."""
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    n, h, w = 256, 56, 56
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xw = torch.randn(n, h, w, 64, device="cuda", generator=g).bfloat16()
+    wt = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
+    shift = torch.randn(64, device="cuda", generator=g) * 0.1
+    wpk = torch.empty(64, 3, 3, 64, device="cuda", dtype=torch.bfloat16)
+    wdg = torch.empty(64, 3, 3, 64, device="cuda", dtype=torch.bfloat16)
+    check(lib.mvf_pack_conv_weight(P(wt), 64, 64, 3, 3, 3, 64, None, P(wpk), 1, None))
+    check(lib.mvf_pack_conv_weight_dgrad(P(wt), 64, 64, 3, 3, P(wdg), 1, None))
+    m = n * h * w
+    zb = torch.randn(m, 64, device="cuda", generator=g).bfloat16()
+    mu, rs = torch.randn(64, device="cuda", generator=g) * 0.1, torch.rand(64, device="cuda", generator=g) + 0.5
+    sc, sh = torch.randn(64, device="cuda", generator=g), torch.randn(64, device="cuda", generator=g) * 0.3
+    d = _lib.ConvDesc(n, h, w, 64, 64, 3, 3, 1, 1, h, w, 64, 1, 0, 0, 0, 0, 0)
+    rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+    z = torch.full((m, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dx = torch.full((m, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+    part = torch.full((64, rows, 2), float("nan"), device="cuda")
+    sums = torch.full((64, rows, 2), float("nan"), device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd_stats(C.byref(d), P(xw), None, P(wpk), P(z), P(part), P(shift), None, 0, None))
+    check(lib.mvf_conv2d_nhwc_dgrad_bnsums(C.byref(d), P(xw), P(wdg), P(dx), P(zb), P(mu), P(rs), P(sc), P(sh), P(sums), None, 0, None))
+    torch.cuda.synchronize()
+    assert torch.isfinite(z.float()).all() and torch.isfinite(dx.float()).all() and torch.isfinite(part).all() and torch.isfinite(sums).all()
+    wb = wt.bfloat16().float().cpu()
+    for f in (0, 1, 127, 128, 255):
+        xf = xw[f].float().cpu().permute(2, 0, 1)[None]
+        ref = F.conv2d(xf, wb, padding=1)[0].permute(1, 2, 0).numpy()
+        ref_d = F.conv_transpose2d(xf, wb, padding=1)[0].permute(1, 2, 0).numpy()
+        assert rel_err(z.view(n, h, w, 64)[f].float().cpu().numpy(), ref) < 6e-3, f
+        assert rel_err(dx.view(n, h, w, 64)[f].float().cpu().numpy(), ref_d) < 6e-3, f
+    dz = z.double() - shift.double()
+    st = part.double().sum(1)
+    assert rel_err(st[:, 0].cpu().numpy(), dz.sum(0).cpu().numpy()) < 1e-4 and rel_err(st[:, 1].cpu().numpy(), (dz * dz).sum(0).cpu().numpy()) < 1e-5
+    gm = dx.double() * ((zb.float() * sc + sh) > 0)
+    bs = sums.double().sum(1)
+    assert rel_err(bs[:, 0].cpu().numpy(), gm.sum(0).cpu().numpy()) < 1e-4
+    assert rel_err(bs[:, 1].cpu().numpy(), (gm * ((zb.float() - mu) * rs).double()).sum(0).cpu().numpy()) < 1e-4
+
+
 @pytest.mark.parametrize("shape", [(3, 64, 64), (2, 32, 32), (1, 48, 80), (2, 224, 224)], ids=lambda s: "n%d_%dx%d" % s)
 def test_stem_direct_conv_vs_oracle_and_the_implicit_gemm(shape):
     """[r3] The bf16 stem (resnet.py:420-431 conv1) runs on its own direct kernel (csrc/stem_direct.hip: input patch staged once, weights in
