@@ -312,6 +312,14 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
                                    "+ the pointwise conv's weight gradient in one pass; the slab reduces run on the side stream", "bn_wgrad")
     for k, g in groups.items():
         r[k] = g
+    if "bn_wgrad" in groups:
+        # the paired fused launches run their reduce pass (bn_bwd_reduce2_kernel) inside the bracket, so their algorithmic bytes sit under bn_wgrad
+        # while the counters file that kernel under bn: the two groups together are the comparable pair
+        tb, tf_ = groups["bn"].get("traffic_per_step"), groups["bn_wgrad"].get("traffic_per_step")
+        ab = groups["bn"]["alg_bytes_per_step"] + groups["bn_wgrad"]["alg_bytes_per_step"]
+        r["bn_and_bn_wgrad"] = {"alg_bytes_per_step": ab, "traffic_per_step": (tb + tf_) if (tb and tf_) else None,
+                                "traffic_over_algorithmic": round((tb + tf_) / ab, 3) if (tb and tf_ and ab) else None,
+                                "ms_per_step": round(groups["bn"]["ms_per_step"] + groups["bn_wgrad"]["ms_per_step"], 3)}
     # whole step against the fully fused floor: every conv input / output read / written exactly once, forward + two backward GEMMs
     from mvfnet_amd.arch import fused_activation_elems_per_image
     clips, t = imgs.shape[0], imgs.shape[1]
