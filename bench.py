@@ -45,6 +45,8 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MF
 # MFMA): their ceiling in fp32-EQUIVALENT flops is the bf16 peak / 6.  The fp32 weight gradients keep the fp32 MFMA (157.3).
 F32_X3 = os.environ.get("MVF_F32_X3", "1") != "0"
 F32_CONV_PEAK = PEAK_TFLOPS["bf16"] / 6.0 if F32_X3 else PEAK_TFLOPS["f32"]
+# the fp32 weight gradients likewise ([r4] wgrad_x3_kernel; MVF_WGRAD_X3=0 = the fp32 MFMA kernel)
+F32_WGRAD_PEAK = PEAK_TFLOPS["bf16"] / 6.0 if (F32_X3 and os.environ.get("MVF_WGRAD_X3", "1") != "0") else PEAK_TFLOPS["f32"]
 VIDEO = False
 T_FRAMES, SIZE = 8, 224     # overwritten from --frames / --mode video in main()
 
@@ -284,7 +286,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
             eng.backward()
             torch.cuda.synchronize()
             for k, t in timers:
-                tot[k] = [a + b for a, b in zip(tot[k], _summ(t.rec, per_layer and i == reps - 1, k, F32_CONV_PEAK if (dtype == "f32" and k == "igemm") else PEAK_TFLOPS[dtype]))]
+                tot[k] = [a + b for a, b in zip(tot[k], _summ(t.rec, per_layer and i == reps - 1, k, (F32_CONV_PEAK if k == "igemm" else F32_WGRAD_PEAK if k == "wgrad" else PEAK_TFLOPS[dtype]) if dtype == "f32" else PEAK_TFLOPS[dtype]))]
             rec = [r_ for r_ in tc.rec if r_[3].startswith(RECOMPUTE_TAGS)]
             req = [r_ for r_ in tc.rec if not r_[3].startswith(RECOMPUTE_TAGS)]
             tot["igemm_recompute"] = [a + b for a, b in zip(tot["igemm_recompute"], _summ(rec, False, "", PEAK_TFLOPS[dtype]))]
@@ -304,7 +306,8 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
     # BatchNorm passes that moved MORE bytes; `required` is the like-for-like family (one forward + one data gradient per conv).
     r["required"] = _roof(tot["igemm_required"], reps, dtype, ovh, kernel="forward convs (incl. statistics-only first passes) + data gradients: one each per conv", peak_tf=cpeak)
     r["recompute"] = _roof(tot["igemm_recompute"], reps, dtype, ovh, kernel="conv3 second passes: fwd+bn (bn3 apply + residual + ReLU), bwd-sums, bwd-apply (z3-free blocks)", peak_tf=cpeak)
-    groups = {"wgrad": _roof(tot["wgrad"], reps, dtype, ovh, key, "wgrad_*_kernel + wgrad_reduce_kernel (csrc/wgrad_nhwc.hip) [+ the fused BatchNorm-backward-apply + weight-gradient kernels, csrc/bnbwd_wgrad.hip, where the step uses them]", "wgrad"),
+    groups = {"wgrad": _roof(tot["wgrad"], reps, dtype, ovh, key, "wgrad_*_kernel + wgrad_reduce_kernel (csrc/wgrad_nhwc.hip) [+ the fused BatchNorm-backward-apply + weight-gradient kernels, csrc/bnbwd_wgrad.hip, where the step uses them]", "wgrad",
+                              peak_tf=(F32_WGRAD_PEAK if dtype == "f32" else None)),
               "bn": _roof(tot["bn"], reps, dtype, ovh, key, "bn_apply / bn_bwd_reduce / bn_bwd_apply kernels (csrc/train_ops.hip)", "bn"),
               "mvf": _roof(tot["mvf"], reps, dtype, ovh, key, "mvf_nhwc_apply (stencil and transposed stencil, csrc/mvf_nhwc.hip)", "mvf")}
     if tot["bnwg"][3]:

@@ -466,6 +466,191 @@ __global__ __launch_bounds__(WMG * 128) void wgrad_bf16_kernel(WgArgs a) {
     }
 }
 
+// ---- [r4] fp32 operands on the BF16 matrix cores with fp32 accuracy (the weight-gradient side of conv_nhwc.hip's X3) -------------------
+// Every fp32 value of dz and x is split exactly into three bf16 terms (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid): both
+// differences are exactly representable in fp32) on its way from the staging registers into LDS, one [pixel][channel] bf16 image per term in
+// wgrad_bf16_kernel's swizzled layout; the contraction is the six partial products of total order <= 2 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi,
+// mid.mid -- what is dropped is below 2^-24 of |dz||x|), smallest first, accumulated in fp32 by v_mfma_f32_32x32x16_bf16 through the same
+// transpose reads.  6 matrix instructions at 16x the fp32 instruction's rate = 2.7x its ceiling; the loop carries ~22 VALU operations per
+// float4 for the split, so it is a register-staged single-buffer kernel at three workgroups per CU (48 KB of planes each) whose neighbours
+// fill each other's split / barrier phases, as in conv_tile.  A chunk = 32 pixels = 2 k-steps.
+constexpr int BMRX = 32;
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 3) void wgrad_x3_kernel(WgArgs a) {
+    constexpr int kThreads = 256;
+    constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
+    constexpr int PA = BCO * 2, PB = BK * 2;                        // plane row pitches in bytes
+    constexpr int UA = BCO / 8, UB = BK / 8;                        // 16-B units per plane row
+    constexpr int QA = BCO / 4, QB = BK / 4;                        // float4 units per fp32 row
+    constexpr int NA = BMRX * QA / kThreads, NB = BMRX * QB / kThreads;
+    __shared__ __attribute__((aligned(16))) char Ds[3 * BMRX * PA];      // [plane][pixel][BCO bf16]
+    __shared__ __attribute__((aligned(16))) char Xs[3 * BMRX * PB];
+    int wg_tile, wg_split;
+    if (!wg_map(a.tiles, a.nsplit, wg_tile, wg_split, a.xcd_rr)) return;
+    const int tile_k = wg_tile % a.tiles_k, tile_co = wg_tile / a.tiles_k;
+    const int co0 = tile_co * BCO, k0 = tile_k * BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int qa = tid % QA, ra0 = tid / QA, qb = tid % QB, rb0 = tid / QB;
+    const int co = co0 + qa * 4;
+    const bool co_ok = co < a.Cout;
+    const int kcol = k0 + qb * 4;
+    const bool k_ok = kcol < a.K;
+    const int tap = k_ok ? kcol / a.Cin : 0;
+    const int ci = k_ok ? kcol - tap * a.Cin : 0;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const bool from2 = a.split_c > 0 && ci < a.split_c;
+    const float* xb = reinterpret_cast<const float*>(from2 ? a.x2 : a.x);
+    const float* dzp = reinterpret_cast<const float*>(a.dz);
+    const int ps = from2 ? a.x2ps : a.xps;
+
+    const int m_begin = wg_split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nchunks = (m_end - m_begin + BMRX - 1) / BMRX;
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned kOOB = 0x80000000u;
+    const int hw_o = a.Ho * a.Wo;
+    // dz: buffer loads relative to the split's first row (rows past the split / channel tails are out of range = zeros); x: flat loads,
+    // branch-free (padding / out-of-range taps read the tensor base and are zeroed before the split), as in wgrad_bf16_kernel
+    const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(dzp + (long)m_begin * a.Cout), 0, (unsigned)min((long)(m_end - m_begin) * a.Cout * 4, 0x7ffffff0L), 0x00020000);
+    uint4 sd[NA], sx[NB];
+    unsigned okx = 0u;
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = c * BMRX + ra0 + (kThreads / QA) * i;
+            const unsigned off = co_ok ? (unsigned)(r * a.Cout + co) * 4u : kOOB;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_dz, off, 0, 0);
+            sd[i] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+        okx = 0u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int m = m_begin + c * BMRX + rb0 + (kThreads / QB) * i;
+            const int img = wg_fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * hw_o;
+            const int oh = wg_fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
+            const int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+            const bool ok = m < m_end && k_ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const long off = ok ? ((long)((img * a.H + ih) * a.W + iw) * ps + ci) : 0L;
+            sx[i] = *reinterpret_cast<const uint4*>(xb + off);
+            okx |= ok ? (1u << i) : 0u;
+        }
+    };
+    // hi / mid / lo bf16 terms of four fp32 values, 8 bytes per plane (conv_tile's split3: scalar v_sub_f32 through asm -- packed fp32 VALU
+    // beside matrix instructions is an anti-lever on this chip)
+    auto split3 = [&](const uint4& v, uint2 (&pl)[3]) {
+        float r[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned lo2 = pack_bf16x2(r[0], r[1]), hi2 = pack_bf16x2(r[2], r[3]);
+            pl[p] = make_uint2(lo2, hi2);
+            if (p < 2) {
+                auto sub1 = [](float x, float y) { float d; asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+                r[0] = sub1(r[0], __uint_as_float(lo2 << 16)); r[1] = sub1(r[1], __uint_as_float(lo2 & 0xffff0000u));
+                r[2] = sub1(r[2], __uint_as_float(hi2 << 16)); r[3] = sub1(r[3], __uint_as_float(hi2 & 0xffff0000u));
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = ra0 + (kThreads / QA) * i;
+            uint2 pl[3];
+            split3(sd[i], pl);
+            char* d = Ds + row * PA + ((((qa >> 1) ^ swz16<UA>(row)) << 4) | ((qa & 1) << 3));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * BMRX * PA) = pl[p];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = rb0 + (kThreads / QB) * i;
+            const bool ok = (okx >> i) & 1u;
+            const uint4 v = sx[i];
+            uint2 pl[3];
+            split3(make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u), pl);
+            char* d = Xs + row * PB + ((((qb >> 1) ^ swz16<UB>(row)) << 4) | ((qb & 1) << 3));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * BMRX * PB) = pl[p];
+        }
+    };
+    // transpose reads exactly as in wgrad_bf16_kernel (same images, one per plane)
+    const int tg = lane >> 4, ti = lane & 15;
+    const int trow = (ti >> 2) + 8 * (tg >> 1);
+    const int tunit = 2 * (tg & 1) + ((ti & 3) >> 1), thalf = ti & 1;
+    int offA[TM], offB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offA[i] = trow * PA + ((((wm * TM + i) * 4 + tunit) ^ swz16<UA>(trow)) * 16) + thalf * 8;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offB[j] = trow * PB + ((((wn * TN + j) * 4 + tunit) ^ swz16<UB>(trow)) * 16) + thalf * 8;
+    auto gather = [&](const char* p, int pitch) {
+        typedef short v4s __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s* lds_v4s;
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p + 4 * pitch));
+        bf16x8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return v;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < BMRX / 16; ++ks) {
+            bf16x8_t fa[3][TM], fb[3][TN];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[p][i] = gather(Ds + (p * BMRX + ks * 16) * PA + offA[i], PA);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[p][j] = gather(Xs + (p * BMRX + ks * 16) * PB + offB[j], PB);
+            }
+            // the product term is the OUTER loop (consecutive matrix instructions on different accumulators), smallest terms first
+            constexpr int PA_[6] = {0, 2, 1, 0, 1, 0}, PB_[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA_[t]][i], fb[PB_[t]][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // one chunk ahead in registers; the loads are unconditional (rows >= m_end read zeros / the tensor base) so that the compiler's static
+    // s_waitcnt counts stay exact
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        store_chunk();
+        __syncthreads();
+        load_chunk(c + 1);
+        compute();
+        __syncthreads();
+    }
+    const int lr = lane >> 5, lc = lane & 31;
+    float* out = a.part + (long)wg_split * a.Cout * a.K;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = k0 + (wn * TN + j) * 32 + lc;
+        if (col >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
+                if (row < a.Cout) out[(long)row * a.K + col] = acc[i][j][r];
+            }
+    }
+}
+
 // ---- the 256 x 256 weight-gradient tile on the four-phase ping-pong loop (conv_nhwc.hip, conv_tile GLDS = 4; probe: tools/probes/gemm8p_probe.hip) ----
 // Same machine as the conv kernel with the roles A := im2col(X) columns (4 fragments of 32 per wave), B := dZ columns (2 fragments per wave):
 // 8 waves = 4 (co) x 2 (k), two groups (waves 0-3 / 4-7: one wave of each per SIMD) one barrier apart; a chunk = 64 pixels = 4 MFMA k-steps.
@@ -985,7 +1170,16 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     }
     a.tiles_k = (a.K + t.bk - 1) / t.bk;
     const int tiles = ((d->cout + t.bco - 1) / t.bco) * a.tiles_k;
-    a.rows_per_split = big ? wg_big_rows(d) : plan_split(a.M, tiles);
+    // [r4] fp32 storage on the bf16 matrix cores (wgrad_x3_kernel): on with the conv kernels' switch (MVF_F32_X3 != 0) unless MVF_WGRAD_X3=0.
+    // Three workgroups per CU = 768 slots: the pixel split aims at one full round of them (1024 / 1536 / 2304: 3185 / 3218 / 3308 us over the
+    // twelve C3 shapes against 3115), unless MVF_WGRAD_WGS says otherwise
+    static const int x3_env = (getenv("MVF_F32_X3") ? atoi(getenv("MVF_F32_X3")) != 0 : 1) && (getenv("MVF_WGRAD_X3") ? atoi(getenv("MVF_WGRAD_X3")) != 0 : 1);
+    bool x3 = d->dtype == MVF_F32 && x3_env && d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride % 4 == 0 && d->split_c % 4 == 0 &&
+              (d->x2_pix_stride % 4 == 0 || !d->split_c) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0;
+    static const bool wgs_forced = getenv("MVF_WGRAD_WGS") != nullptr;
+    a.rows_per_split = big ? wg_big_rows(d) : plan_split(a.M, tiles, x3 && !wgs_forced ? 768 : 0);
+    x3 = x3 && ((long)a.rows_per_split + 64) * d->cout * 4 < 0x7ffffff0L;
+    if (d->dtype == MVF_F32 && !x3 && !wgs_forced) a.rows_per_split = plan_split(a.M, tiles);
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
     a.tiles = tiles;
     a.nsplit = nsplit;
@@ -1004,7 +1198,11 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
                        (a.split_c == 0 || (a.split_c % t.bk == 0 && a.Cin % t.bk == 0)) &&
                        ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
                        (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 4 < 0x7ffffff0L && ((long)a.rows_per_split + 64) * d->cout * 4 < 0x7ffffff0L;
-    if (dma32) {
+    if (x3) {
+        if (t.bco == 64) hipLaunchKernelGGL((wgrad_x3_kernel<1, 2>), dim3(nsplit * tiles), dim3(256), 0, st, a);
+        else if (t.bk == 64) hipLaunchKernelGGL((wgrad_x3_kernel<2, 1>), dim3(nsplit * tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_x3_kernel<2, 2>), dim3(nsplit * tiles), dim3(256), 0, st, a);
+    } else if (dma32) {
         if (t.bco == 64) hipLaunchKernelGGL((wgrad_kernel<float, 1, 2, true>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
         else if (t.bk == 64) hipLaunchKernelGGL((wgrad_kernel<float, 2, 1, true>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
         else hipLaunchKernelGGL((wgrad_kernel<float, 2, 2, true>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);

@@ -1051,19 +1051,74 @@ def test_process_group_does_not_cost_the_stream_overlap():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2", "MVF_WGRAD_DMA_F32=0", "MVF_WGRAD_P4=0", "MVF_WGRAD_BIG=0"],
-                         ids=["register_staged_wgrad", "lds_dma_wgrad_everywhere", "register_staged_wgrad_f32", "big_tile_two_barrier_loop", "no_big_tile"])
+@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2", "MVF_WGRAD_X3=0,MVF_WGRAD_DMA_F32=0", "MVF_WGRAD_P4=0", "MVF_WGRAD_BIG=0", "MVF_WGRAD_X3=0"],
+                         ids=["register_staged_wgrad", "lds_dma_wgrad_everywhere", "register_staged_wgrad_f32", "big_tile_two_barrier_loop", "no_big_tile",
+                              "fp32_mfma_wgrad_lds_dma"])
 def test_wgrad_loader_variants_forced_by_env(env):
     """The weight-gradient loader choice is a per-process policy; both forced settings re-run this file's gradient comparisons
     (conv weight gradients vs the oracle, whole-network goldens) in a child process."""
     import os
     import subprocess
     import sys
-    k, v = env.split("=")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
                         "conv_dgrad_wgrad or c1_train or norm_eval_training or bottleneck_train or stem_wgrad", "-p", "no:cacheprovider"],
-                       env=dict(os.environ, **{k: v}), capture_output=True, text=True, timeout=900)
+                       env=dict(os.environ, **dict(kv.split("=") for kv in env.split(","))), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+_WX3_CHILD = r"""
+import ctypes as C, sys, numpy as np, torch
+from mvfnet_amd import _lib
+lib, check = _lib.lib, _lib.check
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+out = {}
+for (n, h, cin, cout, k, stride) in SHAPES:
+    gen = torch.Generator().manual_seed(cin + cout + k)
+    ho = (h + 2 * (k // 2) - k) // stride + 1
+    x = torch.randn(n, h, h, cin, generator=gen).cuda()
+    dz = torch.randn(n, ho, ho, cout, generator=gen).cuda()
+    d = _lib.ConvDesc(n, h, h, cin, cout, k, k, stride, k // 2, ho, ho, cin, 0, 0, 0, 0, 0)
+    ws = torch.empty(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device="cuda")
+    dw = torch.empty(cout, cin, k, k, device="cuda")
+    check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), p(dz), p(x), None, k, cin, k, cin, p(dw), p(ws), ws.numel(), None))
+    torch.cuda.synchronize()
+    out["%d_%d_%d_%d" % (cin, cout, k, stride)] = dw.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+# (n, h, cin, cout, k, stride): pointwise long / short contraction, 64-wide tiles on either side, 3x3 with padding taps, stride 2, ragged channel tails
+_WX3_SHAPES = [(16, 14, 256, 1024, 1, 1), (4, 28, 64, 256, 1, 1), (4, 28, 256, 64, 1, 1), (4, 14, 128, 128, 3, 1), (3, 13, 64, 96, 3, 2), (2, 9, 132, 36, 3, 1)]
+
+
+@pytest.mark.gpu
+def test_fp32_weight_gradient_on_the_bf16_matrix_cores_is_as_accurate_as_the_fp32_mfma(tmp_path):
+    """[r4] wgrad_x3_kernel (the default fp32 weight gradient): dz and x are split exactly into three bf16 terms each on their way into LDS and the
+    contraction over pixels is six partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Against an fp64 weight gradient of the
+    same operands the error must be the fp32 ACCUMULATION error -- no larger than what the exact-fp32 MFMA kernel (MVF_WGRAD_X3=0, run in a
+    child process: the switch is read once per process) leaves -- over contractions of 196 ... 3136 pixels per split."""
+    import os
+    import subprocess
+    import sys
+    src = "SHAPES = %r\n" % (_WX3_SHAPES,) + _WX3_CHILD
+    res = {}
+    for tag, val in (("x3", "1"), ("mfma", "0")):
+        f = str(tmp_path / (tag + ".npz"))
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MVF_WGRAD_") and k != "MVF_F32_X3"}
+        env.update(MVF_WGRAD_X3=val, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", src, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(f)
+    for (n, h, cin, cout, k, stride) in _WX3_SHAPES:
+        gen = torch.Generator().manual_seed(cin + cout + k)
+        ho = (h + 2 * (k // 2) - k) // stride + 1
+        x = torch.randn(n, h, h, cin, generator=gen).double().permute(0, 3, 1, 2)
+        dz = torch.randn(n, ho, ho, cout, generator=gen).double().permute(0, 3, 1, 2)
+        ref = torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), dz, stride=stride, padding=k // 2).numpy()
+        key = "%d_%d_%d_%d" % (cin, cout, k, stride)
+        e3 = np.linalg.norm(res["x3"][key] - ref) / np.linalg.norm(ref)
+        e1 = np.linalg.norm(res["mfma"][key] - ref) / np.linalg.norm(ref)
+        assert not np.array_equal(res["x3"][key], res["mfma"][key])           # (two different kernels did run)
+        assert e3 < 2e-6 and e3 < 1.5 * e1 + 2e-8, (key, e3, e1)
+        assert np.abs(res["x3"][key] - ref).max() / np.abs(ref).max() < 2e-6
 
 
 # ------------------------------------------------------------------------------------------------ round 2: optimizer wire format, runner shell

@@ -182,6 +182,34 @@ def bench_bnwg():
             name, m, c, k, ta, tw, ta + tw, tf, tr, ns, by_f / tf / 1e6, ta + tw - tf - tr))
 
 
+def bench_wgrad(dt=0, only=None):
+    """Single weight-gradient launches (kernel + slab reduce) at the C3 shapes, fp32 by default (`wgrad` / `wgrad16`); A/B the fp32 kernels
+    with MVF_WGRAD_X3=0 (the exact-fp32 MFMA kernel) against the default (three-term bf16 splits on the bf16 matrix cores)."""
+    from mvfnet_amd._lib import ConvDesc
+    tdt = torch.bfloat16 if dt else torch.float32
+    dev = "cuda"
+    shapes = [("l1.c1", 56, 256, 64, 1), ("l1.c2", 56, 64, 64, 3), ("l1.c3", 56, 64, 256, 1), ("l2.c1", 28, 512, 128, 1), ("l2.c2", 28, 128, 128, 3),
+              ("l2.c3", 28, 128, 512, 1), ("l3.c1", 14, 1024, 256, 1), ("l3.c2", 14, 256, 256, 3), ("l3.c3", 14, 256, 1024, 1),
+              ("l4.c1", 7, 2048, 512, 1), ("l4.c2", 7, 512, 512, 3), ("l4.c3", 7, 512, 2048, 1)]
+    n = int(os.environ.get("KBENCH_FRAMES", "256"))
+    tot = 0.0
+    for name, hw, cin, cout, k in shapes:
+        if only and only not in name:
+            continue
+        m = n * hw * hw
+        d = ConvDesc(n, hw, hw, cin, cout, k, k, 1, k // 2, hw, hw, cin, dt, 0, 0, 0, 0, 0)
+        x = torch.randn(m, cin, device=dev).to(tdt)
+        dz = torch.randn(m, cout, device=dev).to(tdt)
+        ws = torch.empty(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+        dw = torch.empty(cout, cin, k, k, device=dev)
+        fn = lambda: check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), P(dz), P(x), None, k, cin, k, cin, P(dw), P(ws), ws.numel(), None))  # noqa: E731
+        t = timeit(fn, reps=20, warm=3)
+        fl = 2.0 * m * cout * k * k * cin
+        tot += t
+        print("%-6s M%-7d K%-5d N%-5d %8.1f us  %6.1f TF/s" % (name, m, k * k * cin, cout, t, fl / t / 1e6))
+    print("sum %.1f us" % tot)
+
+
 def bench_mvf():
     """[r4] The engine's MVF stencil (mvf_nhwc_stencil: plain, and transposed + gated addend as the backward runs it) on the layer3 / layer4 shapes,
     reading its slice (a) where it lies today -- the first cs channels of every c-channel pixel row (256 B of every 2 KB) -- and (b) from a COMPACT
@@ -217,6 +245,9 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "bn"
     if what == "mvf":
         bench_mvf()
+        sys.exit(0)
+    if what in ("wgrad", "wgrad16"):
+        bench_wgrad(1 if what == "wgrad16" else 0, sys.argv[2] if len(sys.argv) > 2 else None)
         sys.exit(0)
     if what == "bnwg":
         bench_bnwg()
