@@ -964,10 +964,71 @@ int launch_wgrad_bf16_big(const WgArgs& a, int tiles, int nsplit, hipStream_t st
 }
 
 // dW_oihw[co][ci][kh][kw] = sum_s part[s][co][(kh*KWP + kw)*CINP + ci]   (KWP/CINP = packed extents; stem: 8 / 4)
+// [r4] EXPERIMENT, off (MVF_WGRAD_REDUCE4=1 turns it on, n > 1 forces n split-lanes).  In the profile of the overlapped bf16 step the reduce is the largest
+// single kernel (53 launches x 37.7 us = 2.0 ms: 1.7 TB/s over 3.4 GB of slabs), which reads like a slow kernel: 4-byte loads, four per
+// thread in flight.  This form gives a thread FOUR consecutive packed elements (16-byte loads, 1 KB of a slab row per wave instruction), four
+// independent accumulators over its share of the splits, and SL split-lanes per workgroup combined by a fixed LDS tree (host-chosen so that
+// a launch has >= 1024 workgroups even for layer1's 16 K-element gradients with 512 splits; deterministic, no atomics).  Measured: alone the
+// two forms take the same time (the slabs were written a moment ago and come from L2 / MALL: wgrad + reduce over the twelve C3 shapes 964.8 vs
+// 963.5 us) -- the 37.7 us are contention with the launch stream, not the access pattern -- and IN the step the wider loads take more from
+// the launch stream's kernels than they give back: 19.93 vs 20.02 ms (three alternations, every pair the same sign); fp32 52.75 vs 52.78.
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
+                                                           float* dw) {
+    constexpr int Q = 256 / SL;                       // quads (4 elements) per workgroup
+    __shared__ float4 red[SL > 1 ? 256 : 1];
+    const long K = (long)kh * kwp * cinp;
+    const long total = (long)cout * K;
+    const int q = threadIdx.x % Q, sl = threadIdx.x / Q;
+    const long i = ((long)blockIdx.x * Q + q) * 4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    if (i < total) {
+        const float* p = part + i;
+        int k = sl;
+        for (; k + 3 * SL < nsplit; k += 4 * SL) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p + (long)k * total);
+            const float4 v1 = *reinterpret_cast<const float4*>(p + (long)(k + SL) * total);
+            const float4 v2 = *reinterpret_cast<const float4*>(p + (long)(k + 2 * SL) * total);
+            const float4 v3 = *reinterpret_cast<const float4*>(p + (long)(k + 3 * SL) * total);
+            add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
+        }
+        for (; k < nsplit; k += SL) add(s0, *reinterpret_cast<const float4*>(p + (long)k * total));
+    }
+    add(s0, s1); add(s2, s3); add(s0, s2);
+    if constexpr (SL > 1) {
+        red[threadIdx.x] = s0;
+        __syncthreads();
+#pragma unroll
+        for (int w = SL / 2; w >= 1; w >>= 1) {
+            if (sl < w) {
+                float4 a = red[threadIdx.x];
+                add(a, red[threadIdx.x + w * Q]);
+                red[threadIdx.x] = a;
+            }
+            __syncthreads();
+        }
+        s0 = red[q];
+    }
+    if (sl != 0 || i >= total) return;
+    if (kh * kwp == 1 && cin == cinp) {               // pointwise: the packed layout IS the parameter's
+        *reinterpret_cast<float4*>(dw + i) = s0;
+        return;
+    }
+    const float v[4] = {s0.x, s0.y, s0.z, s0.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        long t = i + e;
+        const int ci = (int)(t % cinp); t /= cinp;
+        const int x = (int)(t % kwp); t /= kwp;
+        const int y = (int)(t % kh);
+        const int co = (int)(t / kh);
+        if (ci < cin && x < kw) dw[(((long)co * cin + ci) * kh + y) * kw + x] = v[e];
+    }
+}
+// the default form (one element per thread, four split-lanes)
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
                                     float* dw) {
-    // 64 consecutive packed elements x 4 split-lanes per workgroup: coalesced 256-B reads of every partial slab, four
-    // independent accumulators per lane for memory-level parallelism, fixed summation order (deterministic)
     __shared__ float red[4][64];
     const long K = (long)kh * kwp * cinp;
     const long total = (long)cout * K;
@@ -994,6 +1055,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
         const int co = (int)(t / kh);
         if (ci < cin && x < kw) dw[(((long)co * cin + ci) * kh + y) * kw + x] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
+}
+int launch_wgrad_reduce(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp, float* dw, hipStream_t st) {
+    static const int r4 = getenv("MVF_WGRAD_REDUCE4") ? atoi(getenv("MVF_WGRAD_REDUCE4")) : 0;
+    const long total = (long)cout * kh * kwp * cinp;
+    if (!r4 || total % 4 || ((uintptr_t)part | (uintptr_t)dw) % 16) {
+        hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, part, nsplit, cout, cin, kh, kw, kwp, cinp, dw);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
+    const long quads = total / 4;
+    int sl = 1;                                        // split-lanes: >= 1024 workgroups, at least two splits per lane
+    while (sl < 32 && quads * sl / 256 < 1024 && 4 * sl <= nsplit) sl *= 2;
+    if (r4 > 1) sl = std::min(32, r4);                 // (A/B: MVF_WGRAD_REDUCE4=2 / 4 / ... forces the lane count)
+    const int blocks = (int)((quads * sl + 255) / 256);
+#define MVF_RED(SLV) hipLaunchKernelGGL(wgrad_reduce_kernel<SLV>, dim3(blocks), dim3(256), 0, st, part, nsplit, cout, cin, kh, kw, kwp, cinp, dw)
+    switch (sl) {
+        case 1: MVF_RED(1); break;
+        case 2: MVF_RED(2); break;
+        case 4: MVF_RED(4); break;
+        case 8: MVF_RED(8); break;
+        case 16: MVF_RED(16); break;
+        default: MVF_RED(32); break;
+    }
+#undef MVF_RED
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
 }
 
 template <typename ET>
@@ -1102,10 +1189,7 @@ namespace mvf_internal {
 // the fixed-order sum of [nsplit][cout][k] fp32 partial slabs of a pointwise conv's weight gradient into dw (cout, k, 1, 1): the tail of
 // mvf_conv2d_nhwc_wgrad, also behind the fused BatchNorm-backward + weight-gradient kernels (bnbwd_wgrad.hip)
 int wgrad_slab_reduce_launch(const float* part, int nsplit, int cout, int k, float* dw_oihw, hipStream_t st) {
-    const long total = (long)cout * k;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, part, nsplit, cout, k, 1, 1, 1, k, dw_oihw);
-    MVF_LAUNCH_CHECK();
-    return MVF_OK;
+    return launch_wgrad_reduce(part, nsplit, cout, k, 1, 1, 1, k, dw_oihw, st);
 }
 }  // namespace mvf_internal
 
@@ -1225,12 +1309,8 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
         else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 2>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
     }
     MVF_LAUNCH_CHECK();
-    const long total = (long)d->cout * d->kh * d->kw * d->cin;
     const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, a.part, nsplit,
-                       d->cout, cin_real, kh_p, kw_real, kw_packed, cin_packed, dw_oihw);
-    MVF_LAUNCH_CHECK();
-    return MVF_OK;
+    return launch_wgrad_reduce(a.part, nsplit, d->cout, cin_real, kh_p, kw_real, kw_packed, cin_packed, dw_oihw, st);
 }
 
 int mvf_pack_conv_weights_batched(const mvf_pack_job_t* jobs_dev, int njobs, int total_blocks, int dtype, void* stream) {

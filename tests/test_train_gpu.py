@@ -1051,9 +1051,9 @@ def test_process_group_does_not_cost_the_stream_overlap():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2", "MVF_WGRAD_X3=0,MVF_WGRAD_DMA_F32=0", "MVF_WGRAD_P4=0", "MVF_WGRAD_BIG=0", "MVF_WGRAD_X3=0"],
+@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2", "MVF_WGRAD_X3=0,MVF_WGRAD_DMA_F32=0", "MVF_WGRAD_P4=0", "MVF_WGRAD_BIG=0", "MVF_WGRAD_X3=0", "MVF_WGRAD_REDUCE4=1"],
                          ids=["register_staged_wgrad", "lds_dma_wgrad_everywhere", "register_staged_wgrad_f32", "big_tile_two_barrier_loop", "no_big_tile",
-                              "fp32_mfma_wgrad_lds_dma"])
+                              "fp32_mfma_wgrad_lds_dma", "slab_reduce_16_byte_loads"])
 def test_wgrad_loader_variants_forced_by_env(env):
     """The weight-gradient loader choice is a per-process policy; both forced settings re-run this file's gradient comparisons
     (conv weight gradients vs the oracle, whole-network goldens) in a child process."""
