@@ -318,7 +318,10 @@ int mvf_head_train_bwd(const float* dscores, const float* pooled, const float* f
                        int hw, int c, int classes, float* dfc_w, float* dfc_b, float* dpool_ws /* clips*c */, void* dfeat, int dtype,
                        void* stream);
 /* conv weight gradient dw_oihw (cout, cin_real, kh, kw_real) fp32; d describes the FORWARD conv (x dims, ho/wo = dz dims).
- * kw_packed*cin_packed == d->kw*d->cin; they differ from (kw_real, cin_real) only for the stem view (8x4 vs 7x3). */
+ * kw_packed*cin_packed == d->kw*d->cin; they differ from (kw_real, cin_real) only for the stem view (8x4 vs 7x3).
+ * fp32 accumulation over the pixels in a fixed order (per-split partial tiles, then a split-lane reduce): deterministic, no atomics.  fp32
+ * operands are multiplied on the bf16 matrix cores as exact three-term bf16 splits, six partial products per product -- as accurate against
+ * an fp64 weight gradient as the exact-fp32 matrix instruction, which MVF_WGRAD_X3=0 (or MVF_F32_X3=0) selects. */
 size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d);
 int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real,
                           int cin_real, int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes,
