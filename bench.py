@@ -345,6 +345,7 @@ def eng_depth(eng):
 
 
 RECOMPUTE_TAGS = ("fwd+bn", "bwd-sums", "bwd-apply")     # launch tags (roofline_train) of the conv3 passes that recompute z3
+PMC_MATCHES_RUN = True    # main(): False unless the run IS the profiled workload (R50, 8 x 224^2 frames, 32 clips) -- the counters are static, per step of that one
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured ceiling)
 
 
@@ -353,7 +354,7 @@ def _pmc_traffic(pmc_key, group):
     from separate --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 FETCH correction).  STATIC: collected once per round on the
     round's final kernels, not in this run."""
     pmc = os.path.join(REPO, "profiles", "pmc_traffic_per_step.json")
-    if not (pmc_key and os.path.exists(pmc)):
+    if not (pmc_key and os.path.exists(pmc) and PMC_MATCHES_RUN):
         return None, None
     try:
         d = json.load(open(pmc)).get(pmc_key) or {}
@@ -640,6 +641,8 @@ def main():
     train = args.mode == "train"
     model = build_model(args.depth, args.dtype, train)
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    global PMC_MATCHES_RUN
+    PMC_MATCHES_RUN = args.depth == 50 and T_FRAMES == 8 and SIZE == 224 and args.clips == 32
     imgs = torch.randn(args.clips, T_FRAMES, 3, SIZE, SIZE, device="cuda", generator=gen)
     if video:
         imgs = imgs.reshape(1, args.clips * T_FRAMES, 3, SIZE, SIZE)      # [1, crops*clips*T, 3, 256, 256] as the test pipeline emits
