@@ -119,6 +119,13 @@ struct PwSumsArgs {
     float* part;                // [N][rows][2]
     int rows, mode, M, N, K, xps;
 };
+// weight gradient of the 64 -> 64 channel 3x3 stride-1 pad-1 conv as a direct kernel (wgrad3x3_c64.hip)
+struct Wgrad3x3C64Args {
+    const void* dz;             // (N, H, W, 64) bf16
+    const void* x;              // (N, H, W, xps >= 64) bf16, channels [0, 64)
+    float* part;                // [nwg][64][576] fp32 partial slabs (wgrad_reduce_kernel's layout: [co][(kh * 3 + kw) * 64 + ci])
+    int N, H, W, xps, nwg;
+};
 namespace mvf_internal {
 // BatchNorm backward apply fused with the pointwise conv's weight gradient (bnbwd_wgrad.hip); index 0 / 1 = the one or two BatchNorms
 // (1 = the downsample branch of a paired backward) that share g and the sign bits
@@ -139,6 +146,9 @@ bool bnbwd_wgrad_tile(int c, int k, int nbn, int mask_mode, int* ct, int* kt);
 int bnbwd_wgrad_plan(long m, int c, int k, int nbn, int mask_mode, int* rows_per_split, int* ctiles, int* ktiles);
 int bnbwd_wgrad_launch(const BnBwdWgradArgs& a, int nbn, int mask_mode, hipStream_t st);
 int wgrad_slab_reduce_launch(const float* part, int nsplit, int cout, int k, float* dw_oihw, hipStream_t st);
+bool wgrad3x3_c64_ok(int n, int h, int w, int xps);
+int wgrad3x3_c64_wgs(int n, int h);
+int wgrad3x3_c64_launch(const Wgrad3x3C64Args& a, hipStream_t st);
 int stem_direct_launch(const StemDirectArgs& a, hipStream_t st);
 int conv3x3_c64_launch(const Conv3x3C64Args& a, hipStream_t st);
 int pw_sums_launch(const PwSumsArgs& a, hipStream_t st);

@@ -1216,6 +1216,12 @@ static int wg_big_rows(const mvf_conv_desc_t* d) {
     return plan_split(M, (d->cout / 256) * (K / 256), big_wgs);
 }
 
+// [r4] layer1's 3x3 (64 -> 64 channels, stride 1, pad 1, bf16) on the direct kernel of wgrad3x3_c64.hip (MVF_WGRAD3X3_DIRECT=0: the implicit GEMM)
+static bool wg_direct3x3(const mvf_conv_desc_t* d) {
+    return d->dtype == MVF_BF16 && d->cin == 64 && d->cout == 64 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->split_c == 0 &&
+           d->ho == d->h && d->wo == d->w && mvf_internal::wgrad3x3_c64_ok(d->n, d->h, d->w, d->x_pix_stride);
+}
+
 size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
     if (!d || d->cout <= 0 || d->cin <= 0) return 0;
     const int M = d->n * d->ho * d->wo, K = d->kh * d->kw * d->cin;
@@ -1224,6 +1230,7 @@ size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
     const int rows = plan_split(M, tiles);
     int nsplit = (M + rows - 1) / rows;
     if (wg_big_shape(d)) nsplit = std::max(nsplit, (M + wg_big_rows(d) - 1) / wg_big_rows(d));
+    if (wg_direct3x3(d)) nsplit = std::max(nsplit, mvf_internal::wgrad3x3_c64_wgs(d->n, d->h));
     return align_up((size_t)nsplit * d->cout * K * sizeof(float), 256);
 }
 
@@ -1237,6 +1244,13 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     MVF_REQUIRE(kw_packed * cin_packed == d->kw * d->cin && kw_real <= kw_packed && cin_real <= cin_packed, MVF_EINVAL, "wgrad: packed extents inconsistent");
     MVF_REQUIRE(ws && ws_bytes >= mvf_conv2d_wgrad_workspace_bytes(d), MVF_EWS, "wgrad: workspace too small");
     if (d->split_c) MVF_REQUIRE(x2 && d->kh == 1 && d->kw == 1 && d->split_c % 4 == 0, MVF_EINVAL, "wgrad: bad split_c");
+    hipStream_t st0 = (hipStream_t)stream;
+    if (wg_direct3x3(d) && kw_real == 3 && cin_real == 64 && kw_packed == 3 && cin_packed == 64 && ((uintptr_t)dz | (uintptr_t)x) % 16 == 0) {
+        Wgrad3x3C64Args w = {dz, x, (float*)ws, d->n, d->h, d->w, d->x_pix_stride, mvf_internal::wgrad3x3_c64_wgs(d->n, d->h)};
+        const int rc = mvf_internal::wgrad3x3_c64_launch(w, st0);
+        if (rc != MVF_OK) return rc;
+        return launch_wgrad_reduce((const float*)ws, w.nwg, 64, 64, 3, 3, 3, 64, dw_oihw, st0);
+    }
     WgArgs a = {};
     a.dz = dz; a.x = x; a.x2 = x2; a.part = (float*)ws;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KH = d->kh; a.KW = d->kw;

@@ -321,7 +321,10 @@ GRAD_CASES = [(2, 8, 8, 64, 32, 1, 1, 0), (2, 9, 9, 32, 64, 3, 1, 1), (2, 10, 10
               (150, 1, 1, 64, 64, 1, 1, 0), (3, 2, 33, 64, 96, 3, 1, 1), (5, 13, 11, 128, 64, 3, 2, 1), (2, 20, 20, 64, 256, 1, 1, 0),
               # [r3] shapes of the 256 x 256 weight-gradient tile (cout % 256 == 0, K % 256 == 0, cin % 64 == 0): 6 / 7 / 11 pixel chunks incl.
               # ragged last ones, stride 2, more than one split (M = 1452 -> 256-row splits), 512-wide output
-              (4, 9, 9, 256, 512, 1, 1, 0), (7, 8, 8, 512, 256, 1, 1, 0), (2, 13, 11, 256, 256, 3, 2, 1), (12, 11, 11, 256, 256, 1, 1, 0)]
+              (4, 9, 9, 256, 512, 1, 1, 0), (7, 8, 8, 512, 256, 1, 1, 0), (2, 13, 11, 256, 256, 3, 2, 1), (12, 11, 11, 256, 256, 1, 1, 0),
+              # [r4] the direct 64 -> 64 channel 3x3 weight-gradient kernel (bf16; fp32 takes the implicit GEMM): the C3 frame size, a ragged last band
+              # (H % 4 != 0), narrow / tiny frames, more bands than workgroups (n = 40 frames of 56 rows = 560 bands on 512 workgroups)
+              (2, 56, 56, 64, 64, 3, 1, 1), (3, 7, 12, 64, 64, 3, 1, 1), (1, 5, 4, 64, 64, 3, 1, 1), (40, 56, 24, 64, 64, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("case", GRAD_CASES, ids=lambda c: "n%d_%dx%d_c%d_o%d_k%d_s%d" % c[:7])
@@ -1051,9 +1054,10 @@ def test_process_group_does_not_cost_the_stream_overlap():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2", "MVF_WGRAD_X3=0,MVF_WGRAD_DMA_F32=0", "MVF_WGRAD_P4=0", "MVF_WGRAD_BIG=0", "MVF_WGRAD_X3=0", "MVF_WGRAD_REDUCE4=1"],
+@pytest.mark.parametrize("env", ["MVF_WGRAD_DMA=0", "MVF_WGRAD_DMA=2", "MVF_WGRAD_X3=0,MVF_WGRAD_DMA_F32=0", "MVF_WGRAD_P4=0", "MVF_WGRAD_BIG=0", "MVF_WGRAD_X3=0", "MVF_WGRAD_REDUCE4=1",
+                                 "MVF_WGRAD3X3_DIRECT=0", "MVF_WGRAD3X3_R=4,MVF_WGRAD3X3_WGS=96"],
                          ids=["register_staged_wgrad", "lds_dma_wgrad_everywhere", "register_staged_wgrad_f32", "big_tile_two_barrier_loop", "no_big_tile",
-                              "fp32_mfma_wgrad_lds_dma", "slab_reduce_16_byte_loads"])
+                              "fp32_mfma_wgrad_lds_dma", "slab_reduce_16_byte_loads", "layer1_3x3_wgrad_on_the_implicit_gemm", "direct_3x3_wgrad_four_row_bands_96_workgroups"])
 def test_wgrad_loader_variants_forced_by_env(env):
     """The weight-gradient loader choice is a per-process policy; both forced settings re-run this file's gradient comparisons
     (conv weight gradients vs the oracle, whole-network goldens) in a child process."""

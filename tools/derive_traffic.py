@@ -14,7 +14,7 @@ import sys
 GROUPS = (
     ("conv", ("conv_igemm", "conv_streamk", "conv3x3_c64", "conv3x3_c128", "stem_direct", "pw_sums")),
     ("bn_wgrad", ("bnbwd_wgrad",)),                             # [r4] BatchNorm backward apply + pointwise weight gradient in one pass
-    ("wgrad", ("wgrad_",)),                                     # GEMMs + wgrad_reduce (the fp32 partial slabs are real traffic)
+    ("wgrad", ("wgrad_", "wgrad3x3")),                                   # GEMMs + wgrad_reduce (the fp32 partial slabs are real traffic)
     ("bn", ("bn_apply", "bn_bwd_apply", "bn_bwd_reduce", "bn_stats_kernel")),
     ("bn_finalize", ("bn_stats_finalize", "bn_bwd_finalize")),
     ("mvf", ("mvf_nhwc_apply", "mvf_nhwc_stencil")),
