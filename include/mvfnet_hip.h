@@ -285,6 +285,18 @@ int mvf_bn_bwd_pair_wgrad(const void* g, int g_pitch, const void* z_a, const voi
                           const float* gamma_b, const float* mean_b, const float* invstd_b, float* dgamma_b, float* dbeta_b,
                           void* dz_a, void* dz_b, const void* x_a, int xa_pitch, const void* x_b, int xb_pitch, int k,
                           float* slabs_a, float* slabs_b, size_t slab_bytes, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* [r4] The WHOLE backward of the last conv of a bottleneck that never stored its conv output (autograd of Bottleneck.forward, resnet.py:229-244:
+ * out = relu(bn3(conv3(a2)) + identity), a2 = relu(bn2(z2))) in ONE pass: the 64 -> 256 channel pointwise conv is recomputed per 64-pixel chunk,
+ * dz3 = gamma invstd (gm - dbeta / m - xhat dgamma / m) (gm = g gated by the block output's sign bits; bn3's dgamma / dbeta must be final) stays in
+ * LDS and is contracted three ways: the weight gradient (fp32 slabs [splits][256][64] for mvf_wgrad_slab_reduce), the data gradient
+ * dx = round_bf16(dz3 W) (m, 64), and the backward sums of bn2 over dx gated by scale2 z2 + shift2 > 0 (partial rows [64][sums_rows][2] for
+ * mvf_bn_bwd_finalize, sums_rows = 2 x splits).  Replaces mvf_conv2d_nhwc_fwd_bnbwd_apply + mvf_conv2d_nhwc_dgrad_bnsums + mvf_conv2d_nhwc_wgrad
+ * (dz3 is neither written nor re-read).  bf16 storage, c = 256, k = 64 only: mvf_conv1x1_bwd_fused_splits returns 0 for anything else. */
+int mvf_conv1x1_bwd_fused_splits(long m, int c, int k);
+int mvf_conv1x1_bwd_fused(const void* a_in, int a_pitch, const void* w_packed, const void* g, int g_pitch, const unsigned char* sign_bits, long m, int c,
+                          int k, const float* gamma, const float* mean, const float* invstd, const float* dgamma, const float* dbeta, const void* z_in,
+                          const float* in_mean, const float* in_invstd, const float* in_scale, const float* in_shift, void* dx, float* sums_part,
+                          int sums_rows, float* slabs, size_t slab_bytes, int dtype, void* stream);
 int mvf_wgrad_slab_reduce(const float* slabs, int nsplit, int cout, int k, float* dw_oihw, void* stream);
 /* stem: y = maxpool3x3/2(relu(z*scale+shift)) (resnet.py:482-484).  argmax (optional, one byte per element of y) receives
  * the window position dy*3+dx of the first maximum; the backward routes g to it: ga = dL/d relu(bn(z)). */

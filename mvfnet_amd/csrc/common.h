@@ -142,6 +142,24 @@ struct BnBwdWgradArgs {
     int g_pitch, M, C, K;
     int rows_per_split, nsplit, ctiles, ktiles;
 };
+// the whole backward of a z3-free bottleneck's last conv in one pass (pw_bwd_fused.hip): recomputed conv + BatchNorm-backward apply + data gradient
+// (+ the next BatchNorm's backward sums) + weight gradient; 64 -> 256 channels, bf16
+struct PwBwdFusedArgs {
+    const void* a;              // (M, aps >= 64) bf16 conv input, channels [0, 64)
+    const void* w;              // packed weights [256][64] bf16
+    const void* g;              // (M, g_pitch >= 256) bf16 gradient of the block output
+    const unsigned char* bits;  // sign bits of the block output, (M, 64) bytes
+    const float *gamma, *mean, *invstd, *dgamma, *dbeta;       // the BatchNorm behind the conv (dgamma / dbeta final)
+    const void* z_in;           // (M, 64) bf16: the pre-activation the conv input was made from (a = relu(bn_in(z_in)))
+    const float *in_scale, *in_shift, *in_mean, *in_invstd;    // that BatchNorm
+    void* dx;                   // (M, 64) bf16 out: gradient of the conv input
+    float* sums_part;           // [64][sums_rows][2] out: partial rows of bn_in's backward sums (2 x nsplit rows)
+    float* part;                // [nsplit][256][64] fp32 out: weight-gradient slabs
+    int aps, g_pitch, M, sums_rows, rows_per_split, nsplit;
+    int ablate;                 // -DMVF_PWBF_ABLATE builds only: phases to skip (timing experiments)
+};
+int pw_bwd_fused_plan(long m, int c, int k, int* rows_per_split);
+int pw_bwd_fused_launch(const PwBwdFusedArgs& a, hipStream_t st);
 bool bnbwd_wgrad_tile(int c, int k, int nbn, int mask_mode, int* ct, int* kt);
 int bnbwd_wgrad_plan(long m, int c, int k, int nbn, int mask_mode, int* rows_per_split, int* ctiles, int* ktiles);
 int bnbwd_wgrad_launch(const BnBwdWgradArgs& a, int nbn, int mask_mode, hipStream_t st);

@@ -1617,6 +1617,30 @@ int mvf_bn_bwd_pair_wgrad(const void* g, int g_pitch, const void* z_a, const voi
     return mvf_internal::bnbwd_wgrad_launch(a, 2, 4, st);
 }
 
+// ---- the whole backward of a z3-free bottleneck's last conv in one pass (csrc/pw_bwd_fused.hip) ----
+int mvf_conv1x1_bwd_fused_splits(long m, int c, int k) { return mvf_internal::pw_bwd_fused_plan(m, c, k, nullptr); }
+
+int mvf_conv1x1_bwd_fused(const void* a_in, int a_pitch, const void* w_packed, const void* g, int g_pitch, const unsigned char* sign_bits, long m, int c,
+                          int k, const float* gamma, const float* mean, const float* invstd, const float* dgamma, const float* dbeta, const void* z_in,
+                          const float* in_mean, const float* in_invstd, const float* in_scale, const float* in_shift, void* dx, float* sums_part,
+                          int sums_rows, float* slabs, size_t slab_bytes, int dtype, void* stream) {
+    MVF_REQUIRE(a_in && w_packed && g && sign_bits && gamma && mean && invstd && dgamma && dbeta && z_in && in_mean && in_invstd && in_scale && in_shift &&
+                    dx && sums_part && slabs && m > 0 && a_pitch >= k && g_pitch >= c, MVF_EINVAL, "conv1x1_bwd_fused: bad argument");
+    MVF_REQUIRE(dtype == MVF_BF16, MVF_EUNSUPPORTED, "conv1x1_bwd_fused: bf16 storage only");
+    mvf_internal::PwBwdFusedArgs a = {};
+    a.nsplit = mvf_internal::pw_bwd_fused_plan(m, c, k, &a.rows_per_split);
+    MVF_REQUIRE(a.nsplit > 0, MVF_EUNSUPPORTED, "conv1x1_bwd_fused: built for 64 -> 256 channels (c=%d k=%d); use the separate calls", c, k);
+    MVF_REQUIRE(sums_rows == 2 * a.nsplit, MVF_EINVAL, "conv1x1_bwd_fused: sums_rows must be 2 x mvf_conv1x1_bwd_fused_splits (%d), got %d", 2 * a.nsplit, sums_rows);
+    MVF_REQUIRE(slab_bytes >= (size_t)a.nsplit * c * k * sizeof(float), MVF_EWS, "conv1x1_bwd_fused: slab buffer too small (splits x c x k floats)");
+    MVF_REQUIRE(a_pitch % 8 == 0 && g_pitch % 8 == 0 && al16(a_in) && al16(w_packed) && al16(g) && al16(z_in) && al16(dx) && ((uintptr_t)sign_bits & 1) == 0 &&
+                    m * (long)std::max(g_pitch, a_pitch) * 2 < 0x7ffffff0L, MVF_ESHAPE, "conv1x1_bwd_fused: alignment / 2 GB addressing");
+    a.a = a_in; a.aps = a_pitch; a.w = w_packed; a.g = g; a.g_pitch = g_pitch; a.bits = sign_bits; a.M = (int)m;
+    a.gamma = gamma; a.mean = mean; a.invstd = invstd; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.z_in = z_in; a.in_mean = in_mean; a.in_invstd = in_invstd; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.dx = dx; a.sums_part = sums_part; a.sums_rows = sums_rows; a.part = slabs;
+    return mvf_internal::pw_bwd_fused_launch(a, (hipStream_t)stream);
+}
+
 int mvf_wgrad_slab_reduce(const float* slabs, int nsplit, int cout, int k, float* dw_oihw, void* stream) {
     MVF_REQUIRE(slabs && dw_oihw && nsplit > 0 && cout > 0 && k > 0, MVF_EINVAL, "wgrad_slab_reduce: bad argument");
     return mvf_internal::wgrad_slab_reduce_launch(slabs, nsplit, cout, k, dw_oihw, (hipStream_t)stream);

@@ -310,6 +310,37 @@ class _TConv(object):
         self.launch_bwd_apply(d, a_in, g, bits, bn, dz, ws)
         return dz
 
+    def bwd_fused_ok(self, m):
+        """[r4] The one-pass backward of a z3-free block's last conv is built for this shape (bf16, 64 -> 256 channels, pointwise, stride 1)."""
+        return (self.eng.tdtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and self.stride == 1 and not self.stem and
+                lib.mvf_conv1x1_bwd_fused_splits(m, self.cout, self.cin) > 0)
+
+    def bwd_fused(self, a_in, g, bits, n, h, w, bn, bn_in, z_in):
+        """[r4] bwd_recompute + dgrad_bnsums + wgrad of a z3-free block's last conv with dz3 kept on chip (mvf_conv1x1_bwd_fused): bn's dgamma / dbeta
+        from the sums pass as before, then ONE launch that returns the gradient of the conv input (bn_in's backward sums finalised) and leaves the
+        weight gradient as partial slabs whose fixed-order reduce goes to the side stream."""
+        d = self.desc(n, h, w, h, w, self.cin)
+        m = n * h * w
+        ws = _conv_ws(a_in.device)
+        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        part = self.eng.buf((id(self), "bwpart"), (rows, self.cout, 2), torch.float32)
+        self.launch_bwd_sums(d, a_in, g, bits, bn, part, ws)
+        check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cout, _p(bn.dgamma), _p(bn.dbeta), _st()), "mvf_bn_bwd_finalize")
+        ns = lib.mvf_conv1x1_bwd_fused_splits(m, self.cout, self.cin)
+        dx = self.eng.buf((id(self), "dx"), (m, self.cin))
+        spart = self.eng.buf((id(self), "bnsums_fused"), (self.cin, 2 * ns, 2), torch.float32)
+        slabs = self.eng.buf((id(self), "wslab"), (ns * self.cout * self.cin,), torch.float32)
+        self.launch_bwd_fused(m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs)
+        check(lib.mvf_bn_bwd_finalize(_p(spart), 2 * ns, self.cin, _p(bn_in.dgamma), _p(bn_in.dbeta), _st()), "bn bwd finalize")
+        self.slab_reduce(slabs, ns, self.eng)
+        return dx
+
+    def launch_bwd_fused(self, m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs):
+        """Exactly one launch (bench.py brackets this call with HIP events)."""
+        check(lib.mvf_conv1x1_bwd_fused(_p(a_in), self.cin, _p(self.wp), _p(g), self.cout, _p(bits), m, self.cout, self.cin, _p(bn.gamma), _p(bn.mean),
+                                        _p(bn.invstd), _p(bn.dgamma), _p(bn.dbeta), _p(z_in), _p(bn_in.mean), _p(bn_in.invstd), _p(bn_in.scale), _p(bn_in.shift),
+                                        _p(dx), _p(spart), 2 * ns, _p(slabs), slabs.numel() * 4, self.eng.dt, _st()), "conv1x1 backward fused")
+
     def launch_bwd_sums(self, d, a_in, g, bits, bn, part, ws):
         check(lib.mvf_conv2d_nhwc_fwd_bnbwd_sums(C.byref(d), _p(a_in), None, _p(self.wp), _p(g), _p(bits), _p(bn.mean), _p(bn.invstd), _p(part),
                                                  _p(ws), ws.numel(), _st()), "conv + bn backward sums")
@@ -572,6 +603,10 @@ class _TBlock(object):
                 aux.wait_stream(eng.main_stream())
                 with _on_stream(aux):
                     resid_aux = self.cd.dgrad(dzd, nt, ho, wo, h, w)
+        elif s["z3"] is None and eng.fuse_c3_bwd and eng.fuse_bn_bwd_sums and self.c3.bwd_fused_ok(m2):
+            # [r4] z3 never stored AND dz3 never stored: one pass forms it per 64-pixel chunk and contracts it three ways
+            da2 = self.c3.bwd_fused(s["a2"], g, bits, nt, ho, wo, self.b3, self.b2, s["z2"])
+            dz3, w3_done = None, True
         elif s["z3"] is None:          # z3 was never stored: bn3's backward on the recomputed conv3
             dz3 = self.c3.bwd_recompute(s["a2"], g, bits, nt, ho, wo, self.b3)
         elif (eng.fuse_bnwg & 1) and self.c3.fuses_wgrad(eng, m2, self.c3.cout, 4):
@@ -580,7 +615,9 @@ class _TBlock(object):
         else:
             dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 4, ymask=bits)
         fuse = eng.fuse_bn_bwd_sums
-        if fuse:       # the data gradient's epilogue also produces the BatchNorm-backward sums of the BN its output feeds
+        if dz3 is None:
+            pass       # the fused pass above already produced da2 and bn2's sums
+        elif fuse:     # the data gradient's epilogue also produces the BatchNorm-backward sums of the BN its output feeds
             da2 = self.c3.dgrad_bnsums(dz3, nt, ho, wo, ho, wo, self.b2, s["z2"])
         else:
             da2 = self.c3.dgrad(dz3, nt, ho, wo, ho, wo)
@@ -746,6 +783,7 @@ class _ParamStore(object):
     # 1 conv3 of plain stored-z3 blocks, 2 conv3 (+ stride-1 downsample conv) of downsample blocks, 4 conv1 of blocks without MVF,
     # 8 also give up the z3-free path of layer1's plain blocks for it)
     fuse_bnwg = int(os.environ.get("MVF_FUSE_BNWG", "7"))
+    fuse_c3_bwd = int(os.environ.get("MVF_FUSE_C3_BWD", "1"))   # [r4] z3-free blocks: conv3 recompute + bn3 backward apply + data gradient (+ bn2 sums) + weight gradient in ONE pass (csrc/pw_bwd_fused.hip); 0 = three launches
     fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes
 
     def side_stream(self):

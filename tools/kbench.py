@@ -183,6 +183,62 @@ def bench_bnwg():
             name, m, c, k, ta, tw, ta + tw, tf, tr, ns, by_f / tf / 1e6, ta + tw - tf - tr))
 
 
+def bench_c3bwd():
+    """[r4] The one-pass backward of a z3-free block's last conv (mvf_conv1x1_bwd_fused, csrc/pw_bwd_fused.hip) against the three launches it replaces
+    (conv + BatchNorm-backward apply, data gradient + BatchNorm sums, weight gradient), each alone on the stream, at layer1's C3 shape."""
+    from mvfnet_amd._lib import ConvDesc
+    dev, bf = "cuda", torch.bfloat16
+    cin, cout = 64, 256
+    for frames in (int(os.environ.get("KBENCH_FRAMES", "256")),):
+        m = frames * 56 * 56
+        a2 = torch.relu(torch.randn(m, cin, device=dev)).to(bf)
+        g = torch.randn(m, cout, device=dev).to(bf)
+        z2 = torch.randn(m, cin, device=dev).to(bf)
+        bits = torch.randint(0, 16, (m, cout // 4), device=dev, dtype=torch.uint8)
+        w = torch.randn(cout, cin, 1, 1, device=dev) * 0.1
+        wp = torch.empty(cout, 1, 1, cin, dtype=bf, device=dev)
+        wd = torch.empty(cin, 1, 1, cout, dtype=bf, device=dev)
+        check(lib.mvf_pack_conv_weight(P(w), cout, cin, 1, 1, 1, cin, None, P(wp), 1, None))
+        check(lib.mvf_pack_conv_weight_dgrad(P(w), cout, cin, 1, 1, P(wd), 1, None))
+        p3 = [(torch.rand(cout, device=dev) + 0.5) for _ in range(5)]          # gamma mean invstd dgamma dbeta
+        p2 = [(torch.rand(cin, device=dev) + 0.5) for _ in range(4)]           # mean invstd scale shift
+        d = ConvDesc(frames, 56, 56, cin, cout, 1, 1, 1, 0, 56, 56, cin, 1, 0, 0, 0, 0, 0)
+        dd = ConvDesc(frames, 56, 56, cout, cin, 1, 1, 1, 0, 56, 56, cout, 1, 0, 0, 0, 0, 0)
+        ws = torch.empty(lib.mvf_conv2d_workspace_bytes(None), dtype=torch.uint8, device=dev)
+        dz3 = torch.empty(m, cout, dtype=bf, device=dev)
+        dx = torch.empty(m, cin, dtype=bf, device=dev)
+        rows2 = lib.mvf_conv2d_stats_rows(C.byref(dd))
+        part = torch.empty(rows2, cin, 2, device=dev)
+        wsz = lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d))
+        wws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+        dw = torch.empty(cout, cin, device=dev)
+        ns = lib.mvf_conv1x1_bwd_fused_splits(m, cout, cin)
+        spart = torch.empty(cin, 2 * ns, 2, device=dev)
+        slabs = torch.empty(ns * cout * cin, device=dev)
+
+        def apply_():
+            check(lib.mvf_conv2d_nhwc_fwd_bnbwd_apply(C.byref(d), P(a2), None, P(wp), P(g), P(bits), P(p3[0]), P(p3[1]), P(p3[2]), P(p3[3]), P(p3[4]), P(dz3),
+                                                      P(ws), ws.numel(), None))
+
+        def dgrad():
+            check(lib.mvf_conv2d_nhwc_dgrad_bnsums(C.byref(dd), P(dz3), P(wd), P(dx), P(z2), P(p2[0]), P(p2[1]), P(p2[2]), P(p2[3]), P(part), P(ws), ws.numel(), None))
+
+        def wgrad():
+            check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), P(dz3), P(a2), None, 1, cin, 1, cin, P(dw), P(wws), wsz, None))
+
+        def fused():
+            check(lib.mvf_conv1x1_bwd_fused(P(a2), cin, P(wp), P(g), cout, P(bits), m, cout, cin, P(p3[0]), P(p3[1]), P(p3[2]), P(p3[3]), P(p3[4]), P(z2),
+                                            P(p2[0]), P(p2[1]), P(p2[2]), P(p2[3]), P(dx), P(spart), 2 * ns, P(slabs), slabs.numel() * 4, 1, None))
+
+        def reduce_():
+            check(lib.mvf_wgrad_slab_reduce(P(slabs), ns, cout, cin, P(dw), None))
+
+        ta, td, tw, tf, tr = timeit(apply_), timeit(dgrad), timeit(wgrad), timeit(fused), timeit(reduce_)
+        by_f = 2 * m * (cout + 3 * cin) + m * cout // 4
+        print("l1.c3 backward  M %7d  apply %6.1f + dgrad+bn %6.1f + wgrad %6.1f = %6.1f us | fused %6.1f + slab reduce %5.1f us (%d splits)  %5.2f TB/s %6.1f TF/s  saves %6.1f us"
+              % (m, ta, td, tw, ta + td + tw, tf, tr, ns, by_f / tf / 1e6, 6.0 * m * cout * cin / tf / 1e6, ta + td + tw - tf - tr))
+
+
 def bench_wgrad(dt=0, only=None):
     """Single weight-gradient launches (kernel + slab reduce) at the C3 shapes, fp32 by default (`wgrad` / `wgrad16`); A/B the fp32 kernels
     with MVF_WGRAD_X3=0 (the exact-fp32 MFMA kernel) against the default (three-term bf16 splits on the bf16 matrix cores)."""
@@ -252,6 +308,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if what == "bnwg":
         bench_bnwg()
+        sys.exit(0)
+    if what == "c3bwd":
+        bench_c3bwd()
         sys.exit(0)
     if what == "bn":
         bench_bn(1)
