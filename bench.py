@@ -219,6 +219,10 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         m = d.n * d.ho * d.wo
         return (2.0 * m * self.cout * self.cin, "bwd-apply M%d N%d K%d" % (m, self.cout, self.cin), esz * (m * self.cin + 2 * m * self.cout + self.w.numel()) + m * self.cout // 4)
 
+    def dbwf(self, out, m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs):      # [r4] conv3 again + bn3 backward apply + data gradient + bn2 sums + weight gradient, dz3 on chip
+        nbytes = esz * (3 * m * self.cin + m * self.cout + self.w.numel()) + m * self.cout // 4 + 4 * self.w.numel()      # a2, z2, dx, g, bits, W, dW
+        return (3 * 2.0 * m * self.cout * self.cin, "bwd-fused M%d N%d K%d (apply + dgrad + wgrad)" % (m, self.cout, self.cin), nbytes)
+
     def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
         fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin          # algorithmic = the forward conv's MACs
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * (2 if residual is not None else 1) + self.w.numel())
@@ -268,7 +272,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         return (2.0 * m * d.cs * taps, "mvf stencil%s M%d Cs%d" % ("^T" if flip else "", m, d.cs), nb)
 
     undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "launch_fwd_apply", dfap), tc.wrap(TE._TConv, "launch_bwd_sums", dbws), tc.wrap(TE._TConv, "launch_bwd_apply", dbwa),
-            tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb),
+            tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb), tc.wrap(TE._TConv, "launch_bwd_fused", dbwf),
             tw.wrap(TE._TConv, "wgrad", dwgr), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
             tb.wrap(TE._BN, "backward_pair", dbpr),
             tm.wrap(TE._TMvf, "launch_stencil", dmvf), tf.wrap(TE._BN, "_apply_bwd_wgrad", dbaw), tf.wrap(TE._BN, "backward_pair_wgrad", dbpw)]
@@ -297,8 +301,8 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         eng.overlap_wgrad = overlap
     ovh = event_pair_overhead_ms()
     key = dtype + "_train"
-    conv_kernels = ("conv_igemm_* (conv_tile instantiations: lowk / glds / p4 / streamk, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct / pw_sums (the direct "
-                    "kernels of layer1's 3x3 + its data gradient, of the stem, and the sum-only passes of layer1's conv3)")
+    conv_kernels = ("conv_igemm_* (conv_tile instantiations: lowk / glds / p4 / streamk, csrc/conv_nhwc.hip) + conv3x3_c64 / stem_direct / pw_sums / pw_bwd_fused (the direct "
+                    "kernels of layer1's 3x3 + its data gradient, of the stem, the sum-only passes of layer1's conv3 and its one-pass backward)")
     cpeak = F32_CONV_PEAK if dtype == "f32" else None
     r = _roof(tot["igemm"], reps, dtype, ovh, key, conv_kernels, "conv", peak_tf=cpeak)
     # the family with and without the RECOMPUTE passes (conv3 run again instead of re-reading z3: bn3's apply, backward sums, backward
