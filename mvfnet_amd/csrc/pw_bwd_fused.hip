@@ -8,23 +8,26 @@
 //     da2[m][k] = round_bf16(sum_c dz3[m][c] W[c][k])                                    (the data gradient, conv_nhwc.hip EPI 6)
 //     bn2's backward sums: sum_m gq, sum_m gq (z2 - mean2) invstd2 with gq = da2 * [scale2 z2 + shift2 > 0]
 // The un-fused step runs three launches for this (conv + BatchNorm-backward apply, data gradient + sums, weight gradient): dz3 -- a 4 x planes
-// tensor, 411 MB in layer1 of the R50 8x8 step -- is written once and read twice.  Here a persistent workgroup of NW waves walks chunks of
-// CH = 8 NW pixels of its row range and keeps the chunk's dz3 tile in LDS between three small matrix products:
-//   GEMM 1  z3^T = W a2^T          a wave owns 256 / NW channels x CH pixels; its W fragments live in registers
+// tensor, 411 MB in layer1 of the R50 8x8 step -- is written once and read twice.  Here a persistent workgroup (8 waves, one per CU) walks
+// 64-pixel chunks of its row range and keeps the chunk's dz3 tile in LDS between three small matrix products:
+//   GEMM 1  z3^T = W a2^T          wave w: channels [32 w, 32 w + 32) x 64 pixels; its W fragments live in registers
 //   (VALU)  dz3 in place, thread = (8-channel unit, 4 rows): the arithmetic of bn_bwd_apply_kernel
-//   GEMM 2  dW += dz3^T a2          transpose reads (ds_read_b64_tr_b16) of both tiles, 256 x 64 fp32 accumulator spread over the workgroup
-//   GEMM 3  da2^T = W^T dz3^T       wave = (pixel block, input-channel half, channel half); the two channel halves meet in an fp32 LDS tile
-//   (VALU)  thread = (row, 8-channel unit of da2): sum of the halves, round, 16-byte store, bn2's gated sums in registers
-// Every operand (a2, g, sign bits, z2) arrives by LDS-DMA one chunk ahead: no staging registers and no compiler-visible loads in the loop
-// (the first version prefetched g through registers, spilled 13 of them and lost 80 us per launch to the scratch reloads' waits).  LDS tiles
-// are XOR-swizzled in 16-byte units so that the row-per-lane 16-byte reads (GEMM 1 / 3 operands), the transpose reads (GEMM 2) and the
-// unit-per-lane accesses are all conflict-free.  Three LDS barriers per chunk, one vmcnt(0).  The phases of ONE workgroup do not overlap
-// (ablations: the launch is the sum of its phases), so the default is NW = 4 with TWO workgroups per CU (73 KB of LDS, <= 256 VGPRs each):
-// while one waits at a barrier or forms dz3 on the VALU, the other's matrix products and transfers proceed.
+//   then the workgroup splits: waves 4-7 run GEMM 2, waves 0-3 GEMM 3 (a wave of each kind per SIMD, 16 matrix instructions each):
+//   GEMM 2  dW += dz3^T a2          transpose reads (ds_read_b64_tr_b16) of both tiles; wave 4 + q owns channels [64 q, 64 q + 64) x 64
+//   GEMM 3  da2^T = W^T dz3^T       wave = (pixel block, input-channel half): ONE accumulation chain over the 256 channels in ascending order --
+//                                   da2 is bit-identical to the un-fused data gradient -- rounded and written to a bf16 LDS tile
+//   (VALU)  thread = (row, 8-channel unit of da2): 16-byte store of the tile, bn2's gated sums in registers
+//   The 64 registers of a lane hold GEMM 3's sixteen W^T fragments in waves 0-3 and GEMM 2's four accumulator blocks in waves 4-7.
+// Every operand (a2, g, sign bits, z2) arrives by LDS-DMA: no staging registers and no compiler-visible loads in the loop (the first version
+// prefetched g through registers, spilled 13 of them and lost 80 us per launch to the scratch reloads' waits).  a2 / bits / z2 are one chunk
+// ahead, g -- four fifths of the bytes -- two: its buffer is dead as soon as dz3 is formed.  LDS tiles are XOR-swizzled in 16-byte units so that
+// the row-per-lane 16-byte reads (GEMM 1 / 3 operands), the transpose reads (GEMM 2) and the unit-per-lane accesses are all conflict-free.
+// Three LDS barriers per chunk; the wait before the last one is counted (vmcnt(4): the four g transfers of chunk c + 2 stay in flight).
 // HBM traffic per pixel: g 512 B + bits 64 B + a2 128 B + z2 128 B in, da2 128 B out (960 B; the three launches it replaces move 2.6 KB).
 // Outputs: da2, one fp32 weight-gradient slab per workgroup ([nsplit][256][64], mvf_wgrad_slab_reduce), two partial rows of bn2's sums per
 // workgroup (value + remainder of an fp64 sum, channel-major [64][2 nsplit][2], mvf_bn_bwd_finalize).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -34,31 +37,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kT = 512;                  // 8 waves, two per SIMD
+constexpr int CH = 64;                   // pixels per chunk
 constexpr int NC = 256, NK = 64;         // conv output / input channels
 constexpr int PD = NC * 2;               // dz3 / g tile row pitch (bytes): 32 units of 16 bytes
-constexpr int PX = NK * 2;               // a2 / z2 tile row pitch: 8 units
-constexpr int PS = NK * 4;               // fp32 da2 tile row pitch: 16 units, XOR-swizzled by the row (swz_s)
+constexpr int PX = NK * 2;               // a2 / z2 / da2 tile row pitch: 8 units
 constexpr int PB = NC / 4;               // sign-bit tile row pitch (bytes)
 constexpr unsigned kOOB = 0x80000000u;
+constexpr int kOffD = 0, kOffX = CH * PD, kOffG = kOffX + 2 * CH * PX, kOffZ = kOffG + 2 * CH * PD, kOffM = kOffZ + 2 * CH * PX, kOffT = kOffM + 2 * CH * PB,
+              kOffC = kOffT + CH * PX, kOffB = kOffC + 4 * NK * 4, kLds = kOffB + 4 * NC * 4;
+static_assert(CH * 8 * 16 * 4 <= CH * PD, "the final reduction of the sums reuses a g buffer");
+static_assert(kLds <= 160 * 1024, "LDS");
 
-template <int NW>
-struct Cfg {
-    static constexpr int kT = 64 * NW;           // threads
-    static constexpr int CH = 8 * NW;            // pixels per chunk: 64 (8 waves) or 32 (4 waves)
-    // LDS map.  The fp32 da2 tile of chunk c (two channel halves) lives in the g buffer of chunk c: g(c) is dead once dz3(c) is formed.
-    static constexpr int kOffD = 0, kOffX = CH * PD, kOffG = kOffX + 2 * CH * PX, kOffZ = kOffG + 2 * CH * PD, kOffM = kOffZ + 2 * CH * PX,
-                         kOffC = kOffM + 2 * CH * PB, kOffB = kOffC + 4 * NK * 4, kLds = kOffB + 4 * NC * 4;
-    static_assert(2 * CH * PS <= CH * PD, "the fp32 da2 halves fit the dead g buffer");
-    static_assert(CH * 8 * 16 * 4 <= CH * PD, "the final reduction of the sums reuses a g buffer");
-    static_assert(kLds * (8 / NW) <= 160 * 1024, "LDS per CU");
-};
-
-// row -> XOR mask of the 16-byte unit index.  swz_d / swz_x are invariant under row += 16 (a transpose read's k-step) and give 16 distinct bank
-// groups over any 16 consecutive rows (ds_read_b128 services 16 lanes per cycle) as well as over the row sets {0-3, 8-11} / {4-7, 12-15} of a
+// row -> XOR mask of the 16-byte unit index.  Both are invariant under row += 16 (a transpose read's k-step) and give 16 distinct bank groups
+// over any 16 consecutive rows (ds_read_b128 services 16 lanes per cycle) as well as over the row sets {0-3, 8-11} / {4-7, 12-15} of a
 // transpose read.
 __device__ __forceinline__ int swz_d(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ int swz_x(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
-__device__ __forceinline__ int swz_s(int row) { return row & 15; }
 
 __device__ __forceinline__ void unpack8(const u32x4 r, float (&f)[8]) {
     f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
@@ -86,6 +81,7 @@ __device__ __forceinline__ void ldp8(const float* p, int c, float (&f)[8]) {
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void full_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void g_ahead_barrier() { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #ifdef MVF_PWBF_ABLATE
 #define PWBF_ON(bit) if (!(a.ablate & (bit)))
@@ -93,65 +89,53 @@ __device__ __forceinline__ void full_barrier() { asm volatile("s_waitcnt vmcnt(0
 #define PWBF_ON(bit)
 #endif
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_internal::PwBwdFusedArgs a) {
-    typedef Cfg<NW> G;
-    constexpr int kT = G::kT, CH = G::CH;
-    constexpr int CB1 = 8 / NW;                                      // GEMM 1: channel blocks per wave
-    constexpr int PBN = CH / 32;                                     // pixel blocks per chunk
-    constexpr int RP = kT / 32;                                      // dz3 formation: rows per pass (4 passes per chunk)
-    constexpr int WN = NW / 4, TN = 2 / WN;                          // GEMM 2: wave grid 4 x WN over the 256 x 64 accumulator, 2 x TN blocks per wave
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+__global__ __launch_bounds__(kT) void pw_bwd_fused_kernel(const mvf_internal::PwBwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ds = smem + G::kOffD;                                      // [CH][PD]      z3, then dz3 (bf16)
-    char* Xs = smem + G::kOffX;                                      // [2][CH][PX]   a2 (bf16)
-    char* Gs = smem + G::kOffG;                                      // [2][CH][PD]   g (bf16); then [2][CH][PS] da2 of the two channel halves (fp32)
-    char* Zs = smem + G::kOffZ;                                      // [2][CH][PX]   z2 (bf16)
-    char* Ms = smem + G::kOffM;                                      // [2][CH][PB]   sign bits of the block output
-    float* Cs = reinterpret_cast<float*>(smem + G::kOffC);           // [4][NK]       bn2: scale, shift, mean, invstd
-    float* Bs = reinterpret_cast<float*>(smem + G::kOffB);           // [4][NC]       bn3: gamma invstd, dbeta / M, invstd dgamma / M, mean
+    char* Ds = smem + kOffD;                                         // [CH][PD]      z3, then dz3 (bf16)
+    char* Xs = smem + kOffX;                                         // [2][CH][PX]   a2 (bf16)
+    char* Gs = smem + kOffG;                                         // [2][CH][PD]   g (bf16)
+    char* Zs = smem + kOffZ;                                         // [2][CH][PX]   z2 (bf16)
+    char* Ms = smem + kOffM;                                         // [2][CH][PB]   sign bits of the block output
+    char* Ts = smem + kOffT;                                         // [CH][PX]      da2 (bf16, as it is stored)
+    float* Cs = reinterpret_cast<float*>(smem + kOffC);              // [4][NK]       bn2: scale, shift, mean, invstd
+    float* Bs = reinterpret_cast<float*>(smem + kOffB);              // [4][NC]       bn3: gamma invstd, dbeta / M, invstd dgamma / M, mean
 
     const int split = blockIdx.x;
     const int m_begin = split * a.rows_per_split, m_end = min(a.M, m_begin + a.rows_per_split);
     const int nchunks = (m_end - m_begin + CH - 1) / CH;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
+    const bool role_a = wave < 4;                                    // GEMM 3 (waves 0-3) / GEMM 2 (waves 4-7)
 
-    // ---- this thread's dz3 unit: channels [8 q, 8 q + 8), rows r0 + RP i; bn3's backward coefficients (bn_bwd_apply_kernel's folding) ----
+    // ---- this thread's dz3 unit: channels [8 q, 8 q + 8), rows r0 + 16 i; bn3's backward coefficients (bn_bwd_apply_kernel's folding) ----
     const int q = tid & 31, r0 = tid >> 5;
-    for (int c = tid; c < NC; c += kT) {
+    if (tid < NC) {
         const float inv_m = 1.0f / (float)a.M;
-        const float rs = a.invstd[c];
-        Bs[c] = a.gamma[c] * rs; Bs[NC + c] = a.dbeta[c] * inv_m; Bs[2 * NC + c] = rs * a.dgamma[c] * inv_m; Bs[3 * NC + c] = a.mean[c];
+        const float rs = a.invstd[tid];
+        Bs[tid] = a.gamma[tid] * rs; Bs[NC + tid] = a.dbeta[tid] * inv_m; Bs[2 * NC + tid] = rs * a.dgamma[tid] * inv_m; Bs[3 * NC + tid] = a.mean[tid];
     }
     if (tid < NK) {
         Cs[tid] = a.in_scale[tid]; Cs[NK + tid] = a.in_shift[tid]; Cs[2 * NK + tid] = a.in_mean[tid]; Cs[3 * NK + tid] = a.in_invstd[tid];
     }
 
-    // ---- weights in registers.  GEMM 1 (A operand, row = channel 32 (CB1 wave + cb) + l31): 8 input channels per k-step half.  GEMM 3 (A
-    // operand, row = input channel 32 kb + l31 of W^T): 8 output channels of this wave's channel half per k-step half, gathered once ----
-    const int pb3 = wave % PBN, kb3 = (wave / PBN) & 1, ch3 = wave / (2 * PBN);
-    bf16x8_t w1[CB1][4], wt[8];
+    // ---- weights in registers.  GEMM 1 (A operand, row = channel 32 wave + l31): 8 input channels per k-step half.  GEMM 3 (A operand,
+    // row = input channel 32 kb + l31 of W^T): 8 output channels per k-step half, all 16 k-steps, gathered once (waves 0-3, in run() below);
+    // waves 4-7 keep GEMM 2's four accumulator blocks in those registers instead ----
+    const int pb3 = wave & 1, kb3 = (wave >> 1) & 1;
+    bf16x8_t w1[4];
     {
         const char* wp = reinterpret_cast<const char*>(a.w);
 #pragma unroll
-        for (int cb = 0; cb < CB1; ++cb)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const uint4 v = *reinterpret_cast<const uint4*>(wp + ((long)(32 * (CB1 * wave + cb) + l31) * NK + ks * 16 + half * 8) * 2);
-                __builtin_memcpy(&w1[cb][ks], &v, 16);
-            }
-        const short* ws = reinterpret_cast<const short*>(a.w);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) wt[ks][e] = ws[(ch3 * 128 + ks * 16 + half * 8 + e) * NK + kb3 * 32 + l31];
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 v = *reinterpret_cast<const uint4*>(wp + ((long)(32 * wave + l31) * NK + ks * 16 + half * 8) * 2);
+            __builtin_memcpy(&w1[ks], &v, 16);
+        }
     }
 
     const __amdgpu_buffer_rsrc_t rs_dx = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, (unsigned)min((long)a.M * NK * 2, 0x7ffffff0L), 0x00020000);
 
     // ---- LDS-DMA: a2 and z2 one 16-byte transfer per thread and chunk (lane at LDS position (row, p) fetches a2's source unit p ^ swz_x(row)),
-    // g four, the sign bits one per thread of the first NW / 2 waves ----
+    // g four, the sign bits one per thread of waves 0-3 ----
     const int rbx = tid >> 3;
     const int qbx = (tid & 7) ^ swz_x(rbx);
     const i32x4 gs_x = rsrc_words(a.a, (unsigned)min((long)a.M * a.aps * 2, 0x7ffffff0L));
@@ -165,18 +149,21 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_inte
         const int m = m_begin + cc * CH + rbx;
         glds16(gs_x, lds_x + (unsigned)((cc & 1) * CH * PX), m < m_end ? (unsigned)(m * a.aps + qbx * 8) * 2u : kOOB);
     };
-    auto dma_gmz = [&](int cc) {
+    auto dma_g = [&](int cc) {                                       // exactly four transfers per wave (g_ahead_barrier counts them)
         const int mc = m_begin + cc * CH;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                                // g: a wave lays down rows RP i + 2 wave, + 1 (32 units each)
-            const int m = mc + RP * i + 2 * wave + half;
-            glds16(gs_g, lds_g + (unsigned)((cc & 1) * CH * PD + RP * i * PD), m < m_end ? (unsigned)(m * a.g_pitch + l31 * 8) * 2u : kOOB);
+        for (int i = 0; i < 4; ++i) {                                // a wave lays down rows 16 i + 2 wave, + 1 (32 units each)
+            const int m = mc + 16 * i + 2 * wave + half;
+            glds16(gs_g, lds_g + (unsigned)((cc & 1) * CH * PD + 16 * i * PD), m < m_end ? (unsigned)(m * a.g_pitch + l31 * 8) * 2u : kOOB);
         }
+    };
+    auto dma_mz = [&](int cc) {
+        const int mc = m_begin + cc * CH;
         {                                                            // z2: rows 8 wave + (lane >> 3), unit lane & 7
             const int m = mc + rbx;
             glds16(gs_z, lds_z + (unsigned)((cc & 1) * CH * PX), m < m_end ? (unsigned)(m * NK + (tid & 7) * 8) * 2u : kOOB);
         }
-        if (wave < NW / 2) {                                         // bits: rows 16 wave + (lane >> 2), unit lane & 3
+        if (role_a) {                                                // bits: rows 16 wave + (lane >> 2), unit lane & 3
             const int m = mc + 16 * wave + (lane >> 2);
             glds16(gs_m, lds_m + (unsigned)((cc & 1) * CH * PB), m < m_end ? (unsigned)(m * PB + (lane & 3) * 16) : kOOB);
         }
@@ -187,33 +174,29 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_inte
     auto gemm1 = [&](int buf) {
         const char* xs = Xs + buf * CH * PX;
 #pragma unroll
-        for (int pb = 0; pb < PBN; ++pb) {
+        for (int pb = 0; pb < 2; ++pb) {
             const int row = pb * 32 + l31;
-            bf16x8_t bv[4];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const u32x4 v = lds16(xs + row * PX + (((ks * 2 + half) ^ swz_x(row)) * 16));
-                __builtin_memcpy(&bv[ks], &v, 16);
+                bf16x8_t bv;
+                __builtin_memcpy(&bv, &v, 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[ks], bv, acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int cb = 0; cb < CB1; ++cb) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[cb][ks], bv[ks], acc, 0, 0, 0);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {                     // z3 as the forward pass rounded it
-                    uint2 pk;
-                    pk.x = pack_bf16x2(acc[4 * g4], acc[4 * g4 + 1]);
-                    pk.y = pack_bf16x2(acc[4 * g4 + 2], acc[4 * g4 + 3]);
-                    *reinterpret_cast<uint2*>(Ds + row * PD + (((4 * (CB1 * wave + cb) + g4) ^ swz_d(row)) * 16) + half * 8) = pk;
-                }
+            for (int g4 = 0; g4 < 4; ++g4) {                         // z3 as the forward pass rounded it
+                uint2 pk;
+                pk.x = pack_bf16x2(acc[4 * g4], acc[4 * g4 + 1]);
+                pk.y = pack_bf16x2(acc[4 * g4 + 2], acc[4 * g4 + 3]);
+                *reinterpret_cast<uint2*>(Ds + row * PD + (((4 * wave + g4) ^ swz_d(row)) * 16) + half * 8) = pk;
             }
         }
     };
 
-    // ---- dz3 in place: this thread's unit q of rows r0 + RP i ----
+    // ---- dz3 in place: this thread's unit q of rows r0 + 16 i ----
     auto form_dz = [&](int buf) {
         float ca[8], cd[8], ck[8], cmu[8];
         ldp8(Bs, q * 8, ca); ldp8(Bs + NC, q * 8, cd); ldp8(Bs + 2 * NC, q * 8, ck); ldp8(Bs + 3 * NC, q * 8, cmu);
@@ -221,7 +204,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_inte
         const char* ms = Ms + buf * CH * PB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = r0 + RP * i;
+            const int row = r0 + 16 * i;
             char* p = Ds + row * PD + ((q ^ swz_d(row)) * 16);
             const u32x4 zu = lds16(p), gu = lds16(gs + row * PD + q * 16);
             const unsigned mb = *reinterpret_cast<const unsigned short*>(ms + row * PB + q * 2);
@@ -238,10 +221,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_inte
         }
     };
 
-    // ---- GEMM 2: dW tile (wgrad_bf16_kernel's transpose reads): wave (wm, wn) owns channels [64 wm, 64 wm + 64) x input channels [32 TN wn, + 32 TN);
+    // ---- GEMM 2 (waves 4-7): dW tile (wgrad_bf16_kernel's transpose reads): wave 4 + wq owns channels [64 wq, 64 wq + 64) x the 64 input channels;
     // group tg = lane >> 4 supplies pixel rows (ti >> 2) + 8 (tg >> 1) [+ 4 for the second read] and channel quad 16 (tg & 1) + 4 (ti & 3) ----
-    const int wm = wave / WN, wn = wave % WN;
-    int offA[2][2], offB[TN][2];
+    const int wq = wave & 3;
+    int offA[2][2], offB[2][2];
     {
         const int tg = lane >> 4, ti = lane & 15;
         const int trow = (ti >> 2) + 8 * (tg >> 1);
@@ -250,9 +233,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_inte
         for (int h = 0; h < 2; ++h) {
             const int row = trow + 4 * h;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) offA[i][h] = row * PD + ((((wm * 2 + i) * 4 + tunit) ^ swz_d(row)) * 16) + thalf * 8;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) offB[j][h] = row * PX + ((((wn * TN + j) * 4 + tunit) ^ swz_x(row)) * 16) + thalf * 8;
+            for (int i = 0; i < 2; ++i) {
+                offA[i][h] = row * PD + ((((wq * 2 + i) * 4 + tunit) ^ swz_d(row)) * 16) + thalf * 8;
+                offB[i][h] = row * PX + (((i * 4 + tunit) ^ swz_x(row)) * 16) + thalf * 8;
+            }
         }
     }
     auto gather = [&](const char* lo_p, const char* hi_p) {
@@ -265,49 +249,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_inte
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         return v;
     };
-    f32x16 accw[2][TN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accw[i][j][r] = 0.f;
-    auto gemm2 = [&](int buf) {
-        const char* xs = Xs + buf * CH * PX;
-#pragma unroll
-        for (int ks = 0; ks < CH / 16; ++ks) {
-            bf16x8_t fa[2], fb[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = gather(xs + ks * 16 * PX + offB[j][0], xs + ks * 16 * PX + offB[j][1]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = gather(Ds + ks * 16 * PD + offA[i][0], Ds + ks * 16 * PD + offA[i][1]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], accw[i][j], 0, 0, 0);
-        }
-    };
-
-    // ---- GEMM 3: da2^T tile of (pixel block pb3, input-channel block kb3) over the channel half ch3.  D[i = input channel][j = pixel] ----
-    auto gemm3 = [&](int buf) {
-        const int row = pb3 * 32 + l31;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const u32x4 v = lds16(Ds + row * PD + (((ch3 * 16 + ks * 2 + half) ^ swz_d(row)) * 16));
-            bf16x8_t bv;
-            __builtin_memcpy(&bv, &v, 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], bv, acc, 0, 0, 0);
-        }
-        char* sp = Gs + buf * CH * PD + ch3 * CH * PS + row * PS;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)                               // input channels 32 kb3 + 8 g4 + 4 half ..+3 = unit 8 kb3 + 2 g4 + half
-            *reinterpret_cast<float4*>(sp + (((kb3 * 8 + 2 * g4 + half) ^ swz_s(row)) * 16)) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
-    };
-
-    // ---- last phase of a chunk: the two channel halves, rounded and stored; bn2's gated sums of what was stored ----
+    // ---- last phase of a chunk: da2 stored; bn2's gated sums of what was stored ----
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -315,17 +257,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_inte
         const int m = m_begin + cc * CH + re;
         const bool ok = cc >= 0 && m < m_end;
         const int buf = cc & 1;
-        float v[8];
-        {
-            const char* p0 = Gs + buf * CH * PD + re * PS;
-            const char* p1 = p0 + CH * PS;
-            const int u0 = ((2 * ue) ^ swz_s(re)) * 16, u1 = ((2 * ue + 1) ^ swz_s(re)) * 16;
-            const float4 a0 = *reinterpret_cast<const float4*>(p0 + u0), a1 = *reinterpret_cast<const float4*>(p0 + u1);
-            const float4 b0 = *reinterpret_cast<const float4*>(p1 + u0), b1 = *reinterpret_cast<const float4*>(p1 + u1);
-            v[0] = a0.x + b0.x; v[1] = a0.y + b0.y; v[2] = a0.z + b0.z; v[3] = a0.w + b0.w;
-            v[4] = a1.x + b1.x; v[5] = a1.y + b1.y; v[6] = a1.z + b1.z; v[7] = a1.w + b1.w;
-        }
-        const u32x4 pk = pack8(v);
+        const u32x4 pk = lds16(Ts + re * PX + ((ue ^ swz_x(re)) * 16));
         __builtin_amdgcn_raw_buffer_store_b128(pk, rs_dx, ok ? (unsigned)(m * NK + ue * 8) * 2u : kOOB, 0, 0);
         const u32x4 zq = lds16(Zs + buf * CH * PX + re * PX + ue * 16);
         float vr[8], zv[8], sc[8], sh[8], mu[8], rs[8];
@@ -340,46 +272,119 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_inte
         }
     };
 
-    // ---- the chunk loop: three LDS barriers per chunk, ONE vmcnt(0) (at the last of them).  Transfers in flight: a2(c + 1) from the top of
-    // iteration c (its buffer was last read by GEMM 2 of chunk c - 1), g / bits / z2(c + 1) from the first barrier of iteration c on (their
-    // buffers hold chunk c - 1's fp32 da2 tile and z2 until the finish at the top of iteration c has read them): everything the wait at the
-    // end of iteration c covers was issued at least two phases earlier.  (In the first pass the finish reads an uninitialised tile: masked.) ----
-    if (nchunks > 0) {
-        dma_x(0);
-        dma_gmz(0);
-    }
-    full_barrier();
-    for (int cc = 0; cc < nchunks; ++cc) {
-        if (cc + 1 < nchunks) dma_x(cc + 1);
-        PWBF_ON(32) finish(cc - 1);
-        PWBF_ON(2) gemm1(cc & 1);
-        lds_barrier();                                               // z3 tile complete; chunk c - 1's fp32 tile and z2 read by everyone
-        PWBF_ON(16) if (cc + 1 < nchunks) dma_gmz(cc + 1);
-        PWBF_ON(1) form_dz(cc & 1);
-        lds_barrier();                                               // dz3 tile complete, g(c) dead
-        PWBF_ON(4) gemm2(cc & 1);
-        PWBF_ON(8) gemm3(cc & 1);
-        full_barrier();                                              // fp32 da2 halves complete; every read of the dz3 / a2 tiles done; chunk c + 1 landed
-    }
-    finish(nchunks - 1);
-
-    // ---- one fp32 weight-gradient slab per workgroup: part[split][256][64] (wgrad_reduce_kernel's layout) ----
-    {
-        float* out = a.part + (long)split * NC * NK;
-        const int lr = lane >> 5, lc = lane & 31;
+    // ---- the chunk loop: three LDS barriers per chunk.  Transfers: a2(c + 1) from the top of iteration c (its buffer was last read by GEMM 2 of
+    // chunk c - 1); bits / z2(c + 1) from the first barrier on (z2(c - 1) was read by the finish at the top); g(c + 2) from the second barrier on
+    // (g(c) is dead once dz3(c) is formed).  The wait before the last barrier lets exactly those four g transfers stay in flight: loads complete
+    // in order, so vmcnt(4) implies everything issued before them -- a2 / bits / z2(c + 1) and, from the previous iteration, g(c + 1) -- has landed
+    // (the one store in the window, da2(c - 1), can only make the wait longer).  (In the first pass the finish reads an uninitialised tile: masked.) ----
+    // The loop exists twice, once per role, so that the 64 role-specific registers of a lane (GEMM 3's W^T fragments / GEMM 2's accumulators)
+    // are allocated on top of each other.
+    auto run = [&](auto role_c) {
+        constexpr bool A = decltype(role_c)::value;
+        bf16x8_t wt[A ? 16 : 1];
+        f32x16 accw[A ? 1 : 4];
+        if constexpr (A) {
+            const short* ws = reinterpret_cast<const short*>(a.w);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = (wn * TN + j) * 32 + lc;
+            for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int e = 0; e < 8; ++e) wt[ks][e] = ws[(ks * 16 + half * 8 + e) * NK + kb3 * 32 + l31];
+        } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
-                    out[(long)row * NK + col] = accw[i][j][r];
-                }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
         }
-    }
-    // ---- bn2's sums: the CH row-threads of a channel unit in fixed order, in fp64; two fp32 partial rows per workgroup (value + remainder) ----
+        auto gemm2 = [&](int buf) {
+            if constexpr (!A) {
+                const char* xs = Xs + buf * CH * PX;
+#pragma unroll
+                for (int ks = 0; ks < CH / 16; ++ks) {
+                    bf16x8_t fa[2], fb[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[j] = gather(xs + ks * 16 * PX + offB[j][0], xs + ks * 16 * PX + offB[j][1]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[i] = gather(Ds + ks * 16 * PD + offA[i][0], Ds + ks * 16 * PD + offA[i][1]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) accw[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], accw[i * 2 + j], 0, 0, 0);
+                }
+            }
+        };
+        // GEMM 3: da2^T tile of (pixel block pb3, input-channel block kb3), the 256 channels in one chain.  D[i = input channel][j = pixel]
+        auto gemm3 = [&]() {
+            if constexpr (A) {
+                const int row = pb3 * 32 + l31;
+                int vx = half ^ swz_d(row);                          // (2 ks + half) ^ swz = (2 ks) ^ vx; opaque, so that the sixteen addresses are
+                asm volatile("" : "+v"(vx));                         // recomputed here (one v_xor each) instead of living in sixteen registers
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const u32x4 v = lds16(Ds + row * PD + (((ks * 2) ^ vx) * 16));
+                    bf16x8_t bv;
+                    __builtin_memcpy(&bv, &v, 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], bv, acc, 0, 0, 0);
+                    if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four operand fragments in flight, not sixteen (64 registers: spills)
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {                     // input channels 32 kb3 + 8 g4 + 4 half ..+3 = unit 4 kb3 + g4, second half of it for half = 1
+                    uint2 pk;
+                    pk.x = pack_bf16x2(acc[4 * g4], acc[4 * g4 + 1]);
+                    pk.y = pack_bf16x2(acc[4 * g4 + 2], acc[4 * g4 + 3]);
+                    *reinterpret_cast<uint2*>(Ts + row * PX + (((kb3 * 4 + g4) ^ swz_x(row)) * 16) + half * 8) = pk;
+                }
+            }
+        };
+        if (nchunks > 0) {
+            dma_x(0);
+            dma_mz(0);
+            dma_g(0);
+            if (nchunks > 1) dma_g(1);
+        }
+        full_barrier();
+        for (int cc = 0; cc < nchunks; ++cc) {
+            if (cc + 1 < nchunks) dma_x(cc + 1);
+            PWBF_ON(32) finish(cc - 1);
+            PWBF_ON(2) gemm1(cc & 1);
+            lds_barrier();                                           // z3 tile complete; chunk c - 1's da2 tile and z2 read by everyone
+            if (cc + 1 < nchunks) dma_mz(cc + 1);
+            PWBF_ON(1) form_dz(cc & 1);
+            lds_barrier();                                           // dz3 tile complete, g(c) dead
+            const bool g2 = cc + 2 < nchunks;
+            PWBF_ON(16) if (g2) dma_g(cc + 2);
+            PWBF_ON(8) gemm3();
+            PWBF_ON(4) gemm2(cc & 1);
+#ifdef MVF_PWBF_ABLATE
+            full_barrier();
+#else
+            if (g2) g_ahead_barrier(); else full_barrier();          // da2 tile complete; every read of the dz3 / a2 tiles done; chunk c + 1 landed
+#endif
+        }
+        finish(nchunks - 1);
+        // one fp32 weight-gradient slab per workgroup: part[split][256][64] (wgrad_reduce_kernel's layout)
+        if constexpr (!A) {
+            float* out = a.part + (long)split * NC * NK;
+            const int lr = lane >> 5, lc = lane & 31;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = j * 32 + lc;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wq * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
+                        out[(long)row * NK + col] = accw[i * 2 + j][r];
+                    }
+            }
+        }
+    };
+    if (role_a) run(std::true_type());
+    else run(std::false_type());
+
+    // ---- bn2's sums: the 64 row-threads of a channel unit in fixed order, in fp64; two fp32 partial rows per workgroup (value + remainder) ----
     __syncthreads();
     {
         float* red = reinterpret_cast<float*>(Gs);                   // [row re][unit ue][16]
@@ -404,28 +409,6 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_bwd_fused_kernel(const mvf_inte
     }
 }
 
-int waves_cfg() {
-    static const int nw = (getenv("MVF_PWBF_WAVES") && atoi(getenv("MVF_PWBF_WAVES")) == 4) ? 4 : 8;      // A/B switch: 4 = two 4-wave workgroups per CU
-    return nw;
-}
-
-template <int NW>
-int launch(const mvf_internal::PwBwdFusedArgs& a0, hipStream_t st) {
-    auto k = pw_bwd_fused_kernel<NW>;
-    static bool attr = false;
-    if (!attr) {
-        MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<NW>::kLds));
-        attr = true;
-    }
-    mvf_internal::PwBwdFusedArgs a = a0;
-#ifdef MVF_PWBF_ABLATE
-    a.ablate = getenv("MVF_PWBF_ABLATE") ? atoi(getenv("MVF_PWBF_ABLATE")) : 0;
-#endif
-    hipLaunchKernelGGL(k, dim3(a.nsplit), dim3(64 * NW), Cfg<NW>::kLds, st, a);
-    MVF_LAUNCH_CHECK();
-    return MVF_OK;
-}
-
 }  // namespace
 
 namespace mvf_internal {
@@ -433,16 +416,28 @@ namespace mvf_internal {
 // workgroups (= weight-gradient slabs; bn2's sums take 2 x this many partial rows) for an [m][256] gradient over a 64-channel conv input; 0 = not built
 int pw_bwd_fused_plan(long m, int c, int k, int* rows_per_split) {
     if (c != NC || k != NK || m <= 0 || m * (long)NC * 2 >= 0x7ffffff0L) return 0;
-    const int nw = waves_cfg(), ch = 8 * nw;
-    static const int wgs_env = getenv("MVF_PWBF_WGS") ? std::max(1, atoi(getenv("MVF_PWBF_WGS"))) : 0;
-    const int want = wgs_env ? wgs_env : 256 * (8 / nw);             // persistent workgroups: 8 waves' worth per CU
-    long rows = (m + want - 1) / want;
-    rows = (rows + ch - 1) / ch * ch;
-    if (rows < 2 * ch) rows = 2 * ch;
+    static const int wgs_env = getenv("MVF_PWBF_WGS") ? std::max(1, atoi(getenv("MVF_PWBF_WGS"))) : 256;      // one persistent workgroup per CU
+    long rows = (m + wgs_env - 1) / wgs_env;
+    rows = (rows + CH - 1) / CH * CH;
+    if (rows < 2 * CH) rows = 2 * CH;
     if (rows_per_split) *rows_per_split = (int)rows;
     return (int)((m + rows - 1) / rows);
 }
 
-int pw_bwd_fused_launch(const PwBwdFusedArgs& a, hipStream_t st) { return waves_cfg() == 8 ? launch<8>(a, st) : launch<4>(a, st); }
+int pw_bwd_fused_launch(const PwBwdFusedArgs& a0, hipStream_t st) {
+    auto k = pw_bwd_fused_kernel;
+    static bool attr = false;
+    if (!attr) {
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        attr = true;
+    }
+    PwBwdFusedArgs a = a0;
+#ifdef MVF_PWBF_ABLATE
+    a.ablate = getenv("MVF_PWBF_ABLATE") ? atoi(getenv("MVF_PWBF_ABLATE")) : 0;
+#endif
+    hipLaunchKernelGGL(k, dim3(a.nsplit), dim3(kT), kLds, st, a);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
 
 }  // namespace mvf_internal
