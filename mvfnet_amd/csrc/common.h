@@ -126,6 +126,13 @@ struct Wgrad3x3C64Args {
     float* part;                // [nwg][64][576] fp32 partial slabs (wgrad_reduce_kernel's layout: [co][(kh * 3 + kw) * 64 + ci])
     int N, H, W, xps, nwg;
 };
+// weight gradient of the stem conv (7 x 1 taps over the 32-"channel" view of the padded NHWC4 operand, stride 2) as a direct kernel (wgrad_stem.hip)
+struct WgradStemArgs {
+    const void* dz;             // (N, Ho, Wo, 64) bf16
+    const void* x;              // (N, H, W, 4) bf16, padded (mvf_stem_prep)
+    float* part;                // [nwg][64][224] fp32 partial slabs (wgrad_reduce_kernel's layout: [co][(kh * 8 + kw) * 4 + c])
+    int N, H, W, Ho, Wo, nwg;
+};
 namespace mvf_internal {
 // BatchNorm backward apply fused with the pointwise conv's weight gradient (bnbwd_wgrad.hip); index 0 / 1 = the one or two BatchNorms
 // (1 = the downsample branch of a paired backward) that share g and the sign bits
@@ -167,6 +174,9 @@ int wgrad_slab_reduce_launch(const float* part, int nsplit, int cout, int k, flo
 bool wgrad3x3_c64_ok(int n, int h, int w, int xps);
 int wgrad3x3_c64_wgs(int n, int h);
 int wgrad3x3_c64_launch(const Wgrad3x3C64Args& a, hipStream_t st);
+bool wgrad_stem_ok(int n, int h, int w, int ho, int wo);
+int wgrad_stem_wgs(int n, int ho);
+int wgrad_stem_launch(const WgradStemArgs& a, hipStream_t st);
 int stem_direct_launch(const StemDirectArgs& a, hipStream_t st);
 int conv3x3_c64_launch(const Conv3x3C64Args& a, hipStream_t st);
 int pw_sums_launch(const PwSumsArgs& a, hipStream_t st);

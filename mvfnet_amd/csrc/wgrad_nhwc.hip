@@ -1222,6 +1222,12 @@ static bool wg_direct3x3(const mvf_conv_desc_t* d) {
            d->ho == d->h && d->wo == d->w && mvf_internal::wgrad3x3_c64_ok(d->n, d->h, d->w, d->x_pix_stride);
 }
 
+// [r4] the stem (7 x 1 taps over the 32-"channel" view of the padded NHWC4 operand, stride 2, bf16) on the direct kernel of wgrad_stem.hip (MVF_WGRAD_STEM_DIRECT=0: the implicit GEMM)
+static bool wg_direct_stem(const mvf_conv_desc_t* d) {
+    return d->dtype == MVF_BF16 && d->cin == 32 && d->cout == 64 && d->kh == 7 && d->kw == 1 && d->stride == 2 && d->pad == 0 && d->split_c == 0 &&
+           d->x_pix_stride == 4 && mvf_internal::wgrad_stem_ok(d->n, d->h, d->w, d->ho, d->wo);
+}
+
 size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
     if (!d || d->cout <= 0 || d->cin <= 0) return 0;
     const int M = d->n * d->ho * d->wo, K = d->kh * d->kw * d->cin;
@@ -1231,6 +1237,7 @@ size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
     int nsplit = (M + rows - 1) / rows;
     if (wg_big_shape(d)) nsplit = std::max(nsplit, (M + wg_big_rows(d) - 1) / wg_big_rows(d));
     if (wg_direct3x3(d)) nsplit = std::max(nsplit, mvf_internal::wgrad3x3_c64_wgs(d->n, d->h));
+    if (wg_direct_stem(d)) nsplit = std::max(nsplit, mvf_internal::wgrad_stem_wgs(d->n, d->ho));
     return align_up((size_t)nsplit * d->cout * K * sizeof(float), 256);
 }
 
@@ -1250,6 +1257,12 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
         const int rc = mvf_internal::wgrad3x3_c64_launch(w, st0);
         if (rc != MVF_OK) return rc;
         return launch_wgrad_reduce((const float*)ws, w.nwg, 64, 64, 3, 3, 3, 64, dw_oihw, st0);
+    }
+    if (wg_direct_stem(d) && kw_real == 7 && cin_real == 3 && kw_packed == 8 && cin_packed == 4 && ((uintptr_t)dz | (uintptr_t)x) % 16 == 0) {
+        WgradStemArgs w = {dz, x, (float*)ws, d->n, d->h, d->w, d->ho, d->wo, mvf_internal::wgrad_stem_wgs(d->n, d->ho)};
+        const int rc = mvf_internal::wgrad_stem_launch(w, st0);
+        if (rc != MVF_OK) return rc;
+        return launch_wgrad_reduce((const float*)ws, w.nwg, 64, 3, 7, 7, 8, 4, dw_oihw, st0);
     }
     WgArgs a = {};
     a.dz = dz; a.x = x; a.x2 = x2; a.part = (float*)ws;

@@ -360,6 +360,34 @@ def test_conv_dgrad_wgrad_vs_oracle(case, dtype):
     assert rel_err(dx.float().cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy()) < tol
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 64), (2, 96, 96), (2, 224, 224), (5, 32, 64)], ids=str)
+def test_stem_wgrad_direct_bf16_vs_fp64_conv_weight_gradient(shape):
+    """[r4] The stem's weight gradient on the direct kernel (csrc/wgrad_stem.hip; reference resnet.py:448-452, autograd of Conv2d(3, 64, 7, 2, 3)) in bf16
+    storage: against torch's conv weight gradient in fp64 on the same bf16-rounded operands (the kernel multiplies exactly those and sums in fp32)."""
+    from mvfnet_amd import _lib
+    lib, check = _lib.lib, _lib.check
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h * 7 + w)
+    bf = torch.bfloat16
+    x = torch.randn(n, 3, h, w, generator=g).to(bf)
+    ho, wo = h // 2, w // 2
+    dy = torch.randn(n, 64, ho, wo, generator=g).to(bf)
+    wt = torch.zeros(64, 3, 7, 7, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, stride=2, padding=3).backward(dy.double())
+    hp, wp = h + 6, w + 8
+    xp = torch.empty(n, hp, wp, 4, device="cuda", dtype=bf)
+    xg = x.float().cuda()
+    check(lib.mvf_stem_prep(P(xg), n, 3, h, w, 3, wp, P(xp), 1, None))
+    d = _lib.ConvDesc(n, hp, wp, 32, 64, 7, 1, 2, 0, ho, wo, 4, 1, 0, 0, 0, 0, 0)
+    ws = torch.full((lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)) // 4,), float("nan"), device="cuda")
+    dw = torch.full((64, 3, 7, 7), float("nan"), device="cuda")
+    dyg = nhwc(dy).cuda()
+    check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), P(dyg), P(xp), None, 7, 3, 8, 4, P(dw), P(ws), ws.numel() * 4, None))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all()
+    assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < 2e-5
+
+
 def test_stem_wgrad_maxpool_head_sgd_vs_oracle():
     from mvfnet_amd import _lib
     from oracle import net_torch

@@ -42,3 +42,22 @@ for name in ("train", "infer"):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     print("stem %s: %.1f us  (%.2f TB/s of output bytes)" % (name, us, n * ho * wo * 128 / us / 1e6))
+# [r4] the stem's weight gradient (kernel + slab reduce): MVF_WGRAD_STEM_DIRECT=0 -> the implicit GEMM
+dz = torch.randn(n * ho * wo, 64, device="cuda").bfloat16()
+wsz = lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d))
+wws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+dw = torch.empty(64, 3, 7, 7, device="cuda")
+d.relu = 0
+def gow():
+    check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), P(dz), P(xp), None, 7, 3, 8, 4, P(dw), P(wws), wsz, None))
+for _ in range(3):
+    gow()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    gow()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / iters
+print("stem wgrad: %.1f us  (%.2f TB/s of dz + input bytes, %.0f TF/s of the padded K = 224 product)" % (us, (n * ho * wo * 128 + xp.numel() * 2) / us / 1e6, 2.0 * n * ho * wo * 64 * 224 / us / 1e6))
