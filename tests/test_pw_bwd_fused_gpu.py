@@ -61,7 +61,7 @@ def _three_launches(lib, check, ConvDesc, t, m):
     return dict(wp=wp, dg=dg, db=db, dz3=dz3, dx=dx, dg2=dg2, db2=db2)
 
 
-@pytest.mark.parametrize("m", [64 * 40, 300, 64 * 57 + 17, 3 * 56 * 56, 130], ids=str)
+@pytest.mark.parametrize("m", [64 * 40, 300, 64 * 57 + 17, 3 * 56 * 56, 130, 256 * 56 * 56], ids=str)          # (the last: layer1 of the C3 step at full size)
 def test_conv1x1_bwd_fused_equals_apply_dgrad_wgrad(m):
     from mvfnet_amd import _lib
     lib, check, ConvDesc = _lib.lib, _lib.check, _lib.ConvDesc

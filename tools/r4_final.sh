@@ -12,6 +12,6 @@ timeout 600 python bench.py --steps 10 --warmup 3 --per-layer --no-eager-compare
 timeout 600 python bench.py --mode infer --dtype f32 --steps 10 --warmup 3 --per-layer --no-cpu-baseline 2> gpurun_out/per_layer_f32_infer.txt > /dev/null
 timeout 600 python bench.py --dtype f32 --steps 5 --warmup 2 --per-layer --no-eager-compare --no-cpu-baseline --no-other-configs 2> gpurun_out/per_layer_f32_train.txt > /dev/null
 (echo "== fp32, default (wgrad_x3_kernel)"; python tools/kbench.py wgrad; echo "== fp32, MVF_WGRAD_X3=0 (fp32 MFMA kernel)"; MVF_WGRAD_X3=0 python tools/kbench.py wgrad; echo "== bf16, default (layer1 3x3 on the direct kernel)"; python tools/kbench.py wgrad16; echo "== bf16, MVF_WGRAD3X3_DIRECT=0"; MVF_WGRAD3X3_DIRECT=0 python tools/kbench.py wgrad16 l1.c2) > gpurun_out/r4_kbench_wgrad.txt 2>&1
-(python tools/kbench.py c3bwd; MVF_PWBF_WAVES=4 python tools/kbench.py c3bwd; python tools/kbench.py bnwg; python tools/kbench.py mvf; for f in 256 334; do echo "frames $f"; KBENCH_FRAMES=$f python tools/kbench.py conv "l3.c2"; KBENCH_FRAMES=$f python tools/kbench.py conv "l3.c1 fwd"; done) > gpurun_out/r4_kbench.txt 2>&1
+(python tools/kbench.py c3bwd; PYTHONPATH=. python tools/stem_bench.py; MVF_WGRAD_STEM_DIRECT=0 PYTHONPATH=. python tools/stem_bench.py | tail -1; python tools/kbench.py bnwg; python tools/kbench.py mvf; for f in 256 334; do echo "frames $f"; KBENCH_FRAMES=$f python tools/kbench.py conv "l3.c2"; KBENCH_FRAMES=$f python tools/kbench.py conv "l3.c1 fwd"; done) > gpurun_out/r4_kbench.txt 2>&1
 timeout 1500 python bench.py > gpurun_out/default_bench.json 2> gpurun_out/default_bench.err
 tail -c 400 gpurun_out/default_bench.json
