@@ -219,8 +219,8 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         m = d.n * d.ho * d.wo
         return (2.0 * m * self.cout * self.cin, "bwd-apply M%d N%d K%d" % (m, self.cout, self.cin), esz * (m * self.cin + 2 * m * self.cout + self.w.numel()) + m * self.cout // 4)
 
-    def dbwf(self, out, m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs):      # [r4] conv3 again + bn3 backward apply + data gradient + bn2 sums + weight gradient, dz3 on chip
-        nbytes = esz * (3 * m * self.cin + m * self.cout + self.w.numel()) + m * self.cout // 4 + 4 * self.w.numel()      # a2, z2, dx, g, bits, W, dW
+    def dbwf(self, out, m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs, a_pitch=None):      # [r4] conv again + BatchNorm backward apply + data gradient (+ bn_in sums) + weight gradient, dz on chip
+        nbytes = esz * ((3 if bn_in is not None else 2) * m * self.cin + m * self.cout + self.w.numel()) + m * self.cout // 4 + 4 * self.w.numel()      # a2, (z2,) dx, g, bits, W, dW
         return (3 * 2.0 * m * self.cout * self.cin, "bwd-fused M%d N%d K%d (apply + dgrad + wgrad)" % (m, self.cout, self.cin), nbytes)
 
     def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):

@@ -291,7 +291,9 @@ int mvf_bn_bwd_pair_wgrad(const void* g, int g_pitch, const void* z_a, const voi
  * LDS and is contracted three ways: the weight gradient (fp32 slabs [splits][256][64] for mvf_wgrad_slab_reduce), the data gradient
  * dx = round_bf16(dz3 W) (m, 64), and the backward sums of bn2 over dx gated by scale2 z2 + shift2 > 0 (partial rows [64][sums_rows][2] for
  * mvf_bn_bwd_finalize, sums_rows = 2 x splits).  Replaces mvf_conv2d_nhwc_fwd_bnbwd_apply + mvf_conv2d_nhwc_dgrad_bnsums + mvf_conv2d_nhwc_wgrad
- * (dz3 is neither written nor re-read).  bf16 storage, c = 256, k = 64 only: mvf_conv1x1_bwd_fused_splits returns 0 for anything else. */
+ * (dz3 is neither written nor re-read).  z_in = NULL: the conv input is not a BatchNorm's activation (a downsample branch, resnet.py:227-228, reading the block
+ * input): dx is the plain data gradient, no sums (in_* / sums_part unused).  bf16 storage, c = 256, k = 64 only: mvf_conv1x1_bwd_fused_splits returns 0 for
+ * anything else.  sign_bits: 16-byte aligned. */
 int mvf_conv1x1_bwd_fused_splits(long m, int c, int k);
 int mvf_conv1x1_bwd_fused(const void* a_in, int a_pitch, const void* w_packed, const void* g, int g_pitch, const unsigned char* sign_bits, long m, int c,
                           int k, const float* gamma, const float* mean, const float* invstd, const float* dgamma, const float* dbeta, const void* z_in,

@@ -6,7 +6,8 @@
 //     dz3[m][c] = round_bf16(gamma invstd (gm - dbeta / M - (z3 - mean) invstd dgamma / M))   (conv_nhwc.hip EPI 9 = bn_bwd_apply_kernel)
 //     dW[c][k]  = sum_m dz3[m][c] a2[m][k]                                               (wgrad_bf16_kernel; fp32 slabs, fixed-order reduce)
 //     da2[m][k] = round_bf16(sum_c dz3[m][c] W[c][k])                                    (the data gradient, conv_nhwc.hip EPI 6)
-//     bn2's backward sums: sum_m gq, sum_m gq (z2 - mean2) invstd2 with gq = da2 * [scale2 z2 + shift2 > 0]
+//     bn2's backward sums: sum_m gq, sum_m gq (z2 - mean2) invstd2 with gq = da2 * [scale2 z2 + shift2 > 0]      (z_in = NULL: a conv whose input is
+//     not a BatchNorm's activation -- a downsample branch reading the block input -- skips them)
 // The un-fused step runs three launches for this (conv + BatchNorm-backward apply, data gradient + sums, weight gradient): dz3 -- a 4 x planes
 // tensor, 411 MB in layer1 of the R50 8x8 step -- is written once and read twice.  Here a persistent workgroup (8 waves, one per CU) walks
 // 64-pixel chunks of its row range and keeps the chunk's dz3 tile in LDS between three small matrix products:
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(kT) void pw_bwd_fused_kernel(const mvf_internal::Pw
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const bool role_a = wave < 4;                                    // GEMM 3 (waves 0-3) / GEMM 2 (waves 4-7)
+    const bool sums = a.z_in != nullptr;                             // the conv input is relu(bn_in(z_in)): gate the gradient and take bn_in's backward sums
 
     // ---- this thread's dz3 unit: channels [8 q, 8 q + 8), rows r0 + 16 i; bn3's backward coefficients (bn_bwd_apply_kernel's folding) ----
     const int q = tid & 31, r0 = tid >> 5;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(kT) void pw_bwd_fused_kernel(const mvf_internal::Pw
         const float rs = a.invstd[tid];
         Bs[tid] = a.gamma[tid] * rs; Bs[NC + tid] = a.dbeta[tid] * inv_m; Bs[2 * NC + tid] = rs * a.dgamma[tid] * inv_m; Bs[3 * NC + tid] = a.mean[tid];
     }
-    if (tid < NK) {
+    if (sums && tid < NK) {
         Cs[tid] = a.in_scale[tid]; Cs[NK + tid] = a.in_shift[tid]; Cs[2 * NK + tid] = a.in_mean[tid]; Cs[3 * NK + tid] = a.in_invstd[tid];
     }
 
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(kT) void pw_bwd_fused_kernel(const mvf_internal::Pw
     };
     auto dma_mz = [&](int cc) {
         const int mc = m_begin + cc * CH;
-        {                                                            // z2: rows 8 wave + (lane >> 3), unit lane & 7
+        if (sums) {                                                  // z2: rows 8 wave + (lane >> 3), unit lane & 7
             const int m = mc + rbx;
             glds16(gs_z, lds_z + (unsigned)((cc & 1) * CH * PX), m < m_end ? (unsigned)(m * NK + (tid & 7) * 8) * 2u : kOOB);
         }
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(kT) void pw_bwd_fused_kernel(const mvf_internal::Pw
         const int buf = cc & 1;
         const u32x4 pk = lds16(Ts + re * PX + ((ue ^ swz_x(re)) * 16));
         __builtin_amdgcn_raw_buffer_store_b128(pk, rs_dx, ok ? (unsigned)(m * NK + ue * 8) * 2u : kOOB, 0, 0);
+        if (!sums) return;
         const u32x4 zq = lds16(Zs + buf * CH * PX + re * PX + ue * 16);
         float vr[8], zv[8], sc[8], sh[8], mu[8], rs[8];
         unpack8(pk, vr);
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(kT) void pw_bwd_fused_kernel(const mvf_internal::Pw
 
     // ---- bn2's sums: the 64 row-threads of a channel unit in fixed order, in fp64; two fp32 partial rows per workgroup (value + remainder) ----
     __syncthreads();
-    {
+    if (sums) {
         float* red = reinterpret_cast<float*>(Gs);                   // [row re][unit ue][16]
         float* dst = red + (re * 8 + ue) * 16;
         *reinterpret_cast<float4*>(dst) = make_float4(s1[0], s1[1], s1[2], s1[3]);

@@ -1624,15 +1624,15 @@ int mvf_conv1x1_bwd_fused(const void* a_in, int a_pitch, const void* w_packed, c
                           int k, const float* gamma, const float* mean, const float* invstd, const float* dgamma, const float* dbeta, const void* z_in,
                           const float* in_mean, const float* in_invstd, const float* in_scale, const float* in_shift, void* dx, float* sums_part,
                           int sums_rows, float* slabs, size_t slab_bytes, int dtype, void* stream) {
-    MVF_REQUIRE(a_in && w_packed && g && sign_bits && gamma && mean && invstd && dgamma && dbeta && z_in && in_mean && in_invstd && in_scale && in_shift &&
-                    dx && sums_part && slabs && m > 0 && a_pitch >= k && g_pitch >= c, MVF_EINVAL, "conv1x1_bwd_fused: bad argument");
+    MVF_REQUIRE(a_in && w_packed && g && sign_bits && gamma && mean && invstd && dgamma && dbeta && dx && slabs && m > 0 && a_pitch >= k && g_pitch >= c &&
+                    (!z_in || (in_mean && in_invstd && in_scale && in_shift && sums_part)), MVF_EINVAL, "conv1x1_bwd_fused: bad argument");
     MVF_REQUIRE(dtype == MVF_BF16, MVF_EUNSUPPORTED, "conv1x1_bwd_fused: bf16 storage only");
     mvf_internal::PwBwdFusedArgs a = {};
     a.nsplit = mvf_internal::pw_bwd_fused_plan(m, c, k, &a.rows_per_split);
     MVF_REQUIRE(a.nsplit > 0, MVF_EUNSUPPORTED, "conv1x1_bwd_fused: built for 64 -> 256 channels (c=%d k=%d); use the separate calls", c, k);
-    MVF_REQUIRE(sums_rows == 2 * a.nsplit, MVF_EINVAL, "conv1x1_bwd_fused: sums_rows must be 2 x mvf_conv1x1_bwd_fused_splits (%d), got %d", 2 * a.nsplit, sums_rows);
+    MVF_REQUIRE(!z_in || sums_rows == 2 * a.nsplit, MVF_EINVAL, "conv1x1_bwd_fused: sums_rows must be 2 x mvf_conv1x1_bwd_fused_splits (%d), got %d", 2 * a.nsplit, sums_rows);
     MVF_REQUIRE(slab_bytes >= (size_t)a.nsplit * c * k * sizeof(float), MVF_EWS, "conv1x1_bwd_fused: slab buffer too small (splits x c x k floats)");
-    MVF_REQUIRE(a_pitch % 8 == 0 && g_pitch % 8 == 0 && al16(a_in) && al16(w_packed) && al16(g) && al16(z_in) && al16(dx) && ((uintptr_t)sign_bits & 1) == 0 &&
+    MVF_REQUIRE(a_pitch % 8 == 0 && g_pitch % 8 == 0 && al16(a_in) && al16(w_packed) && al16(g) && (!z_in || al16(z_in)) && al16(dx) && ((uintptr_t)sign_bits & 15) == 0 &&
                     m * (long)std::max(g_pitch, a_pitch) * 2 < 0x7ffffff0L, MVF_ESHAPE, "conv1x1_bwd_fused: alignment / 2 GB addressing");
     a.a = a_in; a.aps = a_pitch; a.w = w_packed; a.g = g; a.g_pitch = g_pitch; a.bits = sign_bits; a.M = (int)m;
     a.gamma = gamma; a.mean = mean; a.invstd = invstd; a.dgamma = dgamma; a.dbeta = dbeta;

@@ -315,11 +315,13 @@ class _TConv(object):
         return (self.eng.tdtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and self.stride == 1 and not self.stem and
                 lib.mvf_conv1x1_bwd_fused_splits(m, self.cout, self.cin) > 0)
 
-    def bwd_fused(self, a_in, g, bits, n, h, w, bn, bn_in, z_in):
+    def bwd_fused(self, a_in, g, bits, n, h, w, bn, bn_in=None, z_in=None, a_pitch=None):
         """[r4] bwd_recompute + dgrad_bnsums + wgrad of a z3-free block's last conv with dz3 kept on chip (mvf_conv1x1_bwd_fused): bn's dgamma / dbeta
         from the sums pass as before, then ONE launch that returns the gradient of the conv input (bn_in's backward sums finalised) and leaves the
-        weight gradient as partial slabs whose fixed-order reduce goes to the side stream."""
-        d = self.desc(n, h, w, h, w, self.cin)
+        weight gradient as partial slabs whose fixed-order reduce goes to the side stream.  bn_in = None: a conv that reads a block input (the downsample
+        branch): the plain data gradient, no sums."""
+        pitch = a_pitch or self.cin
+        d = self.desc(n, h, w, h, w, pitch)
         m = n * h * w
         ws = _conv_ws(a_in.device)
         rows = lib.mvf_conv2d_stats_rows(C.byref(d))
@@ -328,17 +330,20 @@ class _TConv(object):
         check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cout, _p(bn.dgamma), _p(bn.dbeta), _st()), "mvf_bn_bwd_finalize")
         ns = lib.mvf_conv1x1_bwd_fused_splits(m, self.cout, self.cin)
         dx = self.eng.buf((id(self), "dx"), (m, self.cin))
-        spart = self.eng.buf((id(self), "bnsums_fused"), (self.cin, 2 * ns, 2), torch.float32)
+        spart = self.eng.buf((id(self), "bnsums_fused"), (self.cin, 2 * ns, 2), torch.float32) if bn_in is not None else None
         slabs = self.eng.buf((id(self), "wslab"), (ns * self.cout * self.cin,), torch.float32)
-        self.launch_bwd_fused(m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs)
-        check(lib.mvf_bn_bwd_finalize(_p(spart), 2 * ns, self.cin, _p(bn_in.dgamma), _p(bn_in.dbeta), _st()), "bn bwd finalize")
+        self.launch_bwd_fused(m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs, pitch)
+        if bn_in is not None:
+            check(lib.mvf_bn_bwd_finalize(_p(spart), 2 * ns, self.cin, _p(bn_in.dgamma), _p(bn_in.dbeta), _st()), "bn bwd finalize")
         self.slab_reduce(slabs, ns, self.eng)
         return dx
 
-    def launch_bwd_fused(self, m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs):
+    def launch_bwd_fused(self, m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs, a_pitch=None):
         """Exactly one launch (bench.py brackets this call with HIP events)."""
-        check(lib.mvf_conv1x1_bwd_fused(_p(a_in), self.cin, _p(self.wp), _p(g), self.cout, _p(bits), m, self.cout, self.cin, _p(bn.gamma), _p(bn.mean),
-                                        _p(bn.invstd), _p(bn.dgamma), _p(bn.dbeta), _p(z_in), _p(bn_in.mean), _p(bn_in.invstd), _p(bn_in.scale), _p(bn_in.shift),
+        i = bn_in
+        check(lib.mvf_conv1x1_bwd_fused(_p(a_in), a_pitch or self.cin, _p(self.wp), _p(g), self.cout, _p(bits), m, self.cout, self.cin, _p(bn.gamma), _p(bn.mean),
+                                        _p(bn.invstd), _p(bn.dgamma), _p(bn.dbeta), _p(z_in) if i is not None else None, _p(i.mean) if i else None,
+                                        _p(i.invstd) if i else None, _p(i.scale) if i else None, _p(i.shift) if i else None,
                                         _p(dx), _p(spart), 2 * ns, _p(slabs), slabs.numel() * 4, self.eng.dt, _st()), "conv1x1 backward fused")
 
     def launch_bwd_sums(self, d, a_in, g, bits, bn, part, ws):
@@ -525,7 +530,9 @@ class _TBlock(object):
         """[r3] The block never stores z3 (reference resnet.py:229-244: out = relu(bn3(conv3(a2)) + identity)): a statistics-only conv3 pass, the
         fused apply pass, and bn3's backward on the recomputed conv (eng.z3_free).  Plain blocks only: a downsample block's paired backward
         reads z3 and z_d in one pass over g; needs batch statistics fused into the conv epilogue."""
-        if not (eng.z3_free and self.cd is None and self.fuse_apply(eng) and eng.fuse_stats and not self.b3.frozen):
+        if self.cd is not None:
+            return self.z3_free_ds(eng)
+        if not (eng.z3_free and self.fuse_apply(eng) and eng.fuse_stats and not self.b3.frozen):
             return False
         if (eng.fuse_bnwg & 8) and eng.tdtype == torch.bfloat16 and lib.mvf_bn_bwd_wgrad_splits(1 << 16, self.c3.cout, self.c3.cin, 1, 4) > 0:
             return False           # A/B: stored z3 + conv3's weight gradient in bn3's backward apply instead
@@ -533,6 +540,18 @@ class _TBlock(object):
         # backward sums 168 -> 205 / 102 -> 119 (the conv kernel's sum epilogue streams g at 2.7 TB/s, the BatchNorm kernel at 5.2), backward apply
         # 242 -> 204 / 116 -> 119: -70 per layer1 block, ~0 per layer2 block -> planes <= 64 by default, 2 = every block with the fused apply
         return eng.z3_free == 2 or self.c3.cin <= 64
+
+    def z3_free_ds(self, eng):
+        """[r4] A DOWNSAMPLE block (reference resnet.py:227-233: out = relu(bn3(conv3(a2)) + bn_d(conv_d(x)))) that does not store z3 and reads neither z3 nor
+        z_d in backward: forward = conv3's statistics-only pass + the fused apply pass with the stored z_d as the residual operand; backward = per branch
+        the sums pass on the recomputed conv (pw_sums) and the one-pass kernel of csrc/pw_bwd_fused.hip (conv3: + bn2's sums; the downsample conv: the
+        plain data gradient) instead of the paired BatchNorm backward (two dz tensors written, each read twice).  Where that kernel is built: both convs
+        64 -> 256 channels pointwise stride 1 (layer1.0), bf16."""
+        if not (eng.z3_free_ds and eng.z3_free and eng.fuse_c3_bwd and eng.fuse_bn_bwd_sums and eng.fuse_stats and self.fuse_apply(eng) and eng.tdtype == torch.bfloat16):
+            return False
+        if self.b3.frozen or self.bd.frozen or self.cd.stride != 1 or self.cd.kh != 1 or self.cd.kw != 1 or self.cd.cin != self.c3.cin or self.cd.cout != self.c3.cout:
+            return False
+        return lib.mvf_conv1x1_bwd_fused_splits(1 << 16, self.c3.cout, self.c3.cin) > 0
 
     def forward(self, x, nt, h, w, c, eng):
         m = nt * h * w
@@ -588,9 +607,14 @@ class _TBlock(object):
         # data-gradient GEMM that shares its dz has been queued on the main stream, so it starts when the main stream
         # moves on to the (HBM-bound) BatchNorm-backward kernels of the next layer -- MFMA work under memory work --
         # instead of fighting the data-gradient GEMM for the matrix cores.
-        dzd = resid_aux = aux = None
+        dzd = resid_aux = aux = resid_ds = None
         w3_done = wd_done = False        # [r4] weight gradient already taken inside the BatchNorm-backward pass
-        if self.cd is not None and eng.pair_bn_bwd and not (self.b3.frozen or self.bd.frozen):
+        if self.cd is not None and s["z3"] is None:
+            # [r4] z3-free downsample block: each branch = sums pass + one-pass backward on the recomputed conv; neither dz3 nor dz_d exists
+            da2 = self.c3.bwd_fused(s["a2"], g, bits, nt, ho, wo, self.b3, self.b2, s["z2"])
+            resid_ds = self.cd.bwd_fused(s["x"], g, bits, nt, h, w, self.bd, a_pitch=c)
+            dz3, w3_done, wd_done = None, True, True
+        elif self.cd is not None and eng.pair_bn_bwd and not (self.b3.frozen or self.bd.frozen):
             if (eng.fuse_bnwg & 2) and self.c3.fuses_wgrad(eng, m2, self.c3.cout, 4, 2):
                 both = self.cd.stride == 1 and self.cd.cin == self.c3.cin and self.cd.kh == 1
                 dz3, dzd = _BN.backward_pair_wgrad(self.b3, self.bd, g, self.c3.cout, s["z3"], s["zd"], m2, eng, bits, self.c3, s["a2"], self.c3.cin,
@@ -642,7 +666,9 @@ class _TBlock(object):
             dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2, sums_done=fuse1)
         del da1
         resid, rbits = g, bits
-        if self.cd is not None:
+        if resid_ds is not None:
+            resid, rbits = resid_ds, None
+        elif self.cd is not None:
             if dzd is None:
                 dzd = self.bd.backward(g, self.cd.cout, s["zd"], m2, eng, 4, ymask=bits)
             if resid_aux is not None:
@@ -783,6 +809,7 @@ class _ParamStore(object):
     # 1 conv3 of plain stored-z3 blocks, 2 conv3 (+ stride-1 downsample conv) of downsample blocks, 4 conv1 of blocks without MVF,
     # 8 also give up the z3-free path of layer1's plain blocks for it)
     fuse_bnwg = int(os.environ.get("MVF_FUSE_BNWG", "7"))
+    z3_free_ds = int(os.environ.get("MVF_Z3_FREE_DS", "1"))    # [r4] layer1.0 (downsample block, both convs 64 -> 256 pointwise): no stored z3, per-branch sums + one-pass backward instead of the paired BatchNorm backward
     fuse_c3_bwd = int(os.environ.get("MVF_FUSE_C3_BWD", "1"))   # [r4] z3-free blocks: conv3 recompute + bn3 backward apply + data gradient (+ bn2 sums) + weight gradient in ONE pass (csrc/pw_bwd_fused.hip); 0 = three launches
     fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes
 

@@ -130,3 +130,31 @@ def test_conv1x1_bwd_fused_against_fp32_restatement():
     assert lib.mvf_conv1x1_bwd_fused(P(t["a2"]), cin, P(ref["wp"]), P(t["g"]), cout, P(t["bits"]), m, cout, cin, P(t["gamma"]), P(t["mean"]), P(t["invstd"]),
                                      P(ref["dg"]), P(ref["db"]), P(t["z2"]), P(t["mean2"]), P(t["invstd2"]), P(t["scale2"]), P(t["shift2"]), P(dx), P(spart),
                                      2 * ns, P(slabs), slabs.numel() * 4, 0, None) == -5
+
+
+@pytest.mark.parametrize("m", [64 * 33 + 5, 2 * 56 * 56], ids=str)
+def test_conv1x1_bwd_fused_without_input_batchnorm(m):
+    """z_in = NULL (a downsample branch reading the block input, reference resnet.py:227-228): the same data gradient and weight gradient bit for bit, no
+    sums taken (the partial-row buffer is not touched)."""
+    from mvfnet_amd import _lib
+    lib, check, ConvDesc = _lib.lib, _lib.check, _lib.ConvDesc
+    cin, cout = 64, 256
+    t = _inputs(m, seed=m + 1)
+    ref = _three_launches(lib, check, ConvDesc, t, m)
+    ns = lib.mvf_conv1x1_bwd_fused_splits(m, cout, cin)
+    out = {}
+    for with_bn in (True, False):
+        dx = torch.full((m, cin), 7.0, dtype=torch.bfloat16, device="cuda")
+        spart = torch.full((cin, 2 * ns, 2), 3.0, device="cuda")
+        slabs = torch.full((ns * cout * cin,), float("nan"), device="cuda")
+        check(lib.mvf_conv1x1_bwd_fused(P(t["a2"]), cin, P(ref["wp"]), P(t["g"]), cout, P(t["bits"]), m, cout, cin, P(t["gamma"]), P(t["mean"]), P(t["invstd"]),
+                                        P(ref["dg"]), P(ref["db"]), P(t["z2"]) if with_bn else None, P(t["mean2"]) if with_bn else None,
+                                        P(t["invstd2"]) if with_bn else None, P(t["scale2"]) if with_bn else None, P(t["shift2"]) if with_bn else None,
+                                        P(dx), P(spart) if with_bn else None, 2 * ns if with_bn else 0, P(slabs), slabs.numel() * 4, 1, None), "conv1x1_bwd_fused")
+        dw = torch.empty(cout, cin, 1, 1, device="cuda")
+        check(lib.mvf_wgrad_slab_reduce(P(slabs), ns, cout, cin, P(dw), None))
+        torch.cuda.synchronize()
+        out[with_bn] = (dx, dw, spart)
+    assert torch.equal(out[True][0].view(torch.int16), out[False][0].view(torch.int16)) and torch.equal(out[True][0].view(torch.int16), ref["dx"].view(torch.int16))
+    assert torch.equal(out[True][1], out[False][1])
+    assert bool((out[False][2] == 3.0).all())

@@ -971,13 +971,21 @@ def test_engine_switch_variants_reproduce_the_default_step(dtype):
         got8 = run(steps=1, fuse_bnwg=15)             # ... also with layer1's plain blocks on stored z3 + the fused pass instead of the z3-free path
         assert abs(got8[0][0] - ref[0][0]) < 1e-2 * abs(ref[0][0]) and rel_l2(got8[1].cpu().numpy(), ref[1].cpu().numpy()) < 1e-2
     # [r4] fuse_c3_bwd: the z3-free blocks' conv3 backward in ONE pass (csrc/pw_bwd_fused.hip; bf16 only, a no-op in fp32): the same dz3 bit for bit,
-    # kept on chip; its data gradient is contracted in two channel halves (a few one-ulp flips of da2), its weight gradient per persistent workgroup
-    got, ref = run(steps=1, fuse_c3_bwd=0), run(steps=1)
+    # kept on chip; its data gradient bit for bit, bn2's sums and the weight gradient summed per persistent workgroup (fp32 summation order).  (With the
+    # downsample block's z3-free mode off on both sides: it depends on this switch and changes the FORWARD's statistics pass.)
+    got, ref = run(steps=1, fuse_c3_bwd=0, z3_free_ds=0), run(steps=1, z3_free_ds=0)
     assert got[0] == ref[0]
     if dtype == torch.float32:
         assert torch.equal(got[1], ref[1])
     else:
         assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < 1e-2
+    # [r4] z3_free_ds: layer1.0 (the downsample block whose two convs are 64 -> 256 pointwise) without a stored z3 and without the paired BatchNorm
+    # backward: per branch the sums pass on the recomputed conv + the one-pass backward (bf16 only; a no-op in fp32)
+    got, ref = run(steps=1, z3_free_ds=0), run(steps=1)
+    if dtype == torch.float32:
+        assert got[0] == ref[0] and torch.equal(got[1], ref[1])
+    else:
+        assert abs(got[0][0] - ref[0][0]) < 1e-2 * abs(ref[0][0]) and rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < 1e-2
     # one step only: the 2-clip batch-statistics network amplifies last-bit differences by orders of magnitude per step
     got, ref = run(steps=1, fuse_stem_bwd=0), run(steps=1)
     tol = 1e-5 if dtype == torch.float32 else 1e-3          # bf16: the stem's dz is re-rounded from sums that differ in the last bits
