@@ -223,6 +223,11 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         nbytes = esz * ((3 if bn_in is not None else 2) * m * self.cin + m * self.cout + self.w.numel()) + m * self.cout // 4 + 4 * self.w.numel()      # a2, (z2,) dx, g, bits, W, dW
         return (3 * 2.0 * m * self.cout * self.cin, "bwd-fused M%d N%d K%d (apply + dgrad + wgrad)" % (m, self.cout, self.cin), nbytes)
 
+    def dbsp(self, out, a2, x, x_pitch, g, bits, m, eng_):      # [r4] bn3's and bn_d's backward sums of a z3-free downsample block: both convs again, g and the bits once
+        c3 = self.c3
+        nbytes = esz * (2 * m * c3.cin + m * c3.cout + 2 * c3.w.numel()) + m * c3.cout // 4
+        return (2 * 2.0 * m * c3.cout * c3.cin, "bwd-sums(pair) M%d N%d K%d" % (m, c3.cout, c3.cin), nbytes)
+
     def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
         fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin          # algorithmic = the forward conv's MACs
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * (2 if residual is not None else 1) + self.w.numel())
@@ -272,7 +277,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         return (2.0 * m * d.cs * taps, "mvf stencil%s M%d Cs%d" % ("^T" if flip else "", m, d.cs), nb)
 
     undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "launch_fwd_apply", dfap), tc.wrap(TE._TConv, "launch_bwd_sums", dbws), tc.wrap(TE._TConv, "launch_bwd_apply", dbwa),
-            tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb), tc.wrap(TE._TConv, "launch_bwd_fused", dbwf),
+            tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb), tc.wrap(TE._TConv, "launch_bwd_fused", dbwf), tc.wrap(TE._TBlock, "launch_sums_pair", dbsp),
             tw.wrap(TE._TConv, "wgrad", dwgr), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
             tb.wrap(TE._BN, "backward_pair", dbpr),
             tm.wrap(TE._TMvf, "launch_stencil", dmvf), tf.wrap(TE._BN, "_apply_bwd_wgrad", dbaw), tf.wrap(TE._BN, "backward_pair_wgrad", dbpw)]

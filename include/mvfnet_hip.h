@@ -299,6 +299,13 @@ int mvf_conv1x1_bwd_fused(const void* a_in, int a_pitch, const void* w_packed, c
                           int k, const float* gamma, const float* mean, const float* invstd, const float* dgamma, const float* dbeta, const void* z_in,
                           const float* in_mean, const float* in_invstd, const float* in_scale, const float* in_shift, void* dx, float* sums_part,
                           int sums_rows, float* slabs, size_t slab_bytes, int dtype, void* stream);
+/* [r4] BatchNorm-backward sums of BOTH branches of a downsample bottleneck that stored no z3 (resnet.py:227-244: out = relu(bn3(conv3(a2)) + bn_d(conv_d(x)))) in one
+ * pass over g: sum gm and sum gm xhat for bn3 (a: conv3 on a_in) and bn_d (b: the downsample conv on x_in), both convs recomputed, g and the sign bits read once
+ * (mvf_conv2d_nhwc_fwd_bnbwd_sums twice reads them twice).  Partial rows [256][rows][2] each for mvf_bn_bwd_finalize, rows = 2 x mvf_conv1x1_bwd_fused_splits.
+ * bf16 storage, c = 256, k = 64 for both convs. */
+int mvf_conv1x1_bnbwd_sums_pair(const void* a_in, int a_pitch, const void* w_a, const void* x_in, int x_pitch, const void* w_b, const void* g, int g_pitch,
+                                const unsigned char* sign_bits, long m, int c, int k, const float* mean_a, const float* invstd_a, const float* mean_b,
+                                const float* invstd_b, float* part_a, float* part_b, int rows, int dtype, void* stream);
 int mvf_wgrad_slab_reduce(const float* slabs, int nsplit, int cout, int k, float* dw_oihw, void* stream);
 /* stem: y = maxpool3x3/2(relu(z*scale+shift)) (resnet.py:482-484).  argmax (optional, one byte per element of y) receives
  * the window position dy*3+dx of the first maximum; the backward routes g to it: ga = dL/d relu(bn(z)). */

@@ -149,6 +149,8 @@ def _load():
     lib.mvf_conv1x1_bwd_fused_splits.argtypes = [i64, i32, i32]
     lib.mvf_conv1x1_bwd_fused.restype = i32
     lib.mvf_conv1x1_bwd_fused.argtypes = [vp, i32, vp, vp, i32, vp, i64, i32, i32, fp, fp, fp, fp, fp, vp, fp, fp, fp, fp, vp, fp, i32, fp, sz, i32, vp]
+    lib.mvf_conv1x1_bnbwd_sums_pair.restype = i32
+    lib.mvf_conv1x1_bnbwd_sums_pair.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, fp, fp, fp, fp, fp, fp, i32, i32, vp]
     lib.mvf_wgrad_slab_reduce.restype = i32
     lib.mvf_wgrad_slab_reduce.argtypes = [fp, i32, i32, i32, fp, vp]
     lib.mvf_ce_loss.restype = i32

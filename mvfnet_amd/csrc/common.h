@@ -165,6 +165,17 @@ struct PwBwdFusedArgs {
     int aps, g_pitch, M, sums_rows, rows_per_split, nsplit;
     int ablate;                 // -DMVF_PWBF_ABLATE builds only: phases to skip (timing experiments)
 };
+// BatchNorm-backward sums of both branches of a z3-free downsample bottleneck in one pass over g (pw_sums_pair.hip); splits as pw_bwd_fused_plan
+struct PwSumsPairArgs {
+    const void *a, *x;          // (M, aps / xps >= 64) bf16 inputs of conv a (conv3) / conv b (the downsample conv), channels [0, 64)
+    const void *w_a, *w_b;      // packed weights [256][64] bf16
+    const void* g;              // (M, g_pitch >= 256) bf16
+    const unsigned char* bits;  // (M, 64) bytes
+    const float *mean_a, *invstd_a, *mean_b, *invstd_b;
+    float *part_a, *part_b;     // [256][rows][2] out, rows = 2 x nsplit
+    int aps, xps, g_pitch, M, rows, rows_per_split, nsplit;
+};
+int pw_sums_pair_launch(const PwSumsPairArgs& a, hipStream_t st);
 int pw_bwd_fused_plan(long m, int c, int k, int* rows_per_split);
 int pw_bwd_fused_launch(const PwBwdFusedArgs& a, hipStream_t st);
 bool bnbwd_wgrad_tile(int c, int k, int nbn, int mask_mode, int* ct, int* kt);

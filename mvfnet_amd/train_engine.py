@@ -315,7 +315,7 @@ class _TConv(object):
         return (self.eng.tdtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and self.stride == 1 and not self.stem and
                 lib.mvf_conv1x1_bwd_fused_splits(m, self.cout, self.cin) > 0)
 
-    def bwd_fused(self, a_in, g, bits, n, h, w, bn, bn_in=None, z_in=None, a_pitch=None):
+    def bwd_fused(self, a_in, g, bits, n, h, w, bn, bn_in=None, z_in=None, a_pitch=None, sums_done=False):
         """[r4] bwd_recompute + dgrad_bnsums + wgrad of a z3-free block's last conv with dz3 kept on chip (mvf_conv1x1_bwd_fused): bn's dgamma / dbeta
         from the sums pass as before, then ONE launch that returns the gradient of the conv input (bn_in's backward sums finalised) and leaves the
         weight gradient as partial slabs whose fixed-order reduce goes to the side stream.  bn_in = None: a conv that reads a block input (the downsample
@@ -325,9 +325,10 @@ class _TConv(object):
         m = n * h * w
         ws = _conv_ws(a_in.device)
         rows = lib.mvf_conv2d_stats_rows(C.byref(d))
-        part = self.eng.buf((id(self), "bwpart"), (rows, self.cout, 2), torch.float32)
-        self.launch_bwd_sums(d, a_in, g, bits, bn, part, ws)
-        check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cout, _p(bn.dgamma), _p(bn.dbeta), _st()), "mvf_bn_bwd_finalize")
+        if not sums_done:          # (a downsample block takes both branches' sums in one pass over g: _TBlock.backward)
+            part = self.eng.buf((id(self), "bwpart"), (rows, self.cout, 2), torch.float32)
+            self.launch_bwd_sums(d, a_in, g, bits, bn, part, ws)
+            check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cout, _p(bn.dgamma), _p(bn.dbeta), _st()), "mvf_bn_bwd_finalize")
         ns = lib.mvf_conv1x1_bwd_fused_splits(m, self.cout, self.cin)
         dx = self.eng.buf((id(self), "dx"), (m, self.cin))
         spart = self.eng.buf((id(self), "bnsums_fused"), (self.cin, 2 * ns, 2), torch.float32) if bn_in is not None else None
@@ -553,6 +554,17 @@ class _TBlock(object):
             return False
         return lib.mvf_conv1x1_bwd_fused_splits(1 << 16, self.c3.cout, self.c3.cin) > 0
 
+    def launch_sums_pair(self, a2, x, x_pitch, g, bits, m, eng):
+        """Exactly one launch (bench.py brackets this call with HIP events) + the two finalizes."""
+        c3, cd = self.c3, self.cd
+        ns = lib.mvf_conv1x1_bwd_fused_splits(m, c3.cout, c3.cin)
+        pa = eng.buf((id(c3), "bwpart_pair"), (c3.cout, 2 * ns, 2), torch.float32)
+        pb = eng.buf((id(cd), "bwpart_pair"), (c3.cout, 2 * ns, 2), torch.float32)
+        check(lib.mvf_conv1x1_bnbwd_sums_pair(_p(a2), c3.cin, _p(c3.wp), _p(x), x_pitch, _p(cd.wp), _p(g), c3.cout, _p(bits), m, c3.cout, c3.cin, _p(self.b3.mean),
+                                              _p(self.b3.invstd), _p(self.bd.mean), _p(self.bd.invstd), _p(pa), _p(pb), 2 * ns, eng.dt, _st()), "bn backward sums (pair)")
+        check(lib.mvf_bn_bwd_finalize(_p(pa), 2 * ns, c3.cout, _p(self.b3.dgamma), _p(self.b3.dbeta), _st()), "mvf_bn_bwd_finalize")
+        check(lib.mvf_bn_bwd_finalize(_p(pb), 2 * ns, c3.cout, _p(self.bd.dgamma), _p(self.bd.dbeta), _st()), "mvf_bn_bwd_finalize")
+
     def forward(self, x, nt, h, w, c, eng):
         m = nt * h * w
         s = dict(x=x, h=h, w=w, c=c)
@@ -611,8 +623,11 @@ class _TBlock(object):
         w3_done = wd_done = False        # [r4] weight gradient already taken inside the BatchNorm-backward pass
         if self.cd is not None and s["z3"] is None:
             # [r4] z3-free downsample block: each branch = sums pass + one-pass backward on the recomputed conv; neither dz3 nor dz_d exists
-            da2 = self.c3.bwd_fused(s["a2"], g, bits, nt, ho, wo, self.b3, self.b2, s["z2"])
-            resid_ds = self.cd.bwd_fused(s["x"], g, bits, nt, h, w, self.bd, a_pitch=c)
+            pair = bool(eng.pair_ds_sums)
+            if pair:           # bn3's and bn_d's sums in ONE pass over g (csrc/pw_sums_pair.hip)
+                self.launch_sums_pair(s["a2"], s["x"], c, g, bits, m2, eng)
+            da2 = self.c3.bwd_fused(s["a2"], g, bits, nt, ho, wo, self.b3, self.b2, s["z2"], sums_done=pair)
+            resid_ds = self.cd.bwd_fused(s["x"], g, bits, nt, h, w, self.bd, a_pitch=c, sums_done=pair)
             dz3, w3_done, wd_done = None, True, True
         elif self.cd is not None and eng.pair_bn_bwd and not (self.b3.frozen or self.bd.frozen):
             if (eng.fuse_bnwg & 2) and self.c3.fuses_wgrad(eng, m2, self.c3.cout, 4, 2):
@@ -809,6 +824,7 @@ class _ParamStore(object):
     # 1 conv3 of plain stored-z3 blocks, 2 conv3 (+ stride-1 downsample conv) of downsample blocks, 4 conv1 of blocks without MVF,
     # 8 also give up the z3-free path of layer1's plain blocks for it)
     fuse_bnwg = int(os.environ.get("MVF_FUSE_BNWG", "7"))
+    pair_ds_sums = int(os.environ.get("MVF_PAIR_DS_SUMS", "1"))    # [r4] that block: bn3's and bn_d's backward sums in one pass over g (csrc/pw_sums_pair.hip); 0 = two pw_sums passes
     z3_free_ds = int(os.environ.get("MVF_Z3_FREE_DS", "1"))    # [r4] layer1.0 (downsample block, both convs 64 -> 256 pointwise): no stored z3, per-branch sums + one-pass backward instead of the paired BatchNorm backward
     fuse_c3_bwd = int(os.environ.get("MVF_FUSE_C3_BWD", "1"))   # [r4] z3-free blocks: conv3 recompute + bn3 backward apply + data gradient (+ bn2 sums) + weight gradient in ONE pass (csrc/pw_bwd_fused.hip); 0 = three launches
     fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes

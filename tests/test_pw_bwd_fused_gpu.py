@@ -158,3 +158,49 @@ def test_conv1x1_bwd_fused_without_input_batchnorm(m):
     assert torch.equal(out[True][0].view(torch.int16), out[False][0].view(torch.int16)) and torch.equal(out[True][0].view(torch.int16), ref["dx"].view(torch.int16))
     assert torch.equal(out[True][1], out[False][1])
     assert bool((out[False][2] == 3.0).all())
+
+
+@pytest.mark.parametrize("m", [64 * 33 + 5, 300, 256 * 56 * 56], ids=str)
+def test_bnbwd_sums_pair_equals_two_sums_passes(m):
+    """mvf_conv1x1_bnbwd_sums_pair (csrc/pw_sums_pair.hip): dgamma / dbeta of bn3 and bn_d against two mvf_conv2d_nhwc_fwd_bnbwd_sums passes and against fp64 sums
+    over the recomputed, bf16-rounded conv outputs."""
+    from mvfnet_amd import _lib
+    lib, check, ConvDesc = _lib.lib, _lib.check, _lib.ConvDesc
+    cin, cout = 64, 256
+    t = _inputs(m, seed=m + 2)
+    gen = torch.Generator().manual_seed(m)
+    xb = torch.randn(m, cin, generator=gen).to("cuda", torch.bfloat16)
+    wb = (torch.randn(cout, cin, 1, 1, generator=gen) * (2.0 / cin) ** 0.5).cuda()
+    mean_b, invstd_b = (torch.randn(cout, generator=gen) * 0.1).cuda(), (torch.rand(cout, generator=gen) + 0.5).cuda()
+    wpa, wpb = torch.empty(cout, 1, 1, cin, dtype=torch.bfloat16, device="cuda"), torch.empty(cout, 1, 1, cin, dtype=torch.bfloat16, device="cuda")
+    check(lib.mvf_pack_conv_weight(P(t["w"]), cout, cin, 1, 1, 1, cin, None, P(wpa), 1, None))
+    check(lib.mvf_pack_conv_weight(P(wb), cout, cin, 1, 1, 1, cin, None, P(wpb), 1, None))
+    d = ConvDesc(1, m, 1, cin, cout, 1, 1, 1, 0, m, 1, cin, 1, 0, 0, 0, 0, 0)
+    ws = torch.zeros(max(lib.mvf_conv2d_workspace_bytes(C.byref(d)), 1), dtype=torch.uint8, device="cuda")
+    rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+    want = []
+    for inp, wp, mu, rs in ((t["a2"], wpa, t["mean"], t["invstd"]), (xb, wpb, mean_b, invstd_b)):
+        sp = torch.empty(cout, rows, 2, device="cuda")
+        check(lib.mvf_conv2d_nhwc_fwd_bnbwd_sums(C.byref(d), P(inp), None, P(wp), P(t["g"]), P(t["bits"]), P(mu), P(rs), P(sp), P(ws), ws.numel(), None))
+        dg, db = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
+        check(lib.mvf_bn_bwd_finalize(P(sp), rows, cout, P(dg), P(db), None))
+        want.append((dg, db))
+    ns = lib.mvf_conv1x1_bwd_fused_splits(m, cout, cin)
+    pa, pb = torch.full((cout, 2 * ns, 2), float("nan"), device="cuda"), torch.full((cout, 2 * ns, 2), float("nan"), device="cuda")
+    check(lib.mvf_conv1x1_bnbwd_sums_pair(P(t["a2"]), cin, P(wpa), P(xb), cin, P(wpb), P(t["g"]), cout, P(t["bits"]), m, cout, cin, P(t["mean"]), P(t["invstd"]),
+                                          P(mean_b), P(invstd_b), P(pa), P(pb), 2 * ns, 1, None), "sums pair")
+    got = []
+    for part in (pa, pb):
+        dg, db = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
+        check(lib.mvf_bn_bwd_finalize(P(part), 2 * ns, cout, P(dg), P(db), None))
+        got.append((dg, db))
+    torch.cuda.synchronize()
+    mask = torch.stack([(t["bits"] >> j) & 1 for j in range(4)], dim=-1).reshape(m, cout).double()
+    gm = t["g"].double() * mask
+    for (dg, db), (wdg, wdb), (inp, w, mu, rs) in zip(got, want, ((t["a2"], t["w"], t["mean"], t["invstd"]), (xb, wb, mean_b, invstd_b))):
+        assert torch.isfinite(dg).all() and torch.isfinite(db).all()
+        assert rel_err(dg.cpu().numpy(), wdg.cpu().numpy()) < 3e-6 and rel_err(db.cpu().numpy(), wdb.cpu().numpy()) < 3e-6
+        z = (inp.float() @ w.view(cout, cin).to(torch.bfloat16).float().t()).to(torch.bfloat16).double()
+        ref_db = gm.sum(0)
+        ref_dg = (gm * ((z - mu.double()) * rs.double())).sum(0)
+        assert rel_err(db.cpu().numpy(), ref_db.float().cpu().numpy()) < 3e-6 and rel_err(dg.cpu().numpy(), ref_dg.float().cpu().numpy()) < 2e-5
