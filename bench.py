@@ -228,6 +228,9 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         nbytes = esz * (2 * m * c3.cin + m * c3.cout + 2 * c3.w.numel()) + m * c3.cout // 4
         return (2 * 2.0 * m * c3.cout * c3.cin, "bwd-sums(pair) M%d N%d K%d" % (m, c3.cout, c3.cin), nbytes)
 
+    def dbs1(self, out, m, a_in, a_pitch, g, bits, bn, part, ns):      # [r4] conv3 again + bn3 backward sums on the one-branch form of pw_sums_pair
+        return (2.0 * m * self.cout * self.cin, "bwd-sums M%d N%d K%d" % (m, self.cout, self.cin), esz * (m * self.cin + m * self.cout + self.w.numel()) + m * self.cout // 4)
+
     def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
         fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin          # algorithmic = the forward conv's MACs
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * (2 if residual is not None else 1) + self.w.numel())
@@ -277,7 +280,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         return (2.0 * m * d.cs * taps, "mvf stencil%s M%d Cs%d" % ("^T" if flip else "", m, d.cs), nb)
 
     undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "launch_fwd_apply", dfap), tc.wrap(TE._TConv, "launch_bwd_sums", dbws), tc.wrap(TE._TConv, "launch_bwd_apply", dbwa),
-            tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb), tc.wrap(TE._TConv, "launch_bwd_fused", dbwf), tc.wrap(TE._TBlock, "launch_sums_pair", dbsp),
+            tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb), tc.wrap(TE._TConv, "launch_bwd_fused", dbwf), tc.wrap(TE._TBlock, "launch_sums_pair", dbsp), tc.wrap(TE._TConv, "launch_bwd_sums1", dbs1),
             tw.wrap(TE._TConv, "wgrad", dwgr), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
             tb.wrap(TE._BN, "backward_pair", dbpr),
             tm.wrap(TE._TMvf, "launch_stencil", dmvf), tf.wrap(TE._BN, "_apply_bwd_wgrad", dbaw), tf.wrap(TE._BN, "backward_pair_wgrad", dbpw)]

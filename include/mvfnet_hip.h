@@ -302,7 +302,7 @@ int mvf_conv1x1_bwd_fused(const void* a_in, int a_pitch, const void* w_packed, c
 /* [r4] BatchNorm-backward sums of BOTH branches of a downsample bottleneck that stored no z3 (resnet.py:227-244: out = relu(bn3(conv3(a2)) + bn_d(conv_d(x)))) in one
  * pass over g: sum gm and sum gm xhat for bn3 (a: conv3 on a_in) and bn_d (b: the downsample conv on x_in), both convs recomputed, g and the sign bits read once
  * (mvf_conv2d_nhwc_fwd_bnbwd_sums twice reads them twice).  Partial rows [256][rows][2] each for mvf_bn_bwd_finalize, rows = 2 x mvf_conv1x1_bwd_fused_splits.
- * bf16 storage, c = 256, k = 64 for both convs. */
+ * x_in = NULL: the sums of bn3 alone (a plain block: conv a only; w_b / mean_b / invstd_b / part_b unused).  bf16 storage, c = 256, k = 64 for both convs. */
 int mvf_conv1x1_bnbwd_sums_pair(const void* a_in, int a_pitch, const void* w_a, const void* x_in, int x_pitch, const void* w_b, const void* g, int g_pitch,
                                 const unsigned char* sign_bits, long m, int c, int k, const float* mean_a, const float* invstd_a, const float* mean_b,
                                 const float* invstd_b, float* part_a, float* part_b, int rows, int dtype, void* stream);

@@ -1,5 +1,5 @@
 // BatchNorm-backward sums of BOTH branches of a z3-free downsample bottleneck in one pass over the block-output gradient (gfx950, bf16 storage,
-// both convs 64 -> 256 channels pointwise: layer1.0 of the ResNet).
+// both convs 64 -> 256 channels pointwise: layer1.0 of the ResNet) -- and, with x = NULL, of the one branch of a plain z3-free block (NBR = 1).
 //
 // Reference arithmetic: autograd of Bottleneck.forward (codes/models/backbones/resnet.py:227-244): out = relu(bn3(conv3(a2)) + bn_d(conv_d(x))).  With
 // g = dL/dout and gm = g * [out > 0] both BatchNorms receive the same gated gradient:
@@ -36,6 +36,7 @@ __device__ __forceinline__ u32x4 lds16(const char* p) {
     return r;
 }
 
+template <int NBR>                                                    // 2 = both branches of a downsample block; 1 = conv a only (a plain z3-free block)
 __global__ __launch_bounds__(kT) void pw_sums_pair_kernel(const mvf_internal::PwSumsPairArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem + kOffA;                                         // [2][CH][PX]   a2 (conv a's input)
@@ -57,9 +58,12 @@ __global__ __launch_bounds__(kT) void pw_sums_pair_kernel(const mvf_internal::Pw
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const long o = ((long)(32 * wave + l31) * NK + ks * 16 + half * 8) * 2;
-            const uint4 va = *reinterpret_cast<const uint4*>(pa + o), vb = *reinterpret_cast<const uint4*>(pb + o);
+            const uint4 va = *reinterpret_cast<const uint4*>(pa + o);
             __builtin_memcpy(&wa[ks], &va, 16);
-            __builtin_memcpy(&wb[ks], &vb, 16);
+            if constexpr (NBR == 2) {
+                const uint4 vb = *reinterpret_cast<const uint4*>(pb + o);
+                __builtin_memcpy(&wb[ks], &vb, 16);
+            }
         }
     }
     float mua[16], rsa[16], mub[16], rsb[16];
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(kT) void pw_sums_pair_kernel(const mvf_internal::Pw
     for (int g4 = 0; g4 < 4; ++g4) {
         const int c = 32 * wave + 8 * g4 + 4 * half;
         const float4 m0 = *reinterpret_cast<const float4*>(a.mean_a + c), r0 = *reinterpret_cast<const float4*>(a.invstd_a + c);
-        const float4 m1 = *reinterpret_cast<const float4*>(a.mean_b + c), r1 = *reinterpret_cast<const float4*>(a.invstd_b + c);
+        float4 m1 = m0, r1 = r0;
+        if constexpr (NBR == 2) { m1 = *reinterpret_cast<const float4*>(a.mean_b + c); r1 = *reinterpret_cast<const float4*>(a.invstd_b + c); }
         mua[4 * g4] = m0.x; mua[4 * g4 + 1] = m0.y; mua[4 * g4 + 2] = m0.z; mua[4 * g4 + 3] = m0.w;
         rsa[4 * g4] = r0.x; rsa[4 * g4 + 1] = r0.y; rsa[4 * g4 + 2] = r0.z; rsa[4 * g4 + 3] = r0.w;
         mub[4 * g4] = m1.x; mub[4 * g4 + 1] = m1.y; mub[4 * g4 + 2] = m1.z; mub[4 * g4 + 3] = m1.w;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(kT) void pw_sums_pair_kernel(const mvf_internal::Pw
             const int m = mc + rbx;
             const bool ok = m < m_end;
             glds16(gs_a, lds_a + (unsigned)(buf * CH * PX), ok ? (unsigned)(m * a.aps + qbx * 8) * 2u : kOOB);
-            glds16(gs_x, lds_x + (unsigned)(buf * CH * PX), ok ? (unsigned)(m * a.xps + qbx * 8) * 2u : kOOB);
+            if constexpr (NBR == 2) glds16(gs_x, lds_x + (unsigned)(buf * CH * PX), ok ? (unsigned)(m * a.xps + qbx * 8) * 2u : kOOB);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                // a wave lays down rows 16 i + 2 wave, + 1 (32 units each)
@@ -120,12 +125,16 @@ __global__ __launch_bounds__(kT) void pw_sums_pair_kernel(const mvf_internal::Pw
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int u = ((ks * 2 + half) ^ swz_x(row)) * 16;
-                const u32x4 va = lds16(as + row * PX + u), vb = lds16(xs + row * PX + u);
-                bf16x8_t fa, fb;
+                const u32x4 va = lds16(as + row * PX + u);
+                bf16x8_t fa;
                 __builtin_memcpy(&fa, &va, 16);
-                __builtin_memcpy(&fb, &vb, 16);
                 za = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], fa, za, 0, 0, 0);      // D[i = channel][j = pixel]: lane = pixel, registers = channels 8 (r >> 2) + 4 half + (r & 3)
-                zb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ks], fb, zb, 0, 0, 0);
+                if constexpr (NBR == 2) {
+                    const u32x4 vb = lds16(xs + row * PX + u);
+                    bf16x8_t fb;
+                    __builtin_memcpy(&fb, &vb, 16);
+                    zb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ks], fb, zb, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(kT) void pw_sums_pair_kernel(const mvf_internal::Pw
                     const int i = 4 * g4 + e;
                     s1[i] += gm;
                     s2a[i] += gm * ((z3[e] - mua[i]) * rsa[i]);
-                    s2b[i] += gm * ((zd[e] - mub[i]) * rsb[i]);
+                    if constexpr (NBR == 2) s2b[i] += gm * ((zd[e] - mub[i]) * rsb[i]);
                 }
             }
         }
@@ -171,11 +180,13 @@ __global__ __launch_bounds__(kT) void pw_sums_pair_kernel(const mvf_internal::Pw
             const int c = 32 * wave + 8 * (i >> 2) + 4 * half + (i & 3);
             const float h1 = (float)t1, ha = (float)ta, hb = (float)tb;
             float2* pa = reinterpret_cast<float2*>(a.part_a) + (long)c * a.rows;
-            float2* pb = reinterpret_cast<float2*>(a.part_b) + (long)c * a.rows;
             pa[split] = make_float2(h1, ha);
-            pb[split] = make_float2(h1, hb);
             pa[a.nsplit + split] = make_float2((float)(t1 - (double)h1), (float)(ta - (double)ha));
-            pb[a.nsplit + split] = make_float2((float)(t1 - (double)h1), (float)(tb - (double)hb));
+            if constexpr (NBR == 2) {
+                float2* pb = reinterpret_cast<float2*>(a.part_b) + (long)c * a.rows;
+                pb[split] = make_float2(h1, hb);
+                pb[a.nsplit + split] = make_float2((float)(t1 - (double)h1), (float)(tb - (double)hb));
+            }
         }
     }
 }
@@ -185,13 +196,14 @@ __global__ __launch_bounds__(kT) void pw_sums_pair_kernel(const mvf_internal::Pw
 namespace mvf_internal {
 
 int pw_sums_pair_launch(const PwSumsPairArgs& a, hipStream_t st) {
-    auto k = pw_sums_pair_kernel;
     static bool attr = false;
     if (!attr) {
-        MVF_HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)pw_sums_pair_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        MVF_HIP_OK(hipFuncSetAttribute((const void*)pw_sums_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
         attr = true;
     }
-    hipLaunchKernelGGL(k, dim3(a.nsplit), dim3(kT), kLds, st, a);
+    if (a.x) hipLaunchKernelGGL(pw_sums_pair_kernel<2>, dim3(a.nsplit), dim3(kT), kLds, st, a);
+    else hipLaunchKernelGGL(pw_sums_pair_kernel<1>, dim3(a.nsplit), dim3(kT), kLds, st, a);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

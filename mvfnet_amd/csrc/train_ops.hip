@@ -1644,15 +1644,15 @@ int mvf_conv1x1_bwd_fused(const void* a_in, int a_pitch, const void* w_packed, c
 int mvf_conv1x1_bnbwd_sums_pair(const void* a_in, int a_pitch, const void* w_a, const void* x_in, int x_pitch, const void* w_b, const void* g, int g_pitch,
                                 const unsigned char* sign_bits, long m, int c, int k, const float* mean_a, const float* invstd_a, const float* mean_b,
                                 const float* invstd_b, float* part_a, float* part_b, int rows, int dtype, void* stream) {
-    MVF_REQUIRE(a_in && w_a && x_in && w_b && g && sign_bits && mean_a && invstd_a && mean_b && invstd_b && part_a && part_b && m > 0 && a_pitch >= k &&
-                    x_pitch >= k && g_pitch >= c, MVF_EINVAL, "conv1x1_bnbwd_sums_pair: bad argument");
+    MVF_REQUIRE(a_in && w_a && g && sign_bits && mean_a && invstd_a && part_a && m > 0 && a_pitch >= k && g_pitch >= c &&
+                    (!x_in || (w_b && mean_b && invstd_b && part_b && x_pitch >= k)), MVF_EINVAL, "conv1x1_bnbwd_sums_pair: bad argument");
     MVF_REQUIRE(dtype == MVF_BF16, MVF_EUNSUPPORTED, "conv1x1_bnbwd_sums_pair: bf16 storage only");
     mvf_internal::PwSumsPairArgs a = {};
     a.nsplit = mvf_internal::pw_bwd_fused_plan(m, c, k, &a.rows_per_split);
     MVF_REQUIRE(a.nsplit > 0, MVF_EUNSUPPORTED, "conv1x1_bnbwd_sums_pair: built for 64 -> 256 channels (c=%d k=%d); use the separate calls", c, k);
     MVF_REQUIRE(rows == 2 * a.nsplit, MVF_EINVAL, "conv1x1_bnbwd_sums_pair: rows must be 2 x mvf_conv1x1_bwd_fused_splits (%d), got %d", 2 * a.nsplit, rows);
-    MVF_REQUIRE(a_pitch % 8 == 0 && x_pitch % 8 == 0 && g_pitch % 8 == 0 && al16(a_in) && al16(x_in) && al16(w_a) && al16(w_b) && al16(g) &&
-                    ((uintptr_t)sign_bits & 15) == 0 && m * (long)std::max(g_pitch, std::max(a_pitch, x_pitch)) * 2 < 0x7ffffff0L, MVF_ESHAPE,
+    MVF_REQUIRE(a_pitch % 8 == 0 && g_pitch % 8 == 0 && al16(a_in) && al16(w_a) && al16(g) && (!x_in || (x_pitch % 8 == 0 && al16(x_in) && al16(w_b))) &&
+                    ((uintptr_t)sign_bits & 15) == 0 && m * (long)std::max(g_pitch, std::max(a_pitch, x_in ? x_pitch : 0)) * 2 < 0x7ffffff0L, MVF_ESHAPE,
                 "conv1x1_bnbwd_sums_pair: alignment / 2 GB addressing");
     a.a = a_in; a.aps = a_pitch; a.x = x_in; a.xps = x_pitch; a.w_a = w_a; a.w_b = w_b; a.g = g; a.g_pitch = g_pitch; a.bits = sign_bits; a.M = (int)m;
     a.mean_a = mean_a; a.invstd_a = invstd_a; a.mean_b = mean_b; a.invstd_b = invstd_b; a.part_a = part_a; a.part_b = part_b; a.rows = rows;

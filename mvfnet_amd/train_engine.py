@@ -325,11 +325,15 @@ class _TConv(object):
         m = n * h * w
         ws = _conv_ws(a_in.device)
         rows = lib.mvf_conv2d_stats_rows(C.byref(d))
-        if not sums_done:          # (a downsample block takes both branches' sums in one pass over g: _TBlock.backward)
+        ns = lib.mvf_conv1x1_bwd_fused_splits(m, self.cout, self.cin)
+        if not sums_done and self.eng.pair_ds_sums & 2:          # [r4] the one-branch form of csrc/pw_sums_pair.hip instead of pw_sums.hip
+            part = self.eng.buf((id(self), "bwpart_pair"), (self.cout, 2 * ns, 2), torch.float32)
+            self.launch_bwd_sums1(m, a_in, pitch, g, bits, bn, part, ns)
+            check(lib.mvf_bn_bwd_finalize(_p(part), 2 * ns, self.cout, _p(bn.dgamma), _p(bn.dbeta), _st()), "mvf_bn_bwd_finalize")
+        elif not sums_done:        # (a downsample block takes both branches' sums in one pass over g: _TBlock.backward)
             part = self.eng.buf((id(self), "bwpart"), (rows, self.cout, 2), torch.float32)
             self.launch_bwd_sums(d, a_in, g, bits, bn, part, ws)
             check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cout, _p(bn.dgamma), _p(bn.dbeta), _st()), "mvf_bn_bwd_finalize")
-        ns = lib.mvf_conv1x1_bwd_fused_splits(m, self.cout, self.cin)
         dx = self.eng.buf((id(self), "dx"), (m, self.cin))
         spart = self.eng.buf((id(self), "bnsums_fused"), (self.cin, 2 * ns, 2), torch.float32) if bn_in is not None else None
         slabs = self.eng.buf((id(self), "wslab"), (ns * self.cout * self.cin,), torch.float32)
@@ -338,6 +342,11 @@ class _TConv(object):
             check(lib.mvf_bn_bwd_finalize(_p(spart), 2 * ns, self.cin, _p(bn_in.dgamma), _p(bn_in.dbeta), _st()), "bn bwd finalize")
         self.slab_reduce(slabs, ns, self.eng)
         return dx
+
+    def launch_bwd_sums1(self, m, a_in, a_pitch, g, bits, bn, part, ns):
+        """Exactly one launch (bench.py brackets this call with HIP events)."""
+        check(lib.mvf_conv1x1_bnbwd_sums_pair(_p(a_in), a_pitch, _p(self.wp), None, 0, None, _p(g), self.cout, _p(bits), m, self.cout, self.cin, _p(bn.mean),
+                                              _p(bn.invstd), None, None, _p(part), None, 2 * ns, self.eng.dt, _st()), "bn backward sums (one branch)")
 
     def launch_bwd_fused(self, m, a_in, g, bits, bn, bn_in, z_in, dx, spart, ns, slabs, a_pitch=None):
         """Exactly one launch (bench.py brackets this call with HIP events)."""
@@ -623,7 +632,7 @@ class _TBlock(object):
         w3_done = wd_done = False        # [r4] weight gradient already taken inside the BatchNorm-backward pass
         if self.cd is not None and s["z3"] is None:
             # [r4] z3-free downsample block: each branch = sums pass + one-pass backward on the recomputed conv; neither dz3 nor dz_d exists
-            pair = bool(eng.pair_ds_sums)
+            pair = bool(eng.pair_ds_sums & 1)
             if pair:           # bn3's and bn_d's sums in ONE pass over g (csrc/pw_sums_pair.hip)
                 self.launch_sums_pair(s["a2"], s["x"], c, g, bits, m2, eng)
             da2 = self.c3.bwd_fused(s["a2"], g, bits, nt, ho, wo, self.b3, self.b2, s["z2"], sums_done=pair)
@@ -824,7 +833,7 @@ class _ParamStore(object):
     # 1 conv3 of plain stored-z3 blocks, 2 conv3 (+ stride-1 downsample conv) of downsample blocks, 4 conv1 of blocks without MVF,
     # 8 also give up the z3-free path of layer1's plain blocks for it)
     fuse_bnwg = int(os.environ.get("MVF_FUSE_BNWG", "7"))
-    pair_ds_sums = int(os.environ.get("MVF_PAIR_DS_SUMS", "1"))    # [r4] that block: bn3's and bn_d's backward sums in one pass over g (csrc/pw_sums_pair.hip); 0 = two pw_sums passes
+    pair_ds_sums = int(os.environ.get("MVF_PAIR_DS_SUMS", "3"))    # [r4] bit 0: that block's bn3 and bn_d backward sums in one pass over g (csrc/pw_sums_pair.hip; 0 = two pw_sums passes); bit 1: the plain z3-free blocks' sums on its one-branch form
     z3_free_ds = int(os.environ.get("MVF_Z3_FREE_DS", "1"))    # [r4] layer1.0 (downsample block, both convs 64 -> 256 pointwise): no stored z3, per-branch sums + one-pass backward instead of the paired BatchNorm backward
     fuse_c3_bwd = int(os.environ.get("MVF_FUSE_C3_BWD", "1"))   # [r4] z3-free blocks: conv3 recompute + bn3 backward apply + data gradient (+ bn2 sums) + weight gradient in ONE pass (csrc/pw_bwd_fused.hip); 0 = three launches
     fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes

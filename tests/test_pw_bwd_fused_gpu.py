@@ -189,12 +189,16 @@ def test_bnbwd_sums_pair_equals_two_sums_passes(m):
     pa, pb = torch.full((cout, 2 * ns, 2), float("nan"), device="cuda"), torch.full((cout, 2 * ns, 2), float("nan"), device="cuda")
     check(lib.mvf_conv1x1_bnbwd_sums_pair(P(t["a2"]), cin, P(wpa), P(xb), cin, P(wpb), P(t["g"]), cout, P(t["bits"]), m, cout, cin, P(t["mean"]), P(t["invstd"]),
                                           P(mean_b), P(invstd_b), P(pa), P(pb), 2 * ns, 1, None), "sums pair")
+    p1 = torch.full((cout, 2 * ns, 2), float("nan"), device="cuda")          # the one-branch form (x_in = NULL): bn3's sums alone, bit for bit the pair's
+    check(lib.mvf_conv1x1_bnbwd_sums_pair(P(t["a2"]), cin, P(wpa), None, 0, None, P(t["g"]), cout, P(t["bits"]), m, cout, cin, P(t["mean"]), P(t["invstd"]),
+                                          None, None, P(p1), None, 2 * ns, 1, None), "sums, one branch")
     got = []
     for part in (pa, pb):
         dg, db = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
         check(lib.mvf_bn_bwd_finalize(P(part), 2 * ns, cout, P(dg), P(db), None))
         got.append((dg, db))
     torch.cuda.synchronize()
+    assert torch.equal(p1, pa)
     mask = torch.stack([(t["bits"] >> j) & 1 for j in range(4)], dim=-1).reshape(m, cout).double()
     gm = t["g"].double() * mask
     for (dg, db), (wdg, wdb), (inp, w, mu, rs) in zip(got, want, ((t["a2"], t["w"], t["mean"], t["invstd"]), (xb, wb, mean_b, invstd_b))):
