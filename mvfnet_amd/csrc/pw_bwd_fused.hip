@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kT) void pw_bwd_fused_kernel(const mvf_internal::Pw
             unpack8(zu, zv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                gv[j] = ((mb >> (j + (j >= 4 ? 4 : 0))) & 1u) ? gv[j] : 0.f;
+                gv[j] = __uint_as_float(__float_as_uint(gv[j]) & (unsigned)__builtin_amdgcn_sbfe((int)mb, j + (j >= 4 ? 4 : 0), 1));      // bit set ? g : +0 (v_bfe_i32 + v_and)
                 o[j] = ca[j] * (gv[j] - cd[j] - (zv[j] - cmu[j]) * ck[j]);
             }
             const u32x4 pk = pack8(o);

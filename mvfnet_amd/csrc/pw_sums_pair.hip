@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kT) void pw_sums_pair_kernel(const mvf_internal::Pw
                 const float gv[4] = {__uint_as_float(gq.x << 16), __uint_as_float(gq.x & 0xffff0000u), __uint_as_float(gq.y << 16), __uint_as_float(gq.y & 0xffff0000u)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float gm = ((mb >> e) & 1u) ? gv[e] : 0.f;     // (rows past the end: g and the bits are zeros)
+                    const float gm = __uint_as_float(__float_as_uint(gv[e]) & (unsigned)__builtin_amdgcn_sbfe((int)mb, e, 1));      // bit set ? g : +0 (rows past the end: g and the bits are zeros)
                     const int i = 4 * g4 + e;
                     s1[i] += gm;
                     s2a[i] += gm * ((z3[e] - mua[i]) * rsa[i]);
