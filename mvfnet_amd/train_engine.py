@@ -536,22 +536,23 @@ class _TBlock(object):
         f = eng.fuse_bn3_apply
         return f == 2 or (f == 1 and self.c3.cin <= 128)
 
-    def z3_free(self, eng):
+    def z3_free(self, eng, m2=None):
         """[r3] The block never stores z3 (reference resnet.py:229-244: out = relu(bn3(conv3(a2)) + identity)): a statistics-only conv3 pass, the
         fused apply pass, and bn3's backward on the recomputed conv (eng.z3_free).  Plain blocks only: a downsample block's paired backward
         reads z3 and z_d in one pass over g; needs batch statistics fused into the conv epilogue."""
+        m2 = m2 or (1 << 16)           # [r5] the block's real pixel count when the caller knows it: the kernels' plan functions refuse m * c * 2 >= 2^31
         if self.cd is not None:
-            return self.z3_free_ds(eng)
+            return self.z3_free_ds(eng, m2)
         if not (eng.z3_free and self.fuse_apply(eng) and eng.fuse_stats and not self.b3.frozen):
             return False
-        if (eng.fuse_bnwg & 8) and eng.tdtype == torch.bfloat16 and lib.mvf_bn_bwd_wgrad_splits(1 << 16, self.c3.cout, self.c3.cin, 1, 4) > 0:
+        if (eng.fuse_bnwg & 8) and eng.tdtype == torch.bfloat16 and lib.mvf_bn_bwd_wgrad_splits(m2, self.c3.cout, self.c3.cin, 1, 4) > 0:
             return False           # A/B: stored z3 + conv3's weight gradient in bn3's backward apply instead
         # measured per block in the bf16 step (us; stored-z3 path -> recompute path): statistics-only pass 148 -> 79 (layer1) / 75 -> 52 (layer2),
         # backward sums 168 -> 205 / 102 -> 119 (the conv kernel's sum epilogue streams g at 2.7 TB/s, the BatchNorm kernel at 5.2), backward apply
         # 242 -> 204 / 116 -> 119: -70 per layer1 block, ~0 per layer2 block -> planes <= 64 by default, 2 = every block with the fused apply
         return eng.z3_free == 2 or self.c3.cin <= 64
 
-    def z3_free_ds(self, eng):
+    def z3_free_ds(self, eng, m2=1 << 16):
         """[r4] A DOWNSAMPLE block (reference resnet.py:227-233: out = relu(bn3(conv3(a2)) + bn_d(conv_d(x)))) that does not store z3 and reads neither z3 nor
         z_d in backward: forward = conv3's statistics-only pass + the fused apply pass with the stored z_d as the residual operand; backward = per branch
         the sums pass on the recomputed conv (pw_sums) and the one-pass kernel of csrc/pw_bwd_fused.hip (conv3: + bn2's sums; the downsample conv: the
@@ -561,7 +562,9 @@ class _TBlock(object):
             return False
         if self.b3.frozen or self.bd.frozen or self.cd.stride != 1 or self.cd.kh != 1 or self.cd.kw != 1 or self.cd.cin != self.c3.cin or self.cd.cout != self.c3.cout:
             return False
-        return lib.mvf_conv1x1_bwd_fused_splits(1 << 16, self.c3.cout, self.c3.cin) > 0
+        # [r5] asked with the block's REAL pixel count: the backward of this form has no fallback, so the forward must not choose it where the one-pass
+        # kernel (stride 1: the downsample branch sees the same m2 pixels) refuses the shape
+        return lib.mvf_conv1x1_bwd_fused_splits(m2, self.c3.cout, self.c3.cin) > 0
 
     def launch_sums_pair(self, a2, x, x_pitch, g, bits, m, eng):
         """Exactly one launch (bench.py brackets this call with HIP events) + the two finalizes."""
@@ -600,7 +603,7 @@ class _TBlock(object):
         z2, ho, wo = self.c2.forward(a1, nt, h, w, bn=self.b2)
         m2 = nt * ho * wo
         a2 = self.b2.apply(z2, m2, 1)
-        z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3, store=not self.z3_free(eng))
+        z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3, store=not self.z3_free(eng, m2))
         if self.cd is not None:
             if side is not None:
                 eng.main_stream().wait_stream(side)               # the downsample branch (queued before conv1, see above)
@@ -640,7 +643,8 @@ class _TBlock(object):
             dz3, w3_done, wd_done = None, True, True
         elif self.cd is not None and eng.pair_bn_bwd and not (self.b3.frozen or self.bd.frozen):
             if (eng.fuse_bnwg & 2) and self.c3.fuses_wgrad(eng, m2, self.c3.cout, 4, 2):
-                both = self.cd.stride == 1 and self.cd.cin == self.c3.cin and self.cd.kh == 1
+                # (mvf_bn_bwd_pair_wgrad contracts BOTH convs only with its 64-wide k tile: wider ones pass x_b = NULL and keep the GEMM)
+                both = self.cd.stride == 1 and self.cd.cin == self.c3.cin and self.cd.kh == 1 and self.c3.cin == 64
                 dz3, dzd = _BN.backward_pair_wgrad(self.b3, self.bd, g, self.c3.cout, s["z3"], s["zd"], m2, eng, bits, self.c3, s["a2"], self.c3.cin,
                                                    self.cd, s["x"] if both else None, c)
                 w3_done, wd_done = True, both
@@ -782,6 +786,7 @@ class _ParamStore(object):
         self._ones = {}
         self._bufs = {}
         self._caps = {}
+        self._last_shape = {}
 
     def grad_of(self, p):
         return self._grad_view[id(p)]
@@ -793,6 +798,13 @@ class _ParamStore(object):
         dt = dtype or self.tdtype
         shape = tuple(shape)
         k = (key, shape, dt)
+        # [r5] every shape asked for under one key is a view of ONE allocation: two shapes inside one step would alias silently
+        step = getattr(self, "forward_count", None)
+        if step is not None:
+            last = self._last_shape.get((key, dt))
+            if last is not None and last[0] == step and last[1] != shape:
+                raise RuntimeError("engine buffer %r requested with shapes %s and %s inside one step: they would share storage" % (key, last[1], shape))
+            self._last_shape[(key, dt)] = (step, shape)
         t = self._bufs.get(k)
         if t is None:
             # One allocation per call site, sized for the LARGEST shape seen there; other shapes (the partial last batch of an epoch:

@@ -295,3 +295,34 @@ def test_bench_runs_its_rccl_path_with_one_rank():
     rep = d["replicas"]
     assert rep["backend"] == "nccl" and rep["rccl_ranks"] == 1 and rep["params_bit_identical_across_ranks"]
     assert rep["allreduce_ms"]["tail_bucket_overlapped_with_backward"] > 0 and d["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_multi_rank_path_with_two_ranks_on_one_gpu():
+    """[r5] `bench.py --gpus 2` exactly as the driver launches it (python -m torch.distributed.run, one process per rank), rehearsed on a ONE-GPU
+    box: BENCH_BACKEND=gloo puts both ranks on cuda:0 with gloo carrying the CUDA tensors (RCCL refuses two ranks per device).  Everything the
+    multi-GPU run adds executes with world = 2: per-rank seeds, barrier + synchronize brackets, MAX over ranks, `rank_ms_per_step`, whole-job
+    `value`, `verify_replicas` (bit-identical parameters across ranks after the timed steps) and the exposed-all-reduce triple."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["clips_per_gpu"] == 4
+    rk = d["rank_ms_per_step"]
+    assert len(rk["all"]) == 2 and abs(rk["max"] - d["ms_per_step"]) < 1e-2 * d["ms_per_step"]          # MAX over ranks is what is reported
+    assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]                        # whole-job clips/s over both ranks
+    rep = d["replicas"]
+    assert rep["backend"] == "gloo" and rep["rccl_ranks"] == 2 and rep["params_bit_identical_across_ranks"]
+    assert set(rep["allreduce_ms"]) == {"tail_bucket_overlapped_with_backward", "single_collective_after_backward", "no_exchange", "exposed"}
+    assert "cpu_baseline" not in d and "other_configs" not in d                                           # N = 1 only
+    assert d["roofline"]["frac"] > 0

@@ -643,6 +643,53 @@ def test_norm_eval_training_vs_reference_golden_tight_on_the_exact_fp32_mfma():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_norm_eval_default_fp32_path_tight_over_seeds():
+    """[r5] The TIGHT end-to-end gradient gate of the shipped fp32 path (convs and weight gradients as exact three-term bf16 splits on the bf16
+    matrix cores, MVF_F32_X3=1).  The frozen-statistics step on six inputs, each against the REFERENCE's own double-precision run
+    (tests/golden/normeval_seeds_fp64.npz, make_normeval_seeds_golden.py).  Every input has ReLU pre-activations within 1e-7 ... 1e-8 of zero in
+    every stage (recorded in the golden as margin/*), so on any ONE input an fp32 path may take one kink decision the other way -- in layer4's
+    72 x 512 tensors that is ~1e-2 of a gradient's norm (seed 77 is the documented case: test_norm_eval_training_vs_reference_golden).  An accuracy
+    regression moves every input; sign luck moves one.  Asserted: all 206 gradient norms and ten named gradients within 2e-3 on at least five
+    of the six inputs (and the median input's worst error), the loose 2e-2 on all six."""
+    import mvfnet_amd
+    g = golden("normeval_seeds_fp64.npz")
+    cfg = mvfnet_amd.mvfnet_config(50, 4, dropout_ratio=0.0)
+    cfg["backbone"]["norm_eval"] = True
+    m = mvfnet_amd.build_recognizer(cfg, None, dict(average_clips=None))
+    sd = m.state_dict()
+    vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in sd}, strict=True)
+    m = m.cuda().train()
+    eng = m.train_engine()
+    params = dict(m.named_parameters())
+    labels = torch.from_numpy(synth.synth_labels(2)).cuda()
+    names = list(g["grad_names"])
+
+    def sample(a, size):
+        a = a.ravel()
+        if a.size > size:        # the generator's fixed random sample of a large tensor's elements
+            a = a[np.sort(np.random.RandomState(a.size % 65521).choice(a.size, size, replace=False))]
+        return a
+
+    worst = {}
+    for seed in [int(s_) for s_ in g["seeds"]]:
+        tag = "s%d/" % seed
+        imgs = torch.from_numpy(synth.synth_clip_batch(2, 4, 96, 96, seed=seed)).cuda()
+        loss = eng.forward(imgs, labels)
+        assert abs(float(loss) - float(g[tag + "loss"])) < 2e-5 * float(g[tag + "loss"]), seed
+        eng.backward()
+        torch.cuda.synchronize()
+        en = max(abs(float(eng.grad_of(params[n]).double().norm()) - r) / max(r, 1e-6) for n, r in zip(names, g[tag + "grad_norms"]))
+        eg = max(rel_err(sample(eng.grad_of(params[k[len(tag) + 5:]]).cpu().numpy().astype(np.float64), 16384), g[k])
+                 for k in g.files if k.startswith(tag + "grad/"))
+        worst[seed] = (en, eg)
+        print("seed %d: worst gradient-norm error %.2e, worst gradient error %.2e (vs the reference in fp64)" % (seed, en, eg))
+    errs = sorted(max(v) for v in worst.values())
+    assert errs[-1] < 2e-2, worst
+    assert errs[-2] < 2e-3, worst                       # at most one input may sit on a kink
+    assert errs[len(errs) // 2] < 1.5e-3, worst          # (measured on the round's kernels: 3e-4 ... 1.1e-3 on five inputs, seed 77 at 1.3e-2)
+
+
 def test_norm_eval_training_bf16_close_to_fp32():
     import mvfnet_amd
     g = golden("normeval_cases.npz")
@@ -1687,6 +1734,12 @@ def test_trailing_partial_batch_reuses_the_engines_buffers():
         torch.cuda.synchronize()
         assert float(l1) == float(l2)
         assert torch.equal(g2, e1.flat_grads)
+        # [r5] every shape asked for under one key is a view of one allocation: a second shape INSIDE one step would alias the first
+        e1.buf("alias_probe", (4, 8))
+        with pytest.raises(RuntimeError, match="inside one step"):
+            e1.buf("alias_probe", (2, 8))
+        e1.forward_count += 1                    # ... the next step may (the partial batch above did)
+        e1.buf("alias_probe", (2, 8))
 
 
 def test_z3_free_block_gradients_match_stored_z3_block():

@@ -5,9 +5,10 @@ sys.path.insert(0, '.')
 import bench
 bench.T_FRAMES = 8
 dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+clips = int(sys.argv[2]) if len(sys.argv) > 2 else 32          # [r5] 12 = the reference's videos_per_gpu (configs/MVFNet/K400/*_r50_dense.py:121-123)
 m = bench.build_model(50, dtype, True)
 eng = m.train_engine(dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
-imgs = torch.randn(32, 8, 3, 224, 224, device="cuda"); labels = torch.randint(0, 400, (32, 1), device="cuda")
+imgs = torch.randn(clips, 8, 3, 224, 224, device="cuda"); labels = torch.randint(0, 400, (clips, 1), device="cuda")
 for _ in range(3): eng.train_step(imgs, labels)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -15,7 +16,9 @@ for _ in range(5): eng.train_step(imgs, labels)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print("dtype %s: host enqueue %.1f ms/step, total %.1f ms/step" % (dtype, (t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3))
+print("clips %d " % clips, end=""); print("dtype %s: host enqueue %.1f ms/step, total %.1f ms/step" % (dtype, (t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3))
+if len(sys.argv) > 3 and sys.argv[3] == "noprofile":
+    sys.exit(0)
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(3): eng.train_step(imgs, labels)
