@@ -231,7 +231,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
     def dbs1(self, out, m, a_in, a_pitch, g, bits, bn, part, ns):      # [r4] conv3 again + bn3 backward sums on the one-branch form of pw_sums_pair
         return (2.0 * m * self.cout * self.cin, "bwd-sums M%d N%d K%d" % (m, self.cout, self.cin), esz * (m * self.cin + m * self.cout + self.w.numel()) + m * self.cout // 4)
 
-    def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
+    def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None, out_gate=None):
         fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin          # algorithmic = the forward conv's MACs
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * (2 if residual is not None else 1) + self.w.numel())
         return (fl, "dgrad M%d N%d K%d s%d" % (n * h * w, self.cin, self.kh * self.kw * self.cout, self.stride), nbytes)
@@ -241,6 +241,11 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * 2 + self.w.numel())
         return (fl, "dgrad M%d N%d K%d s%d +bn" % (n * h * w, self.cin, self.kh * self.kw * self.cout, self.stride), nbytes)
+
+    def ddzf(self, out, d, a_in, gm, bd, bias, dx, z_in, bn_in, part, ws):      # [r5] conv3's data gradient + bn2 sums taken on [gm | a2] (no dz3 tensor): algorithmic work = the data gradient's
+        m, c, k = d.n * d.h * d.w, self.cout, self.cin
+        nbytes = esz * (m * c + 3 * m * k + self.w.numel())          # gm, a2, z2, da2, W
+        return (2.0 * m * c * k, "dgrad M%d N%d K%d s1 +bn (no dz3)" % (m, k, c), nbytes)
 
     def dwgr(self, out, dz, x, n, h, w, ho, wo, eng_, x_pitch=None, x2=None, split_c=0, on_main=False):
         k_alg = 147 if self.stem else self.kh * self.kw * self.cin
@@ -273,14 +278,18 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         nb = esz * m * self.c * 8 + 2 * (m * self.c // 4) + nx * (esz * m * conv_a.cin + 4 * conv_a.w.numel())
         return (2.0 * nx * m * self.c * conv_a.cin, "bn bwd pair + %d wgrad M%d C%d K%d" % (nx, m, self.c, conv_a.cin), nb)
 
-    def dmvf(self, out, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits):
+    def dmvf(self, out, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits, out_gate=None):
         m = d.nt * d.h * d.w
         nb = esz * m * d.cs * (3 if addend is not None else 2)          # slice read + slice write (+ the gated skip-connection slice)
         taps = 3 * bin(d.mode).count("1")
         return (2.0 * m * d.cs * taps, "mvf stencil%s M%d Cs%d" % ("^T" if flip else "", m, d.cs), nb)
 
-    undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tc.wrap(TE._TConv, "launch_fwd_apply", dfap), tc.wrap(TE._TConv, "launch_bwd_sums", dbws), tc.wrap(TE._TConv, "launch_bwd_apply", dbwa),
-            tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb), tc.wrap(TE._TConv, "launch_bwd_fused", dbwf), tc.wrap(TE._TBlock, "launch_sums_pair", dbsp), tc.wrap(TE._TConv, "launch_bwd_sums1", dbs1),
+    def dmvs(self, out, d, x, c, y, part):          # [r5] the forward stencil that also takes the BatchNorm statistics
+        m = d.nt * d.h * d.w
+        return (2.0 * m * d.cs * 3 * bin(d.mode).count("1"), "mvf stencil+stats M%d Cs%d" % (m, d.cs), esz * m * d.cs * 2)
+
+    undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tm.wrap(TE._TMvf, "launch_stencil_stats", dmvs), tc.wrap(TE._TConv, "launch_fwd_apply", dfap), tc.wrap(TE._TConv, "launch_bwd_sums", dbws), tc.wrap(TE._TConv, "launch_bwd_apply", dbwa),
+            tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb), tc.wrap(TE._TConv, "launch_dzfree_dgrad", ddzf), tc.wrap(TE._TConv, "launch_bwd_fused", dbwf), tc.wrap(TE._TBlock, "launch_sums_pair", dbsp), tc.wrap(TE._TConv, "launch_bwd_sums1", dbs1),
             tw.wrap(TE._TConv, "wgrad", dwgr), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
             tb.wrap(TE._BN, "backward_pair", dbpr),
             tm.wrap(TE._TMvf, "launch_stencil", dmvf), tf.wrap(TE._BN, "_apply_bwd_wgrad", dbaw), tf.wrap(TE._BN, "backward_pair_wgrad", dbpw)]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 1
+#define MVF_ABI_VERSION 2    /* 2: mvf_conv_desc_t.x_c0 */
 
 enum { MVF_OK = 0, MVF_EINVAL = -1, MVF_ESHAPE = -2, MVF_EWS = -3, MVF_EHIP = -4, MVF_EUNSUPPORTED = -5 };
 enum { MVF_F32 = 0, MVF_BF16 = 1 };
@@ -115,6 +115,9 @@ typedef struct {
     int32_t res_c0;           /* the residual is added to output channels >= res_c0 only (multiple of 4; 0 = all).   */
                               /*   MVF block backward: channels [0, cs) of the conv1 data gradient go through the    */
                               /*   transposed stencil first, which adds their share (mvf_nhwc_stencil addend)        */
+    int32_t x_c0;             /* [r5] 0, or with split_c > 0: x holds channels [split_c, cin) at column (channel - x_c0) of its rows  */
+                              /*   (x_pix_stride >= cin - x_c0): the contraction runs over the CONCATENATION [x2 | x] of two compact   */
+                              /*   tensors (x_c0 = split_c) instead of over x with its first split_c channels replaced               */
 } mvf_conv_desc_t;
 
 int mvf_conv2d_nhwc_fwd(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
@@ -159,6 +162,13 @@ int mvf_conv2d_nhwc_fwd_bnbwd_apply(const mvf_conv_desc_t* d, const void* x, con
 int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                                 const float* bias, const void* residual, const unsigned char* res_sign_bits, void* y,
                                 void* ws, size_t ws_bytes, void* stream);
+/* [r5] ... and with the OUTPUT gated as well: y[.., c] = (conv + bias + gated residual) * [out_gate bit] for c >= d->res_c0 (channels below res_c0 --
+ * the MVF slice of a block's conv1 data gradient -- are written ungated).  out_gate_bits: the sign bits of the block output whose gradient y is
+ * ([n*ho*wo][cout/4] bytes).  The block below then receives gm = g * [out > 0] (torch autograd's relu backward, resnet.py:244) as a tensor: its
+ * BatchNorm backward, data gradient and weight gradient read it without the bits.  res_sign_bits may be NULL (an ungated residual). */
+int mvf_conv2d_nhwc_fwd_resmask_gate(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
+                                     const void* residual, const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y,
+                                     void* ws, size_t ws_bytes, void* stream);
 /* Stride-1 data gradient whose output da feeds the backward of a = ReLU(BN(z)): besides y = dgrad(dz) it accumulates that
  * BatchNorm's backward sums in the epilogue -- sums_part, CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] = per-128-row column sums of gm and
  * gm * xhat with gm = y * [bn_scale*z + bn_shift > 0], xhat = (z - bn_mean) * bn_invstd (z: the forward conv output the BN
@@ -219,6 +229,26 @@ int mvf_average_clip(const float* scores, int clips, int classes, int kind, floa
  * SGD-nesterov step; optimizer cfg mvf_kinetics400_2d_rgb_r50_dense.py:152-154).
  * All tensors are channels-last matrices [m][c] (m = n*h*w), c % 4 == 0.
  * ---------------------------------------------------------------------------------------------- */
+/* [r5] mvf_conv2d_nhwc_dgrad_bnsums over a SPLIT operand and with a bias: y = [x2 | x] * w_packed^T + bias (d->split_c channels from x2, the rest
+ * from x, see mvf_conv_desc_t.x_c0), pointwise, stride 1 -- the data gradient of a bottleneck's conv3 taken on (gm, a2) instead of on dz3
+ * (mvf_bn_bwd_dzfree_prep makes w_packed and bias). */
+int mvf_conv2d_nhwc_dgrad_bnsums_split(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias, void* y,
+                                       const void* bn_z, const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
+                                       float* sums_part, void* ws, size_t ws_bytes, void* stream);
+/* [r5] BatchNorm backward of out = relu(bn3(conv3(a2)) + identity) (Bottleneck.forward, codes/models/backbones/resnet.py:229-244, under torch autograd)
+ * WITHOUT the dz3 tensor (csrc/bn_dzfree.hip).  dz3 = a (gm - d0 - kx (z3 - mean)) with a = gamma invstd, d0 = dbeta / m, kx = invstd dgamma / m is
+ * affine in (gm, z3) and z3 = a2 W^T, so
+ *   da2 = dz3 W    = [gm | a2] [a.W ; -G] - v      G = W^T diag(a kx) W,  v_k = sum_c a_c (d0_c - kx_c mean_c) W[c][k]
+ *   dW  = dz3^T a2 = a . (Q - d0 (x) sa - kx . (W A2 - mean (x) sa))     Q = gm^T a2, A2 = a2^T a2, sa = m * a_mean
+ * _prep : w_out [k][c + k] (the data-gradient pack's layout: row = conv input channel) and bias_out [k] = -v for mvf_conv2d_nhwc_dgrad_bnsums_split,
+ *         from w_packed_dgrad [k][c] (mvf_pack_conv_weight_dgrad of the c x k pointwise weights) and the BatchNorm's dgamma / dbeta
+ *         (mvf_bn_bwd_reduce on gm and the stored z3; zeros for a BatchNorm with frozen statistics).
+ * _wgrad: dw [c][k] holds Q on entry (mvf_conv2d_nhwc_wgrad with dz = gm) and dW on return; gram [k][k] = A2 (the same call with dz = x = a2),
+ *         a_mean [k] = column means of a2, w_packed [c][k] = the forward pack.  bf16 storage. */
+int mvf_bn_bwd_dzfree_prep(const void* w_packed_dgrad, int c, int k, const float* gamma, const float* mean, const float* invstd, const float* dgamma,
+                           const float* dbeta, long m, void* w_out, float* bias_out, int dtype, void* stream);
+int mvf_bn_bwd_dzfree_wgrad(float* dw, const void* w_packed, const float* gram, const float* a_mean, const float* gamma, const float* mean,
+                            const float* invstd, const float* dgamma, const float* dbeta, long m, int c, int k, int dtype, void* stream);
 size_t mvf_bn_workspace_bytes(long m, int c);
 /* batch mean / biased var of z over m -> save_mean, save_invstd, scale = gamma*invstd, shift = beta - mean*scale;
  * running_mean/var updated in place (unbiased var).  Shifted single-pass sums (shift = old running_mean). */
@@ -370,6 +400,17 @@ int mvf_pack_conv_weight_dgrad(const float* w_oihw, int cout, int cin, int kh, i
 int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t,
                      const float* w_h, const float* w_w, const float* scale, const float* shift, int flip,
                      const void* addend, int addend_c, const unsigned char* addend_sign_bits, void* stream);
+/* [r5] ... with the OUTPUT gated per channel by out_gate_bits ([pixels][out_c/4] bytes): out = (f(stencil(x)) + gated addend) * [bit] */
+int mvf_nhwc_stencil_gate(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t,
+                          const float* w_h, const float* w_w, const float* scale, const float* shift, int flip,
+                          const void* addend, int addend_c, const unsigned char* addend_sign_bits,
+                          const unsigned char* out_gate_bits, void* stream);
+/* [r5] the plain stencil (no activation) that also accumulates the batch statistics of MVF's BatchNorm3d (MVF.py:131-134, training mode) over the
+ * values it stores: stats_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] = per-workgroup sums of (y - K), (y - K)^2, K =
+ * stats_shift (the old running mean; NULL = 0) -> mvf_bn_train_finalize.  Replaces the statistics pass over y. */
+int mvf_nhwc_stencil_stats_rows(const mvf_desc_t* d, int x_c, int out_c);
+int mvf_nhwc_stencil_stats(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
+                           const float* w_w, float* stats_part, const float* stats_shift, void* stream);
 size_t mvf_nhwc_tapgrad_workspace_bytes(const mvf_desc_t* d);
 int mvf_nhwc_tapgrad(const mvf_desc_t* d, const void* x, int x_c, const void* dy, int dy_c, float* dw_t, float* dw_h,
                      float* dw_w, void* ws, size_t ws_bytes, void* stream);

@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("ho", C.c_int32), ("wo", C.c_int32), ("x_pix_stride", C.c_int32),
                 ("dtype", C.c_int32), ("relu", C.c_int32), ("split_c", C.c_int32), ("x2_pix_stride", C.c_int32), ("in_dil", C.c_int32),
-                ("res_c0", C.c_int32)]
+                ("res_c0", C.c_int32), ("x_c0", C.c_int32)]
 
 
 class PackJob(C.Structure):
@@ -82,6 +82,21 @@ def _load():
     lib.mvf_conv2d_nhwc_fwd_bnbwd_apply.argtypes = [cp, vp, vp, vp, vp, vp, fp, fp, fp, fp, fp, vp, vp, sz, vp]
     lib.mvf_conv2d_nhwc_fwd_resmask.restype = i32
     lib.mvf_conv2d_nhwc_fwd_resmask.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, vp, sz, vp]
+    i64_ = C.c_long
+    lib.mvf_conv2d_nhwc_fwd_resmask_gate.restype = i32
+    lib.mvf_conv2d_nhwc_fwd_resmask_gate.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, vp, vp, sz, vp]
+    lib.mvf_conv2d_nhwc_dgrad_bnsums_split.restype = i32
+    lib.mvf_conv2d_nhwc_dgrad_bnsums_split.argtypes = [cp, vp, vp, vp, fp, vp, vp, fp, fp, fp, fp, fp, vp, sz, vp]
+    lib.mvf_bn_bwd_dzfree_prep.restype = i32
+    lib.mvf_bn_bwd_dzfree_prep.argtypes = [vp, i32, i32, fp, fp, fp, fp, fp, i64_, vp, fp, i32, vp]
+    lib.mvf_bn_bwd_dzfree_wgrad.restype = i32
+    lib.mvf_bn_bwd_dzfree_wgrad.argtypes = [fp, vp, fp, fp, fp, fp, fp, fp, fp, i64_, i32, i32, i32, vp]
+    lib.mvf_nhwc_stencil_stats_rows.restype = i32
+    lib.mvf_nhwc_stencil_stats_rows.argtypes = [dp, i32, i32]
+    lib.mvf_nhwc_stencil_stats.restype = i32
+    lib.mvf_nhwc_stencil_stats.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, fp, fp, vp]
+    lib.mvf_nhwc_stencil_gate.restype = i32
+    lib.mvf_nhwc_stencil_gate.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, fp, fp, i32, vp, i32, vp, vp, vp]
     lib.mvf_conv2d_stats_rows.restype = i32
     lib.mvf_conv2d_stats_rows.argtypes = [cp]
     lib.mvf_conv2d_nhwc_fwd_stats.restype = i32

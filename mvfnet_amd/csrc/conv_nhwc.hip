@@ -52,6 +52,10 @@ struct ConvArgs {
     int xps, split_c, x2ps, relu;
     int res_c0;    // residual only for output channels >= res_c0
     const unsigned char* res_mask;   // optional [M][Cout/4] bytes: bit j of byte k gates residual channel 4k+j (ReLU sign bits)
+    // [r5] optional [M][Cout/4] bytes in the same layout: the OUTPUT (accumulator + residual) of channels >= res_c0 is gated by them before the
+    // store -- the data gradient then hands the block below gm = g * [out > 0] instead of g + sign bits (mvf_conv2d_nhwc_fwd_resmask_gate)
+    const unsigned char* out_gate;
+    int x_c0;      // [r5] split operand: x holds channels [split_c, Cin) of the contraction at column (channel - x_c0) of its rows (0: at their own offset)
     int mask_lds;  // stage the gate bytes in LDS (experiment switch MVF_MASK_LDS=0)
     int prio;      // experiment switch MVF_CONV_PRIO=1: raise the wave priority around the MFMA phase of the LDS-DMA loops; in
                    // -DMVF_CONV_ABLATE builds bits 1-5 additionally switch parts of the kernel OFF (timing ablation, wrong results)
@@ -443,13 +447,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     ok = ok && ih < a.H && iw < a.W;
                     if (ok) {
                         const long pix = (long)a_pix0[i] + ih * a.W + iw;
-                        st.a[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
+                        st.a[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci - (from2 ? 0 : a.x_c0)) * ESZ);
                     }
                 } else {
                     const bool ok = cok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
                     if (ok) {
                         const long pix = (long)a_pix0[i] + kh * a.W + kw;
-                        st.a[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci) * ESZ);
+                        st.a[i] = *reinterpret_cast<const uint4*>(xb + (pix * ps + ci - (from2 ? 0 : a.x_c0)) * ESZ);
                     }
                 }
             }
@@ -462,7 +466,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         } else {
             const unsigned cbad = cok ? 0u : kOOB;                          // channel tail of the last chunk of a tap
             const int ps = from2 ? a.x2ps : a.xps;
-            const unsigned toff = (unsigned)((kh * a.W + kw) * ps + cc * CE) * ESZ;     // wave-uniform
+            const unsigned toff = (unsigned)((kh * a.W + kw) * ps + cc * CE - (from2 ? 0 : a.x_c0)) * ESZ;     // wave-uniform
             const __amdgpu_buffer_rsrc_t rs = from2 ? rs_x2 : rs_x;
 #pragma unroll
             for (int i = 0; i < A_ROWS_PT; ++i) {
@@ -512,7 +516,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         const unsigned cbad = ci < a.Cin ? 0u : kOOB;
         p_from2 = (a.split_c > 0) && (cc * CE < a.split_c);
         const int ps = p_from2 ? a.x2ps : a.xps;
-        const unsigned toff = (unsigned)((kh * a.W + kw) * ps + cc * CE) * ESZ;
+        const unsigned toff = (unsigned)((kh * a.W + kw) * ps + cc * CE - (p_from2 ? 0 : a.x_c0)) * ESZ;
 #pragma unroll
         for (int i = 0; i < A_ROWS_PT; ++i) {
             const bool ok = ((hmask[i] >> kh) & (wmask[i] >> kw) & 1u) != 0u;
@@ -784,7 +788,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
             const bool live = c.left > 0;
             const bool from2 = (a.split_c > 0) && (c.cc * CE < a.split_c);
             const int ps = from2 ? a.x2ps : a.xps;
-            const unsigned toff = (unsigned)((c.kh * a.W + c.kw) * ps + c.cc * CE) * ESZ;       // wave-uniform
+            const unsigned toff = (unsigned)((c.kh * a.W + c.kw) * ps + c.cc * CE - (from2 ? 0 : a.x_c0)) * ESZ;       // wave-uniform
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int i = 2 * h + n;
@@ -1027,7 +1031,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // The block tile is staged through LDS (the A/B buffers are dead after the last barrier) with 16-byte writes and read
     // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
     // residual loads.
-    const bool e_bias = EPI == 0 ? a.bias != nullptr : (EPI == 4 || EPI == 5);
+    const bool e_bias = EPI == 0 ? a.bias != nullptr : (EPI == 4 || EPI == 5 || (EPI == 6 && a.bias != nullptr));   // ([r5] EPI 6 + bias: mvf_conv2d_nhwc_dgrad_bnsums_split)
     const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8 || EPI == 9 || EPI == 10);
     constexpr bool e_bw = EPI == 9 || EPI == 10;         // BatchNorm backward on the recomputed conv output (g and its sign-bit gate arrive as the residual operand)
     const bool e_relu = EPI == 0 ? a.relu != 0 : (EPI == 4 || EPI == 5);
@@ -1092,6 +1096,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.res_mask ? a.res_mask + (long)m0 * (a.Cout / 4) : (const unsigned char*)a.y), 0,
         (unsigned)min((long)(a.M - m0) * (a.Cout / 4), 0x7ffffff0L), 0x00020000);
+    // [r5] the OUTPUT gate (same layout): staged into the HIGH nibble of the same LDS bytes (the sign-bit bytes only use their low nibble), so
+    // the gated-output epilogue needs no LDS beyond the residual gate's and keeps its workgroups per CU
+    const __amdgpu_buffer_rsrc_t rs_gate = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.out_gate ? a.out_gate + (long)m0 * (a.Cout / 4) : (const unsigned char*)a.y), 0,
+        (unsigned)min((long)(a.M - m0) * (a.Cout / 4), 0x7ffffff0L), 0x00020000);
+    const bool e_gate = e_res && !e_apply && !e_bw && a.out_gate != nullptr;
     (void)y; (void)res;
     // The tile's gate bytes (BM rows x BN/4) are staged in LDS behind the C tile with ONE 16-byte load per thread (instead of a
     // byte load per thread per row, which made the gated data gradient 35 % slower than the ungated one); visible after the
@@ -1099,12 +1109,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     constexpr int kMaskOff = HR * CP;
     constexpr int MSEG = BN / 64;                        // 16-byte segments per mask row
     static_assert(kMaskOff + BM * (BN / 4) <= kSmem, "mask tile must fit behind the C tile");
-    const bool mask_lds = e_res && a.res_mask && (a.Cout % 64 == 0) && a.mask_lds;
+    const bool mask_lds = e_res && (a.res_mask || e_gate) && (a.Cout % 64 == 0) && a.mask_lds;
     if (mask_lds) {
 #pragma unroll
         for (int it = tid; it < BM * MSEG; it += NT) {       // (one trip for the 128 x 128 / 128 x 64 tiles, two for 256 x 256)
             const int row = it / MSEG, seg = it - row * MSEG;
-            const u32x4 mv = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (unsigned)(row * (a.Cout / 4) + n0 / 4 + seg * 16), 0, 0);
+            const unsigned moff = (unsigned)(row * (a.Cout / 4) + n0 / 4 + seg * 16);
+            u32x4 mv = {0x0f0f0f0fu, 0x0f0f0f0fu, 0x0f0f0f0fu, 0x0f0f0f0fu};      // no residual gate: every residual passes
+            if (a.res_mask) mv = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, moff, 0, 0);
+            if (e_gate) {
+                const u32x4 gv = __builtin_amdgcn_raw_buffer_load_b128(rs_gate, moff, 0, 0);
+                mv.x = (mv.x & 0x0f0f0f0fu) | ((gv.x & 0x0f0f0f0fu) << 4); mv.y = (mv.y & 0x0f0f0f0fu) | ((gv.y & 0x0f0f0f0fu) << 4);
+                mv.z = (mv.z & 0x0f0f0f0fu) | ((gv.z & 0x0f0f0f0fu) << 4); mv.w = (mv.w & 0x0f0f0f0fu) | ((gv.w & 0x0f0f0f0fu) << 4);
+            }
             *reinterpret_cast<uint4*>(smem + kMaskOff + row * (BN / 4) + seg * 16) = make_uint4(mv.x, mv.y, mv.z, mv.w);
         }
     }
@@ -1340,13 +1357,22 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 if (e_bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
                 if (e_res && !e_apply && !e_bw) {
                     float4 rv = unpack(rraw[ps]);
-                    if (a.res_mask) {
-                        const unsigned mb = mask_lds ? (unsigned)*reinterpret_cast<const unsigned char*>(smem + kMaskOff + (hf * HR + r0 + ps * RPP) * (BN / 4) + cq)
-                                                     : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, ok ? off / (4 * ESZ) : kOOB, 0, 0);
+                    unsigned mb = 0xffu;
+                    if (a.res_mask || e_gate) {
+                        if (mask_lds) mb = (unsigned)*reinterpret_cast<const unsigned char*>(smem + kMaskOff + (hf * HR + r0 + ps * RPP) * (BN / 4) + cq);
+                        else {
+                            if (a.res_mask) mb = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, ok ? off / (4 * ESZ) : kOOB, 0, 0) & 0xfu;
+                            else mb = 0xfu;
+                            mb |= e_gate ? ((unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_gate, ok ? off / (4 * ESZ) : kOOB, 0, 0) & 0xfu) << 4 : 0xf0u;
+                        }
                         rv.x = (mb & 1u) ? rv.x : 0.f; rv.y = (mb & 2u) ? rv.y : 0.f;
                         rv.z = (mb & 4u) ? rv.z : 0.f; rv.w = (mb & 8u) ? rv.w : 0.f;
                     }
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    if (e_gate && col >= a.res_c0) {         // [r5] gm = (data gradient + skip-connection gradient) * [block output below > 0]
+                        v.x = (mb & 16u) ? v.x : 0.f; v.y = (mb & 32u) ? v.y : 0.f;
+                        v.z = (mb & 64u) ? v.z : 0.f; v.w = (mb & 128u) ? v.w : 0.f;
+                    }
                 }
                 if (e_relu) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -1913,7 +1939,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         const bool contiguous = (epi_spec & 1) && a.o_s <= 0;
         const bool train_like = contiguous && !a.bias && !a.relu;
         const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
-        const bool bnsum_epi = (epi_spec & 1) && a.bn_z && !a.bias && !a.relu && !a.res;      // contiguous or a scattered parity class
+        const bool bnsum_epi = (epi_spec & 1) && a.bn_z && !a.relu && !a.res;      // contiguous or a scattered parity class ([r5] + an optional bias)
         // long K, wide output: the 256 x 128 LDS-DMA tile (MVF_CONV_BIG = <min chunks>, 0 = off)
         if (BN == 128 && sizeof(ET) == 2 && g_big2_min > 0 && a.nchunks >= g_big2_min && a.Cout % 256 == 0 && a.o_s <= 0 && !a.ap_scale && !a.bw_mode) {
             const long t2 = (long)((a.M + 255) / 256) * (a.Cout / 256);
@@ -2080,7 +2106,7 @@ struct BnApply {              // optional: the epilogue applies a BatchNorm + re
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
                          void* stream, const unsigned char* res_mask = nullptr, const BnBwdSums* bnb = nullptr, const MvfFuse* mf = nullptr,
-                         const BnApply* ap = nullptr, const BnBwdRecompute* bw = nullptr);
+                         const BnApply* ap = nullptr, const BnBwdRecompute* bw = nullptr, const unsigned char* out_gate = nullptr);
 
 int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void* w_packed, const float* bias, const float* mvf_coef,
                             int cs, int n_segment, int act, void* y, void* ws, size_t ws_bytes, void* stream) {
@@ -2141,6 +2167,24 @@ int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const v
     return conv_fwd_impl(d, x, x2, w_packed, bias, residual, y, nullptr, nullptr, ws, ws_bytes, stream, res_sign_bits);
 }
 
+int mvf_conv2d_nhwc_fwd_resmask_gate(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
+                                     const void* residual, const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && residual && out_gate_bits && d->in_dil <= 1 && !d->relu, MVF_EINVAL, "conv2d_resmask_gate: needs a residual, the gate bits and a stride-1 / non-dilated launch without ReLU");
+    MVF_REQUIRE(((uintptr_t)out_gate_bits | (uintptr_t)(res_sign_bits ? res_sign_bits : out_gate_bits)) % 16 == 0 || d->cout % 64 != 0, MVF_EINVAL,
+                "conv2d_resmask_gate: gate byte rows must be 16-byte aligned");
+    return conv_fwd_impl(d, x, x2, w_packed, bias, residual, y, nullptr, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits);
+}
+
+int mvf_conv2d_nhwc_dgrad_bnsums_split(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias, void* y,
+                                       const void* bn_z, const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
+                                       float* sums_part, void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && bn_z && bn_mean && bn_invstd && bn_scale && bn_shift && sums_part, MVF_EINVAL, "conv2d_dgrad_bnsums_split: NULL argument");
+    MVF_REQUIRE(d->in_dil <= 1 && !d->relu && d->kh == 1 && d->kw == 1 && d->stride == 1, MVF_EINVAL, "conv2d_dgrad_bnsums_split: a pointwise stride-1 launch");
+    const BnBwdSums b = {bn_z, bn_mean, bn_invstd, bn_scale, bn_shift};
+    return conv_fwd_impl(d, x, x2, w_packed, bias, nullptr, y, sums_part, nullptr, ws, ws_bytes, stream, nullptr, &b);
+}
+
 int mvf_conv2d_nhwc_fwd_ws(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed,
                            const float* bias, const void* residual, void* y, void* ws, size_t ws_bytes, void* stream) {
     return conv_fwd_impl(d, x, x2, w_packed, bias, residual, y, nullptr, nullptr, ws, ws_bytes, stream);
@@ -2169,7 +2213,8 @@ int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const voi
 
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
-                         void* stream, const unsigned char* res_mask, const BnBwdSums* bnb, const MvfFuse* mf, const BnApply* ap, const BnBwdRecompute* bw) {
+                         void* stream, const unsigned char* res_mask, const BnBwdSums* bnb, const MvfFuse* mf, const BnApply* ap, const BnBwdRecompute* bw,
+                         const unsigned char* out_gate) {
     MVF_REQUIRE(d && x && w_packed && (y || (stats_part && !bnb)), MVF_EINVAL, "conv2d: NULL argument");      // (y may be NULL for a statistics-only pass)
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -2203,6 +2248,10 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     a.split_c = d->split_c; a.x2ps = d->x2_pix_stride; a.relu = d->relu; a.dil = dil;
     a.res_c0 = d->res_c0 > 0 ? d->res_c0 : 0;
     a.res_mask = res_mask;
+    a.out_gate = out_gate;
+    MVF_REQUIRE(d->x_c0 == 0 || (d->split_c > 0 && d->x_c0 > 0 && d->x_c0 <= d->split_c && d->x_c0 % ue == 0 && d->x_pix_stride >= d->cin - d->x_c0), MVF_EINVAL,
+                "conv2d: x_c0=%d needs a split operand (split_c=%d), 0 < x_c0 <= split_c, a multiple of %d, and x rows of >= cin - x_c0 channels", d->x_c0, d->split_c, ue);
+    a.x_c0 = d->x_c0;
     static const int mask_lds_on = getenv("MVF_MASK_LDS") ? atoi(getenv("MVF_MASK_LDS")) : 1;
     a.mask_lds = mask_lds_on;
     static const int prio_on = getenv("MVF_CONV_PRIO") ? atoi(getenv("MVF_CONV_PRIO")) : 0;

@@ -39,6 +39,9 @@ struct NhwcArgs {
     const void* add;   // optional addend (same pixels, channel pitch add_c), added after the activation
     int add_c;
     const unsigned char* add_mask;   // optional gate bits of the addend: [pixels][add_c/4] bytes, bit j of byte k = channel 4k+j
+    float* stats_part;               // [r5] optional (chunked kernel): CHANNEL-MAJOR [cs][gridDim.x][2] column sums of (y - K), (y - K)^2 over the workgroup's outputs AS STORED
+    const float* stats_shift;        //      K per channel (the BatchNorm's old running mean; NULL = 0): the statistics pass of MVF's BatchNorm3d without a pass over y
+    const unsigned char* out_gate;   // [r5] optional gate bits of the OUTPUT (after the addend): [pixels][out_c/4] bytes, same layout (VEC = 4 kernels only)
     int tsplit;    // 1: one frame per workgroup (grid.z = T) instead of sliding along t -- 7 loads, one round trip, T x the threads
 };
 
@@ -137,6 +140,11 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply(NhwcArgs a) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) y[i] += ((mb >> i) & 1u) ? ad[i] : 0.f;
             }
+            if (a.out_gate) {
+                const unsigned gb = a.out_gate[(((long)n * T + t) * HW + pix) * (a.out_c / 4) + c0 / 4] >> (c0 & 3);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) y[i] = ((gb >> i) & 1u) ? y[i] : 0.f;
+            }
             Vec<ET, VEC>::store(out + o0 + (long)t * HW * a.out_c, y);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
@@ -159,11 +167,15 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
     const int n = blockIdx.x / a.bands, band = blockIdx.x % a.bands;
     const int cgi = blockIdx.y * a.cgp + (threadIdx.x % a.cgp);
     const int plane = threadIdx.x / a.cgp, nplanes = kThreads / a.cgp;
-    if (cgi >= a.cg) return;
-    const int c0 = cgi * VEC;
+    const bool active = cgi < a.cg;
+    if (!active && !a.stats_part) return;
+    const int c0 = active ? cgi * VEC : 0;
     const bool vh = a.mode & MVF_VIEW_H, vw = a.mode & MVF_VIEW_W;
     const bool hs = a.scale != nullptr;
     float wt[VEC][3], wh[VEC][3], ww[VEC][3], sc[VEC], sh[VEC];
+    float st1[VEC], st2[VEC], kk[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { st1[i] = st2[i] = 0.f; kk[i] = (a.stats_part && a.stats_shift) ? a.stats_shift[c0 + i] : 0.f; }
     {
         auto load12 = [&](const float* p, bool on, float (&dst)[VEC][3]) {
             float f[12];
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
     const ET* x = reinterpret_cast<const ET*>(a.x);
     ET* out = reinterpret_cast<ET*>(a.out);
     const long fstride = (long)HW * C;                         // one frame
-    const int pend = min(HW, (band + 1) * a.pixw);
+    const int pend = active ? min(HW, (band + 1) * a.pixw) : 0;
     for (int pix = band * a.pixw + plane; pix < pend; pix += nplanes) {
         const int hh = pix / W, wv = pix - hh * W;
         const long e0 = ((long)n * T * HW + pix) * C + c0;     // (n, t=0, pix, c0)
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
         const long d_up = ok_up ? -(long)W * C : 0, d_dn = ok_dn ? (long)W * C : 0, d_lf = ok_lf ? -(long)C : 0, d_rt = ok_rt ? (long)C : 0;
         for (int t0 = 0; t0 < T; t0 += TB) {
             float cen[TB + 2][VEC], up[TB][VEC], dn[TB][VEC], lf[TB][VEC], rt[TB][VEC], ad[TB][VEC];
-            unsigned mb[TB];
+            unsigned mb[TB], gb[TB];
 #pragma unroll
             for (int k = 0; k < TB + 2; ++k) {                 // frames t0 - 1 .. t0 + TB (clamped into the clip; zeroed below where outside)
                 int t = t0 - 1 + k;
@@ -221,6 +233,8 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
                 Vec<ET, VEC>::load(f + d_lf, lf[k]);
                 Vec<ET, VEC>::load(f + d_rt, rt[k]);
                 mb[k] = 0xfu;
+                gb[k] = 0xfu;
+                if (a.out_gate) gb[k] = a.out_gate[(((long)n * T + t) * HW + pix) * (a.out_c / 4) + c0 / 4] >> (c0 & 3);
                 if (a.add) {
                     const long apix = ((long)n * T + t) * HW + pix;
                     Vec<ET, VEC>::load(reinterpret_cast<const ET*>(a.add) + apix * a.add_c + c0, ad[k]);
@@ -246,9 +260,40 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
                         v = u * (fminf(fmaxf(u + 3.0f, 0.0f), 6.0f) / 6.0f);
                     }
                     if (a.add) v += ((mb[k] >> i) & 1u) ? ad[k][i] : 0.f;
-                    y[i] = v;
+                    y[i] = ((gb[k] >> i) & 1u) ? v : 0.f;      // (all ones without an output gate)
                 }
                 Vec<ET, VEC>::store(out + o0 + (long)t * HW * a.out_c, y);
+                if (a.stats_part) {                            // statistics of what is STORED, as bn_stats_kernel would read it back
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        float v = y[i];
+                        if constexpr (sizeof(ET) == 2) v = bf16_to_f32(f32_to_bf16(v));
+                        const float dlt = v - kk[i];
+                        st1[i] += dlt;
+                        st2[i] += dlt * dlt;
+                    }
+                }
+            }
+        }
+    }
+    if (a.stats_part) {
+        // the workgroup's column sums: the planes of a channel group in order (fixed), one partial row per workgroup
+        __shared__ float red[kThreads * 2 * VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            red[(threadIdx.x * VEC + i) * 2] = st1[i];
+            red[(threadIdx.x * VEC + i) * 2 + 1] = st2[i];
+        }
+        __syncthreads();
+        if (plane == 0 && active) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float t1 = 0.f, t2 = 0.f;
+                for (int q = 0; q < nplanes; ++q) {
+                    t1 += red[((q * a.cgp + (threadIdx.x % a.cgp)) * VEC + i) * 2];
+                    t2 += red[((q * a.cgp + (threadIdx.x % a.cgp)) * VEC + i) * 2 + 1];
+                }
+                reinterpret_cast<float2*>(a.stats_part)[(long)(c0 + i) * gridDim.x + blockIdx.x] = make_float2(t1, t2);
             }
         }
     }
@@ -268,7 +313,7 @@ __global__ void copy_tail_nhwc(const ET* src, ET* dst, long npix, int c, int cs)
 
 }  // namespace
 
-struct NhwcFlip { int flip; const void* add; int add_c; const unsigned char* add_mask; };
+struct NhwcFlip { int flip; const void* add; int add_c; const unsigned char* add_mask; const unsigned char* out_gate; float* stats_part; const float* stats_shift; int rows_only; };
 int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
                              const float* ww, const float* scale, const float* shift, NhwcFlip fl, hipStream_t st) {
     // In-place hazard: a workgroup re-reads neighbour pixels that another workgroup may already have overwritten.
@@ -284,9 +329,13 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     a.add = fl.add;
     a.add_c = fl.add_c;
     a.add_mask = fl.add_mask;
+    a.out_gate = fl.out_gate;
+    a.stats_part = fl.stats_part;
+    a.stats_shift = fl.stats_shift;
     const int esz = d->dtype == MVF_F32 ? 4 : 2;
     const bool vec = (d->cs % 4 == 0) && (d->c % 4 == 0) && (out_c % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % (4 * esz) == 0) &&
                      (!fl.add || (fl.add_c % 4 == 0 && (uintptr_t)fl.add % (4 * esz) == 0));
+    MVF_REQUIRE(!fl.out_gate || vec, MVF_EUNSUPPORTED, "nhwc_stencil: the output gate needs the 4-channel kernels (cs, pitches %% 4 == 0, aligned operands)");
     a.cg = vec ? d->cs / 4 : d->cs;
     int cgp = 1;
     while (cgp < a.cg && cgp < kThreads) cgp <<= 1;
@@ -308,9 +357,11 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     static const int tsplit_env = getenv("MVF_STENCIL_TSPLIT") ? atoi(getenv("MVF_STENCIL_TSPLIT")) : 0;
     a.tsplit = tsplit_env != 0 && a.T > 1;
     dim3 grid(a.n_clips * a.bands, (a.cg + cgp - 1) / cgp, a.tsplit ? a.T : 1);
+    if (fl.rows_only) return (int)grid.x;                  // mvf_nhwc_stencil_stats_rows: the partial-row count of this plan, nothing is launched
     // [r3] all of a chunk's loads in flight at once instead of the serial walk over t (MVF_STENCIL_CHUNKED=0: the walk)
     static const int chunked_env = getenv("MVF_STENCIL_CHUNKED") ? atoi(getenv("MVF_STENCIL_CHUNKED")) : 1;
     const bool chunked = chunked_env != 0 && vec && !a.tsplit && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0;
+    MVF_REQUIRE(!fl.stats_part || chunked, MVF_EUNSUPPORTED, "nhwc_stencil_stats: needs the chunked 4-channel kernel (cs, pitches %% 4 == 0, 16-byte aligned taps, MVF_STENCIL_CHUNKED != 0)");
     if (d->dtype == MVF_F32) {
         if (chunked) hipLaunchKernelGGL((mvf_nhwc_apply_chunked<float, 4>), grid, dim3(kThreads), 0, st, a);
         else if (vec) hipLaunchKernelGGL((mvf_nhwc_apply<float, 4>), grid, dim3(kThreads), 0, st, a);
@@ -335,7 +386,7 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
 
 int mvf_nhwc_fwd_infer_impl(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
                             const float* ww, const float* scale, const float* shift, hipStream_t st) {
-    NhwcFlip f = {0, nullptr, 0, nullptr};
+    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
     return mvf_nhwc_fwd_infer_impl2(d, x, out, out_c, wt, wh, ww, scale, shift, f, st);
 }
 
@@ -660,8 +711,42 @@ int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int
     MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil: gate bits need an addend with pitch % 4 == 0");
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits};
+    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, nullptr, nullptr, nullptr, 0};
     return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, scale, shift, f, (hipStream_t)stream);
+}
+
+// [r5] ... with the OUTPUT gated per channel by out_gate_bits ([pixels][out_c/4] bytes, the sign bits of the block output this gradient belongs to):
+// out[..., :cs] = (f(stencil(x)) + gated addend) * [bit] -- the transposed stencil then hands the block below gm = g * [out > 0] for the slice, as
+// mvf_conv2d_nhwc_fwd_resmask_gate does for the channels >= cs
+int mvf_nhwc_stencil_gate(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
+                          const float* w_w, const float* scale, const float* shift, int flip, const void* addend, int addend_c,
+                          const unsigned char* addend_sign_bits, const unsigned char* out_gate_bits, void* stream) {
+    MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs && out_gate_bits, MVF_EINVAL, "nhwc_stencil_gate: bad argument");
+    MVF_REQUIRE(!addend || addend_c >= d->cs, MVF_EINVAL, "nhwc_stencil_gate: addend pitch < cs");
+    MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil_gate: gate bits need an addend with pitch % 4 == 0");
+    mvf_desc_t dd = *d;
+    dd.c = x_c;
+    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, out_gate_bits, nullptr, nullptr, 0};
+    return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, scale, shift, f, (hipStream_t)stream);
+}
+
+// [r5] the plain stencil (y = taps * x-slice, no activation) that ALSO accumulates the batch statistics of MVF's BatchNorm3d (MVF.py:131-134, training
+// mode) over what it stores: stats_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, ...)][2] = per-workgroup sums of (y - K), (y - K)^2 with
+// K = stats_shift (the old running mean; NULL = 0) -> mvf_bn_train_finalize.  Replaces the separate statistics pass over y (mvf_bn_train_stats).
+int mvf_nhwc_stencil_stats_rows(const mvf_desc_t* d, int x_c, int out_c) {
+    if (!d || d->cs <= 0 || d->nt <= 0) return 0;
+    mvf_desc_t dd = *d;
+    dd.c = x_c;
+    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 1};
+    return mvf_nhwc_fwd_infer_impl2(&dd, (const void*)16, (void*)32, out_c, (const float*)16, (const float*)16, (const float*)16, nullptr, nullptr, f, nullptr);
+}
+int mvf_nhwc_stencil_stats(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
+                           const float* w_w, float* stats_part, const float* stats_shift, void* stream) {
+    MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs && stats_part, MVF_EINVAL, "nhwc_stencil_stats: bad argument");
+    mvf_desc_t dd = *d;
+    dd.c = x_c;
+    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, stats_part, stats_shift, 0};
+    return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, nullptr, nullptr, f, (hipStream_t)stream);
 }
 
 size_t mvf_nhwc_tapgrad_workspace_bytes(const mvf_desc_t* d) {

@@ -430,16 +430,78 @@ class _TConv(object):
         check(lib.mvf_conv2d_nhwc_dgrad_bnsums(C.byref(d), _p(dz), _p(self.wd), _p(dx), _p(z), _p(bn.mean), _p(bn.invstd), _p(bn.scale), _p(bn.shift),
                                                _p(part), _p(ws), ws.numel(), _st()), "conv dgrad+bn sums")
 
-    def dgrad(self, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None):
+    def dgrad(self, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None, out_gate=None):
         """dx (n*h*w, cin) from dz (n*ho*wo, cout): a conv of dz with the flipped/transposed weights (+ residual, on output
-        channels >= res_c0, gated per element by the sign bits res_bits when given)."""
+        channels >= res_c0, gated per element by the sign bits res_bits when given).  [r5] out_gate: the sign bits of the tensor dx is the
+        gradient of -- channels >= res_c0 of dx are gated by them, so the block below receives gm = g * [out > 0] as a tensor."""
         d = ConvDesc(n, ho, wo, self.cout, self.cin, self.kh, self.kw, 1, self.kh - 1 - self.pad, h, w, self.cout, self.eng.dt, 0, 0, 0,
                      self.stride if self.stride > 1 else 0, res_c0)
         dx = self.eng.buf((id(self), "dx"), (n * h * w, self.cin))
         ws = _conv_ws(dz.device)
-        check(lib.mvf_conv2d_nhwc_fwd_resmask(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(res_bits), _p(dx), _p(ws), ws.numel(),
-                                              _st()), "conv dgrad")
+        if out_gate is not None:
+            check(lib.mvf_conv2d_nhwc_fwd_resmask_gate(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(res_bits), _p(out_gate), _p(dx), _p(ws),
+                                                       ws.numel(), _st()), "conv dgrad (gated output)")
+        else:
+            check(lib.mvf_conv2d_nhwc_fwd_resmask(C.byref(d), _p(dz), None, _p(self.wd), None, _p(residual), _p(res_bits), _p(dx), _p(ws), ws.numel(),
+                                                  _st()), "conv dgrad")
         return dx
+
+    # ---- [r5] the block's last conv + bn3 backward WITHOUT the dz3 tensor (csrc/bn_dzfree.hip) -------------------------------------------------
+    def dzfree_ok(self, m):
+        """Pointwise stride-1 conv, bf16 storage, shapes the split-operand data gradient and the prep kernel take."""
+        return (self.eng.tdtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and self.stride == 1 and not self.stem and
+                self.cout % 256 == 0 and self.cin % 64 == 0 and self.cout <= 4096 and m * (self.cout + self.cin) * 2 < 0x7ffffff0)
+
+    def dzfree_dgrad(self, gm, a_in, bn, n, h, w, bn_in, z_in, frozen_zero=None):
+        """da = dz W with dz = bn's backward of gm -- taken as ONE GEMM over [gm | a_in] with the weights [a.W ; -G] and a bias (mvf_bn_bwd_dzfree_prep),
+        + bn_in's backward sums in the epilogue.  bn.dgamma / bn.dbeta must hold the sums already."""
+        eng = self.eng
+        c, k, m = self.cout, self.cin, n * h * w
+        bd = eng.buf((id(self), "dzfree_w"), (k, c + k))
+        bias = eng.buf((id(self), "dzfree_b"), (k,), torch.float32)
+        sg, sb = (frozen_zero, frozen_zero) if frozen_zero is not None else (bn.dgamma, bn.dbeta)
+        check(lib.mvf_bn_bwd_dzfree_prep(_p(self.wd), c, k, _p(bn.gamma), _p(bn.mean), _p(bn.invstd), _p(sg), _p(sb), m, _p(bd), _p(bias), eng.dt, _st()),
+              "bn backward without dz: operands")
+        d = ConvDesc(n, h, w, c + k, k, 1, 1, 1, 0, h, w, k, eng.dt, 0, c, c, 0, 0, c)        # x = a_in (pitch k, columns c .. c + k), x2 = gm (pitch c)
+        dx = eng.buf((id(self), "dx"), (m, k))
+        ws = _conv_ws(gm.device)
+        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        part = eng.buf((id(self), "bnsums"), (rows, k, 2), torch.float32)
+        self.launch_dzfree_dgrad(d, a_in, gm, bd, bias, dx, z_in, bn_in, part, ws)
+        check(lib.mvf_bn_bwd_finalize(_p(part), rows, k, _p(bn_in.dgamma), _p(bn_in.dbeta), _st()), "bn bwd finalize")
+        return dx
+
+    def launch_dzfree_dgrad(self, d, a_in, gm, bd, bias, dx, z_in, bn_in, part, ws):
+        """Exactly one implicit-GEMM launch (bench.py brackets this call with HIP events)."""
+        check(lib.mvf_conv2d_nhwc_dgrad_bnsums_split(C.byref(d), _p(a_in), _p(gm), _p(bd), _p(bias), _p(dx), _p(z_in), _p(bn_in.mean), _p(bn_in.invstd),
+                                                     _p(bn_in.scale), _p(bn_in.shift), _p(part), _p(ws), ws.numel(), _st()), "conv dgrad on [gm | a] + bn sums")
+
+    def dzfree_wgrad(self, gm, a_in, bn, n, h, w, eng, frozen_zero=None):
+        """dW = dz^T a_in without dz: Q = gm^T a_in (the usual weight-gradient GEMM, into dw), A2 = a_in^T a_in and the column means of a_in, then the
+        correction kernel -- all on the side stream (they only feed the optimizer)."""
+        c, k, m = self.cout, self.cin, n * h * w
+        self.wgrad(gm, a_in, n, h, w, h, w, eng)
+        gram = eng.buf((id(self), "gram"), (k, k), torch.float32)
+        amean = eng.buf((id(self), "amean"), (4, k), torch.float32)            # rows: mean, and three outputs of the statistics call nobody reads
+        d = ConvDesc(n, h, w, k, k, 1, 1, 1, 0, h, w, k, eng.dt, 0, 0, 0, 0)
+        nbytes = max(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)), lib.mvf_bn_workspace_bytes(m, k))
+        if k not in eng._ones:
+            eng._ones[k] = (torch.ones(k, device=gm.device), torch.zeros(k, device=gm.device))
+        one, zero = eng._ones[k]
+        sg, sb = (frozen_zero, frozen_zero) if frozen_zero is not None else (bn.dgamma, bn.dbeta)
+        side = eng.side_stream()
+        ws = eng.workspace(nbytes, side=side is not None)
+
+        def launch():
+            check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(a_in), _p(a_in), None, 1, k, 1, k, _p(gram), _p(ws), ws.numel(), _st()), "gram")
+            check(lib.mvf_bn_train_stats(_p(a_in), m, k, _p(one), _p(zero), C.c_float(1e-5), C.c_float(0.1), None, None, _p(amean[0]), _p(amean[1]),
+                                         _p(amean[2]), _p(amean[3]), _p(ws), ws.numel(), eng.dt, _st()), "column means")
+            check(lib.mvf_bn_bwd_dzfree_wgrad(_p(self.dw), _p(self.wp), _p(gram), _p(amean[0]), _p(bn.gamma), _p(bn.mean), _p(bn.invstd), _p(sg), _p(sb),
+                                              m, c, k, eng.dt, _st()), "weight gradient without dz: correction")
+        if side is None:
+            launch()
+        else:
+            eng.on_side(launch)
 
 
 class _TMvf(object):
@@ -467,13 +529,25 @@ class _TMvf(object):
         m = nt * h * w
         d = self.desc(nt, h, w, c)
         y = self.eng.buf((id(self), "y"), (m, self.cs))
+        if self.use_hs and eng.fuse_mvf_stats and eng.fuse_stats and not self.bn.frozen and self.cs % 4 == 0:
+            # [r5] the stencil accumulates the BatchNorm's batch statistics over what it stores: no separate pass over y
+            rows = lib.mvf_nhwc_stencil_stats_rows(C.byref(d), c, self.cs)
+            part = self.eng.buf((id(self), "part"), (self.cs, rows, 2), torch.float32)
+            self.launch_stencil_stats(d, x, c, y, part)
+            self.bn.finalize(part, rows, m)
+            return y, self.bn.apply(y, m, 2)
         self.launch_stencil(d, x, c, y, self.cs, 0, None, 0, None)
         if not self.use_hs:
             return y, y
         self.bn.stats(y, m, eng)
         return y, self.bn.apply(y, m, 2)
 
-    def backward(self, dxp, x, y, nt, h, w, c, eng, addend=None, addend_bits=None):
+    def launch_stencil_stats(self, d, x, c, y, part):
+        """Exactly one MVF stencil launch (bench.py brackets this call with HIP events)."""
+        check(lib.mvf_nhwc_stencil_stats(C.byref(d), _p(x), c, _p(y), self.cs, _p(self.wt), _p(self.wh), _p(self.ww), _p(part), _p(self.bn.mod.running_mean),
+                                         _st()), "mvf stencil + statistics")
+
+    def backward(self, dxp, x, y, nt, h, w, c, eng, addend=None, addend_bits=None, out_gate=None):
         """dxp (m, c): grad w.r.t. the conv input [o | x_rest]; on return its first cs channels hold the grad w.r.t. x's slice
         (+ addend[:, :cs], the skip-connection gradient, when given: the conv epilogue added it to channels >= cs only)."""
         m = nt * h * w
@@ -499,11 +573,15 @@ class _TMvf(object):
             def launch():
                 check(lib.mvf_nhwc_tapgrad(C.byref(d), _p(x), c, _p(dy), self.cs, _p(self.dwt), _p(dwh), _p(dww), _p(ws), ws.numel(), _st()), "mvf tapgrad")
             eng.on_side(launch)
-        self.launch_stencil(d, dy, self.cs, dxp, c, 1, addend, c if addend is not None else 0, addend_bits)
+        self.launch_stencil(d, dy, self.cs, dxp, c, 1, addend, c if addend is not None else 0, addend_bits, out_gate)
 
-    def launch_stencil(self, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits):
-        """Exactly one MVF stencil launch (plain: y = taps * x-slice; flip: the transposed stencil of the backward, + gated addend);
-        bench.py brackets this call with HIP events."""
+    def launch_stencil(self, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits, out_gate=None):
+        """Exactly one MVF stencil launch (plain: y = taps * x-slice; flip: the transposed stencil of the backward, + gated addend
+        [, the result gated by out_gate: the block below then receives the slice of gm = g * [out > 0]]); bench.py brackets this call with HIP events."""
+        if out_gate is not None:
+            check(lib.mvf_nhwc_stencil_gate(C.byref(d), _p(src), src_c, _p(dst), dst_c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, flip,
+                                            _p(addend), addend_c, _p(addend_bits), _p(out_gate), _st()), "mvf stencil (gated output)")
+            return
         check(lib.mvf_nhwc_stencil(C.byref(d), _p(src), src_c, _p(dst), dst_c, _p(self.wt), _p(self.wh), _p(self.ww), None, None, flip,
                                    _p(addend), addend_c, _p(addend_bits), _st()), "mvf stencil")
 
@@ -566,6 +644,21 @@ class _TBlock(object):
         # kernel (stride 1: the downsample branch sees the same m2 pixels) refuses the shape
         return lib.mvf_conv1x1_bwd_fused_splits(m2, self.c3.cout, self.c3.cin) > 0
 
+    def dzfree(self, eng, m2=None):
+        """[r5] bn3's backward without the dz3 tensor (csrc/bn_dzfree.hip): plain blocks (no downsample branch) with a STORED z3 whose last conv
+        is pointwise; eng.dzfree: 0 off, 1 planes >= 256 (where dz3 is the widest tensor and no fused pass exists), 2 every eligible block."""
+        if not eng.dzfree or self.cd is not None or self.z3_free(eng, m2) or not eng.fuse_bn_bwd_sums or not self.c3.dzfree_ok(m2 or (1 << 16)):
+            return False
+        return eng.dzfree == 2 or self.c3.cin >= 256
+
+    def wants_gated_gradient(self, eng):
+        """The sign bits of this block's output when its backward wants gm = g * [out > 0] as a tensor (the dz3-free path reads it by LDS-DMA):
+        the block ABOVE then gates the gradient it produces (conv1's data-gradient epilogue, the MVF transposed stencil)."""
+        s = self.saved
+        if s is None or not eng.gate_producer:
+            return None
+        return s["bits"] if self.dzfree(eng, s["out"].shape[0]) else None
+
     def launch_sums_pair(self, a2, x, x_pitch, g, bits, m, eng):
         """Exactly one launch (bench.py brackets this call with HIP events) + the two finalizes."""
         c3, cd = self.c3, self.cd
@@ -622,11 +715,16 @@ class _TBlock(object):
         self.saved = s
         return out, ho, wo, self.c3.cout
 
-    def backward(self, g, nt, eng):
+    def backward(self, g, nt, eng, g_gated=False, out_gate=None):
+        """g: gradient of the block output; g_gated: it already IS gm = g * [out > 0] (the block above gated it for us).  out_gate: the sign bits of
+        the block BELOW's output when that block wants its gradient gated the same way; self.gated_out says whether the returned dx is."""
         s = self.saved
         h, w, c, ho, wo = s["h"], s["w"], s["c"], s["ho"], s["wo"]
         m, m2 = nt * h * w, nt * ho * wo
         bits = s["bits"]       # sign bits of the block output: the ReLU mask of g, applied wherever g is consumed (never materialised)
+        self.gated_out = False
+        if g_gated:
+            assert self.dzfree(eng, m2), "a gated gradient was produced for a block that does not take it"
         # Order matters for the two-stream overlap: each weight-gradient GEMM is queued on the side stream AFTER the
         # data-gradient GEMM that shares its dz has been queued on the main stream, so it starts when the main stream
         # moves on to the (HBM-bound) BatchNorm-backward kernels of the next layer -- MFMA work under memory work --
@@ -661,6 +759,20 @@ class _TBlock(object):
             dz3, w3_done = None, True
         elif s["z3"] is None:          # z3 was never stored: bn3's backward on the recomputed conv3
             dz3 = self.c3.bwd_recompute(s["a2"], g, bits, nt, ho, wo, self.b3)
+        elif self.dzfree(eng, m2):
+            # [r5] no dz3: bn3's sums on gm and z3, then the data gradient on [gm | a2] (+ bn2's sums) and, on the side stream, the weight gradient on gm
+            b3 = self.b3
+            if g_gated:
+                gm = g
+                b3._reduce(gm, self.c3.cout, s["z3"], m2, eng, 0, None, None)
+            else:
+                gm = eng.buf((id(b3), "gm"), s["z3"].shape, s["z3"].dtype)
+                b3._reduce(g, self.c3.cout, s["z3"], m2, eng, 4, bits, gm)
+            fz = b3._zero if b3.frozen else None
+            da2 = self.c3.dzfree_dgrad(gm, s["a2"], b3, nt, ho, wo, self.b2, s["z2"], frozen_zero=fz)
+            self.c3.dzfree_wgrad(gm, s["a2"], b3, nt, ho, wo, eng, frozen_zero=fz)
+            dz3, w3_done = None, True
+            del gm
         elif (eng.fuse_bnwg & 1) and self.c3.fuses_wgrad(eng, m2, self.c3.cout, 4):
             dz3 = self.b3.backward_wgrad(g, self.c3.cout, s["z3"], m2, eng, 4, bits, self.c3, s["a2"], self.c3.cin)
             w3_done = True
@@ -693,7 +805,7 @@ class _TBlock(object):
         else:
             dz1 = self.b1.backward(da1, self.c1.cout, s["z1"], m, eng, 2, sums_done=fuse1)
         del da1
-        resid, rbits = g, bits
+        resid, rbits = (g, None) if g_gated else (g, bits)
         if resid_ds is not None:
             resid, rbits = resid_ds, None
         elif self.cd is not None:
@@ -708,19 +820,22 @@ class _TBlock(object):
                 self.cd.wgrad(dzd, s["x"], nt, h, w, ho, wo, eng, x_pitch=c)
             del dzd
         if self.mvf is None:
-            dx = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid, res_bits=rbits)
+            dx = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid, res_bits=rbits, out_gate=out_gate)
+            self.gated_out = out_gate is not None
             if not w1_done:
                 self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c)
         else:
             # skip-connection gradient without a separate add pass: the data-gradient epilogue adds it to the pass-through
             # channels (>= cs); the slice [0, cs) first goes back through the MVF, whose transposed stencil adds its share
             fuse = self.mvf.cs % 4 == 0
-            dxp = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid if fuse else None, res_c0=self.mvf.cs, res_bits=rbits if fuse else None)
+            og = out_gate if fuse else None
+            dxp = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid if fuse else None, res_c0=self.mvf.cs, res_bits=rbits if fuse else None, out_gate=og)
+            self.gated_out = og is not None
             if self.split_ok:
                 self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c, x2=s["o"], split_c=self.mvf.cs)
             else:
                 self.c1.wgrad(dz1, s["xin"], nt, h, w, h, w, eng, x_pitch=c)
-            self.mvf.backward(dxp, s["x"], s["y"], nt, h, w, c, eng, addend=resid if fuse else None, addend_bits=rbits if fuse else None)
+            self.mvf.backward(dxp, s["x"], s["y"], nt, h, w, c, eng, addend=resid if fuse else None, addend_bits=rbits if fuse else None, out_gate=og)
             if not fuse:
                 if rbits is not None:       # odd slice widths: materialise g * mask once
                     resid = resid * (s["out"] > 0).to(resid.dtype)
@@ -728,7 +843,7 @@ class _TBlock(object):
             else:
                 dx = dxp
         if eng.keep_io:      # parity tests: this block's boundary tensors of the step (persistent buffers, valid until the next step)
-            self.io = dict(x=s["x"], out=s["out"], g=g, dx=dx, h=h, w=w, c=c, ho=ho, wo=wo)
+            self.io = dict(x=s["x"], out=s["out"], g=g, dx=dx, h=h, w=w, c=c, ho=ho, wo=wo, g_gated=g_gated, dx_gated=self.gated_out)
         self.saved = None
         if not getattr(eng, "_hold_side", False):
             eng.flush_side()
@@ -849,6 +964,12 @@ class _ParamStore(object):
     z3_free_ds = int(os.environ.get("MVF_Z3_FREE_DS", "1"))    # [r4] layer1.0 (downsample block, both convs 64 -> 256 pointwise): no stored z3, per-branch sums + one-pass backward instead of the paired BatchNorm backward
     fuse_c3_bwd = int(os.environ.get("MVF_FUSE_C3_BWD", "1"))   # [r4] z3-free blocks: conv3 recompute + bn3 backward apply + data gradient (+ bn2 sums) + weight gradient in ONE pass (csrc/pw_bwd_fused.hip); 0 = three launches
     fuse_bn_bwd_strided = os.environ.get("MVF_FUSE_BN_BWD_STRIDED", "1") != "0"    # ... also for the stride-2 convs' parity classes
+    # [r5] bn3's backward of plain blocks without the dz3 tensor (csrc/bn_dzfree.hip): 0 off, 1 planes >= 256, 2 every eligible block (layer2 ... layer4's plain
+    # blocks: in layer2 it also replaces the fused BatchNorm-backward + weight-gradient pass, which it beats); and the block above
+    # gating the gradient it hands down (0 = the dz3-free block's own sums pass writes gm)
+    fuse_mvf_stats = os.environ.get("MVF_FUSE_MVF_STATS", "1") != "0"     # [r5] MVF's BatchNorm statistics accumulated by the stencil launch (0 = a pass over y)
+    dzfree = int(os.environ.get("MVF_DZFREE", "2"))        # (measured in the step, one box: C3 19.13 -> 19.03 (1) / 18.78 ms (2); C4 33.66 -> 32.96 / 32.68 ms)
+    gate_producer = os.environ.get("MVF_GATE_PRODUCER", "1") != "0"
 
     def side_stream(self):
         if not self.overlap_wgrad:
@@ -1252,8 +1373,11 @@ class TrainEngine(_ParamStore):
         # leaves them: they then run beside layer2 / layer1's byte-bound BatchNorm passes and short-K convs.  Their operands are persistent
         # per-call-site buffers, so holding the launches back costs no memory.  The tail gradient bucket's all-reduce is ordered behind them.
         self._hold_side = bool(self.side_hold) and self._tail_block is not None and self.overlap_wgrad and self.defer_side
+        gated = False
         for i in range(len(self.blocks) - 1, -1, -1):
-            g = self.blocks[i].backward(g, nt, self)
+            og = self.blocks[i - 1].wants_gated_gradient(self) if i > 0 else None       # the block below takes gm = g * [out > 0] as a tensor
+            g = self.blocks[i].backward(g, nt, self, g_gated=gated, out_gate=og)
+            gated = self.blocks[i].gated_out
             if i == self._tail_block:
                 if self._hold_side:
                     self._hold_side = False

@@ -10,7 +10,7 @@ def test_library_loads_and_exports_declared_symbols():
     assert "mvf_fwd_infer" in names and "mvf_bwd" in names
     for n in names:
         assert hasattr(_lib.lib, n), "libmvfnet_hip.so does not export %s" % n
-    assert _lib.lib.mvf_abi_version() == 1
+    assert _lib.lib.mvf_abi_version() == 2        # [r5] 2: mvf_conv_desc_t.x_c0
 
 
 def test_argument_validation_needs_no_gpu():

@@ -1,0 +1,231 @@
+"""[r5] bn3's backward of a plain bottleneck WITHOUT the dz3 tensor (csrc/bn_dzfree.hip + the gated-output epilogues), through the C ABI.
+
+Reference: Bottleneck.forward, codes/models/backbones/resnet.py:229-244 (out = conv3(a2); out = norm3(out); out += identity; out = relu(out)) under
+torch autograd.  Each piece is compared with the calls it replaces and with an fp64 restatement; the block-level test compares the whole backward of
+a layer3-shaped block with the switch on and off."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
+BF = torch.bfloat16
+
+
+def _lib():
+    from mvfnet_amd import _lib as L
+    return L.lib, L.check, L.ConvDesc, L.MvfDesc
+
+
+@pytest.mark.parametrize("case", [(2, 14, 14, 256, 1024, 128), (3, 7, 9, 128, 512, 0), (1, 28, 28, 64, 256, 64)], ids=str)
+def test_gated_output_data_gradient_equals_the_plain_one_times_the_bits(case):
+    """mvf_conv2d_nhwc_fwd_resmask_gate: y = (conv + gated residual) * [gate bit] on channels >= res_c0, the channels below untouched --
+    bit for bit the ungated launch followed by the gating; with and without a residual gate."""
+    lib, check, ConvDesc, _ = _lib()
+    n, h, w, cin, cout, c0 = case
+    m = n * h * w
+    gen = torch.Generator().manual_seed(m + cout)
+    x = torch.randn(m, cin, generator=gen).cuda().to(BF)
+    wp = (torch.randn(cout, cin, generator=gen) * 0.05).cuda().to(BF)
+    res = torch.randn(m, cout, generator=gen).cuda().to(BF)
+    rbits = torch.randint(0, 16, (m, cout // 4), generator=gen, dtype=torch.uint8).cuda()
+    gate = torch.randint(0, 16, (m, cout // 4), generator=gen, dtype=torch.uint8).cuda()
+    ws = torch.empty(lib.mvf_conv2d_workspace_bytes(None), dtype=torch.uint8, device="cuda")
+    d = ConvDesc(n, h, w, cin, cout, 1, 1, 1, 0, h, w, cin, 1, 0, 0, 0, 0, c0)
+    for rb in (rbits, None):
+        y0 = torch.empty(m, cout, device="cuda", dtype=BF)
+        y1 = torch.empty_like(y0)
+        check(lib.mvf_conv2d_nhwc_fwd_resmask(C.byref(d), P(x), None, P(wp), None, P(res), P(rb), P(y0), P(ws), ws.numel(), None))
+        check(lib.mvf_conv2d_nhwc_fwd_resmask_gate(C.byref(d), P(x), None, P(wp), None, P(res), P(rb), P(gate), P(y1), P(ws), ws.numel(), None))
+        torch.cuda.synchronize()
+        keep = ((gate.unsqueeze(-1) >> torch.arange(4, device="cuda", dtype=torch.uint8)) & 1).reshape(m, cout).bool()
+        keep[:, :c0] = True
+        want = torch.where(keep, y0, torch.zeros_like(y0))
+        assert torch.equal(want.view(torch.int16), y1.view(torch.int16)), rb is None
+
+
+@pytest.mark.parametrize("case", [(2, 4, 14, 14, 1024, 128), (1, 8, 7, 7, 512, 64)], ids=str)
+def test_gated_output_stencil_equals_the_plain_one_times_the_bits(case):
+    """mvf_nhwc_stencil_gate (the transposed stencil of an MVF block's backward, MVF.py:118-129 under autograd): bit for bit the ungated launch
+    followed by the gating of the slice."""
+    lib, check, _, MvfDesc = _lib()
+    from mvfnet_amd import _lib as L
+    nc, t, h, w, c, cs = case
+    nt, m = nc * t, nc * t * h * w
+    gen = torch.Generator().manual_seed(m)
+    dy = torch.randn(m, cs, generator=gen).cuda().to(BF)
+    add = torch.randn(m, c, generator=gen).cuda().to(BF)
+    abits = torch.randint(0, 16, (m, c // 4), generator=gen, dtype=torch.uint8).cuda()
+    gate = torch.randint(0, 16, (m, c // 4), generator=gen, dtype=torch.uint8).cuda()
+    wt, wh, ww = (torch.randn(cs, 3, generator=gen).cuda() for _ in range(3))
+    d = MvfDesc(nt, c, h, w, t, cs, L.MODE_BITS["THW"], L.MVF_NHWC, L.MVF_BF16)
+    o0 = torch.zeros(m, c, device="cuda", dtype=BF)
+    o1 = torch.zeros_like(o0)
+    check(lib.mvf_nhwc_stencil(C.byref(d), P(dy), cs, P(o0), c, P(wt), P(wh), P(ww), None, None, 1, P(add), c, P(abits), None))
+    check(lib.mvf_nhwc_stencil_gate(C.byref(d), P(dy), cs, P(o1), c, P(wt), P(wh), P(ww), None, None, 1, P(add), c, P(abits), P(gate), None))
+    torch.cuda.synchronize()
+    keep = ((gate.unsqueeze(-1) >> torch.arange(4, device="cuda", dtype=torch.uint8)) & 1).reshape(m, c).bool()[:, :cs]
+    want = torch.where(keep, o0[:, :cs], torch.zeros_like(o0[:, :cs]))
+    assert torch.equal(want.view(torch.int16), o1[:, :cs].contiguous().view(torch.int16))
+    assert torch.count_nonzero(o1[:, cs:]) == 0                      # channels >= cs are not this kernel's
+
+
+@pytest.mark.parametrize("case", [(4 * 14 * 14, 1024, 256), (3 * 7 * 7 + 5, 512, 128), (1000, 2048, 512)], ids=str)
+def test_data_and_weight_gradient_without_dz_match_the_dz_path_and_fp64(case):
+    """mvf_bn_bwd_dzfree_prep + mvf_conv2d_nhwc_dgrad_bnsums_split, and mvf_conv2d_nhwc_wgrad(gm) + gram + mvf_bn_bwd_dzfree_wgrad, against (a) the
+    calls they replace -- mvf_bn_bwd_apply_masked -> dz3 (bf16), then the data gradient with bn2's sums and the weight gradient on dz3 -- and (b) an
+    fp64 restatement of dz3 W / dz3^T a2 on the same bf16 operands.  The dz-free path never rounds dz3, so it must be at least as close to (b) as
+    (a) is, and within bf16 noise of (a)."""
+    lib, check, ConvDesc, _ = _lib()
+    m, c, k = case
+    gen = torch.Generator().manual_seed(m + c)
+    dev = "cuda"
+    a2 = torch.relu(torch.randn(m, k, generator=gen)).to(dev, BF)
+    w = (torch.randn(c, k, generator=gen) * (2.0 / k) ** 0.5).to(dev)            # fp32 master weights [c][k]
+    wp = w.to(BF)                                                                # forward pack of a pointwise conv
+    wd = torch.empty(k, c, device=dev, dtype=BF)
+    check(lib.mvf_pack_conv_weight_dgrad(P(w), c, k, 1, 1, P(wd), 1, None))
+    z3 = (a2.float() @ wp.float().t()).to(BF)
+    g = torch.randn(m, c, generator=gen).to(dev, BF)
+    bits = torch.randint(0, 16, (m, c // 4), generator=gen, dtype=torch.uint8).to(dev)
+    keep = ((bits.unsqueeze(-1) >> torch.arange(4, device=dev, dtype=torch.uint8)) & 1).reshape(m, c).bool()
+    gm = torch.where(keep, g, torch.zeros_like(g))
+    gamma = (torch.rand(c, generator=gen) + 0.5).to(dev)
+    mean = z3.float().mean(0).contiguous()
+    invstd = (1.0 / torch.sqrt(z3.float().var(0, unbiased=False) + 1e-5)).contiguous()
+    z2 = torch.randn(m, k, generator=gen).to(dev, BF)                            # bn2's pre-activation and folded coefficients (for the sums epilogue)
+    sc2, sh2 = (torch.rand(k, generator=gen) + 0.5).to(dev), (torch.randn(k, generator=gen) * 0.2).to(dev)
+    mu2, rs2 = (torch.randn(k, generator=gen) * 0.3).to(dev), (torch.rand(k, generator=gen) + 0.4).to(dev)
+    ws_bn = torch.empty(lib.mvf_bn_workspace_bytes(m, c), dtype=torch.uint8, device=dev)
+    dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    check(lib.mvf_bn_bwd_reduce(P(gm), c, P(z3), None, m, c, P(mean), P(invstd), None, None, 0, None, P(dg), P(db), P(ws_bn), ws_bn.numel(), 1, None))
+    # (a) the dz path
+    dz = torch.empty(m, c, device=dev, dtype=BF)
+    check(lib.mvf_bn_bwd_apply_masked(P(gm), c, P(z3), None, m, c, P(gamma), P(mean), P(invstd), None, None, P(dg), P(db), 0, P(dz), 1, None))
+    ws = torch.empty(lib.mvf_conv2d_workspace_bytes(None), dtype=torch.uint8, device=dev)
+    n_img = 1
+    d1 = ConvDesc(n_img, m, 1, c, k, 1, 1, 1, 0, m, 1, c, 1, 0, 0, 0, 0, 0)       # an m x 1 "image": pointwise, any m
+    rows = lib.mvf_conv2d_stats_rows(C.byref(d1))
+    part_a = torch.empty(k, rows, 2, device=dev)
+    da_a = torch.empty(m, k, device=dev, dtype=BF)
+    check(lib.mvf_conv2d_nhwc_dgrad_bnsums(C.byref(d1), P(dz), P(wd), P(da_a), P(z2), P(mu2), P(rs2), P(sc2), P(sh2), P(part_a), P(ws), ws.numel(), None))
+    dwd = ConvDesc(n_img, m, 1, k, c, 1, 1, 1, 0, m, 1, k, 1, 0, 0, 0, 0, 0)
+    wsw = torch.empty(max(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(dwd)), 1 << 20), dtype=torch.uint8, device=dev)
+    dw_a = torch.empty(c, k, device=dev)
+    check(lib.mvf_conv2d_nhwc_wgrad(C.byref(dwd), P(dz), P(a2), None, 1, k, 1, k, P(dw_a), P(wsw), wsw.numel(), None))
+    # (new) without dz
+    bd = torch.empty(k, c + k, device=dev, dtype=BF)
+    bias = torch.empty(k, device=dev)
+    check(lib.mvf_bn_bwd_dzfree_prep(P(wd), c, k, P(gamma), P(mean), P(invstd), P(dg), P(db), m, P(bd), P(bias), 1, None))
+    d2 = ConvDesc(n_img, m, 1, c + k, k, 1, 1, 1, 0, m, 1, k, 1, 0, c, c, 0, 0, c)
+    assert lib.mvf_conv2d_stats_rows(C.byref(d2)) == rows
+    part_n = torch.empty(k, rows, 2, device=dev)
+    da_n = torch.empty(m, k, device=dev, dtype=BF)
+    check(lib.mvf_conv2d_nhwc_dgrad_bnsums_split(C.byref(d2), P(a2), P(gm), P(bd), P(bias), P(da_n), P(z2), P(mu2), P(rs2), P(sc2), P(sh2), P(part_n),
+                                                 P(ws), ws.numel(), None))
+    dw_n = torch.empty(c, k, device=dev)
+    check(lib.mvf_conv2d_nhwc_wgrad(C.byref(dwd), P(gm), P(a2), None, 1, k, 1, k, P(dw_n), P(wsw), wsw.numel(), None))
+    dgr = ConvDesc(n_img, m, 1, k, k, 1, 1, 1, 0, m, 1, k, 1, 0, 0, 0, 0, 0)
+    wsg = torch.empty(max(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(dgr)), 1 << 20), dtype=torch.uint8, device=dev)
+    gram = torch.empty(k, k, device=dev)
+    check(lib.mvf_conv2d_nhwc_wgrad(C.byref(dgr), P(a2), P(a2), None, 1, k, 1, k, P(gram), P(wsg), wsg.numel(), None))
+    amean = a2.float().mean(0).contiguous()
+    check(lib.mvf_bn_bwd_dzfree_wgrad(P(dw_n), P(wp), P(gram), P(amean), P(gamma), P(mean), P(invstd), P(dg), P(db), m, c, k, 1, None))
+    torch.cuda.synchronize()
+    # (b) fp64 on the same operands
+    a = (gamma * invstd).double()
+    dz64 = a * (gm.double() - db.double() / m - (z3.double() - mean.double()) * (invstd.double() * dg.double() / m))
+    da64 = dz64 @ wp.double()
+    dw64 = dz64.t() @ a2.double()
+    ea, en = rel_l2(da_a.float().cpu().numpy(), da64.cpu().numpy()), rel_l2(da_n.float().cpu().numpy(), da64.cpu().numpy())
+    wa, wn = rel_l2(dw_a.cpu().numpy(), dw64.cpu().numpy()), rel_l2(dw_n.cpu().numpy(), dw64.cpu().numpy())
+    print("case %s: data gradient vs fp64: dz path %.2e, without dz %.2e; weight gradient: %.2e / %.2e" % (case, ea, en, wa, wn))
+    assert en < 6e-3 and en < 1.5 * ea + 1e-3, (ea, en)
+    assert wn < 6e-3 and wn < 1.5 * wa + 1e-3, (wa, wn)
+    assert rel_l2(da_n.float().cpu().numpy(), da_a.float().cpu().numpy()) < 1e-2
+    # bn2's sums of the two data gradients (finalised): to the bf16 noise of da itself
+    fa, fn = [torch.empty(k, device=dev) for _ in range(2)], [torch.empty(k, device=dev) for _ in range(2)]
+    check(lib.mvf_bn_bwd_finalize(P(part_a), rows, k, P(fa[0]), P(fa[1]), None))
+    check(lib.mvf_bn_bwd_finalize(P(part_n), rows, k, P(fn[0]), P(fn[1]), None))
+    torch.cuda.synchronize()
+    for u, v in zip(fa, fn):
+        assert rel_l2(v.cpu().numpy(), u.cpu().numpy()) < 2e-2
+
+
+@pytest.mark.parametrize("shape", [(1024, 256, 14, True), (1024, 256, 14, False), (2048, 512, 7, True)], ids=str)
+def test_block_backward_without_dz3_matches_the_dz3_path(shape):
+    """A layer3 / layer4-shaped plain bottleneck (with and without the MVF in front of conv1) through BlockTrainer in bf16 with eng.dzfree = 0 / 2:
+    identical forward, dx and every parameter gradient within bf16 noise of each other."""
+    from mvfnet_amd.backbones.resnet import Bottleneck
+    from mvfnet_amd.modules.MVF import MVF
+    from mvfnet_amd.train_engine import BlockTrainer
+    cin, planes, hw, with_mvf = shape
+    res = {}
+    for mode in (0, 2):
+        torch.manual_seed(5)
+        blk = Bottleneck(cin, planes)
+        if with_mvf:
+            blk.conv1 = MVF(blk.conv1, 4, cin, 0.125)
+        blk = blk.cuda().train()
+        with torch.no_grad():
+            for bn in (blk.bn1, blk.bn2, blk.bn3):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0, 0.2)
+        tr = BlockTrainer(blk, dtype=torch.bfloat16)
+        tr.dzfree = mode
+        assert tr.blk.dzfree(tr, 8 * hw * hw) == bool(mode)
+        x = torch.relu(torch.randn(8, cin, hw, hw, device="cuda"))
+        dy = torch.randn(8, cin, hw, hw, device="cuda")
+        y = tr.forward(x).float().clone()
+        dx = tr.backward(dy).float().clone()
+        torch.cuda.synchronize()
+        names = [n for n, _ in blk.named_parameters()]
+        res[mode] = (y, dx, {n: tr.grad_of(p).clone() for n, p in blk.named_parameters()}, names)
+    assert torch.equal(res[0][0], res[2][0])
+    e_dx = rel_l2(res[2][1].cpu().numpy(), res[0][1].cpu().numpy())
+    worst = max((rel_l2(res[2][2][n].cpu().numpy(), res[0][2][n].cpu().numpy()), n) for n in res[0][3])
+    print("shape %s: dx %.2e, worst parameter gradient %.2e (%s)" % (shape, e_dx, worst[0], worst[1]))
+    assert e_dx < 1e-2 and worst[0] < 1.5e-2, (e_dx, worst)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 14, 14, 1024, 128, BF), (1, 4, 28, 28, 512, 64, BF), (3, 4, 7, 7, 2048, 256, BF), (2, 4, 9, 11, 64, 8, torch.float32)], ids=str)
+def test_stencil_with_fused_statistics_equals_stencil_plus_statistics_pass(case):
+    """[r5] mvf_nhwc_stencil_stats (MVF.forward in training, MVF.py:118-134: the three views' sum, then BatchNorm3d on batch statistics): y bit for
+    bit mvf_nhwc_stencil's, and mean / invstd / scale / shift / running statistics from its per-workgroup partial sums equal to
+    mvf_bn_train_stats' on the stored y (fp32 summation order)."""
+    lib, check, _, MvfDesc = _lib()
+    from mvfnet_amd import _lib as L
+    nc, t, h, w, c, cs, dt = case
+    nt, m = nc * t, nc * t * h * w
+    dtc = L.MVF_BF16 if dt == BF else L.MVF_F32
+    gen = torch.Generator().manual_seed(m + c)
+    x = (torch.randn(m, c, generator=gen) * 1.3 + 0.2).cuda().to(dt)
+    wt, wh, ww = (torch.randn(cs, 3, generator=gen).cuda() for _ in range(3))
+    gamma, beta = (torch.rand(cs, generator=gen) + 0.5).cuda(), (torch.randn(cs, generator=gen) * 0.2).cuda()
+    d = MvfDesc(nt, c, h, w, t, cs, L.MODE_BITS["THW"], L.MVF_NHWC, dtc)
+    out = {}
+    for fused in (False, True):
+        rm, rv = (torch.randn(cs, generator=torch.Generator().manual_seed(1)) * 0.1).cuda(), (torch.rand(cs, generator=torch.Generator().manual_seed(2)) + 0.5).cuda()
+        y = torch.zeros(m, cs, device="cuda", dtype=dt)
+        st = [torch.empty(cs, device="cuda") for _ in range(4)]
+        if fused:
+            rows = lib.mvf_nhwc_stencil_stats_rows(C.byref(d), c, cs)
+            assert rows > 0
+            part = torch.full((cs, rows, 2), float("nan"), device="cuda")
+            check(lib.mvf_nhwc_stencil_stats(C.byref(d), P(x), c, P(y), cs, P(wt), P(wh), P(ww), P(part), P(rm), None))
+            check(lib.mvf_bn_train_finalize(P(part), rows, m, cs, P(gamma), P(beta), C.c_float(1e-5), C.c_float(0.1), P(rm), P(rv), P(st[0]), P(st[1]), P(st[2]), P(st[3]), None))
+        else:
+            check(lib.mvf_nhwc_stencil(C.byref(d), P(x), c, P(y), cs, P(wt), P(wh), P(ww), None, None, 0, None, 0, None, None))
+            ws = torch.empty(lib.mvf_bn_workspace_bytes(m, cs), dtype=torch.uint8, device="cuda")
+            check(lib.mvf_bn_train_stats(P(y), m, cs, P(gamma), P(beta), C.c_float(1e-5), C.c_float(0.1), P(rm), P(rv), P(st[0]), P(st[1]), P(st[2]), P(st[3]), P(ws), ws.numel(),
+                                         dtc, None))
+        torch.cuda.synchronize()
+        out[fused] = (y, st, rm, rv)
+    assert torch.equal(out[True][0], out[False][0])
+    for a, b in zip(out[True][1] + [out[True][2], out[True][3]], out[False][1] + [out[False][2], out[False][3]]):
+        assert torch.isfinite(a).all() and rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6

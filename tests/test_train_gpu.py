@@ -1033,6 +1033,20 @@ def test_engine_switch_variants_reproduce_the_default_step(dtype):
         assert got[0] == ref[0] and torch.equal(got[1], ref[1])
     else:
         assert abs(got[0][0] - ref[0][0]) < 1e-2 * abs(ref[0][0]) and rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < 1e-2
+    # [r5] dzfree: bn3's backward of the plain blocks of layer2 ... layer4 without the dz3 tensor (csrc/bn_dzfree.hip; bf16 only, a no-op in fp32): the same
+    # forward (loss bit for bit); dz3 is no longer rounded to bf16 on its way into the two GEMMs, a.W and G are instead -- parameters to bf16 noise.
+    # gate_producer=False: the dz3-free blocks' own sums pass writes gm instead of the block above gating what it hands down -- the same gm bit for bit.
+    got, ref = run(steps=1, dzfree=0), run(steps=1)
+    assert got[0] == ref[0]
+    if dtype == torch.float32:
+        assert torch.equal(got[1], ref[1])
+    else:
+        assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < 1e-2
+    got = run(steps=1, gate_producer=False)
+    assert got[0] == ref[0] and torch.equal(got[1], ref[1])
+    got = run(steps=1, fuse_mvf_stats=False)            # [r5] MVF's BatchNorm statistics from a pass over y instead of the stencil launch: fp32 summation order
+    assert abs(got[0][0] - ref[0][0]) < (1e-6 if dtype == torch.float32 else 1e-2) * abs(ref[0][0])
+    assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-3 if dtype == torch.float32 else 1e-2)      # (batch statistics in another summation order, amplified by the 2-clip network)
     # one step only: the 2-clip batch-statistics network amplifies last-bit differences by orders of magnitude per step
     got, ref = run(steps=1, fuse_stem_bwd=0), run(steps=1)
     tol = 1e-5 if dtype == torch.float32 else 1e-3          # bf16: the stem's dz is re-rounded from sums that differ in the last bits

@@ -40,7 +40,7 @@ def bench_conv(dt=1, only=None):
     shapes = [("l1.c3 fwd", 56, 64, 256, 1, "stats"), ("l1.c1 fwd", 56, 256, 64, 1, "stats"), ("l1.c1 dgrad", 56, 64, 256, 1, "res"),
               ("l1.c3 dgrad", 56, 256, 64, 1, "bnb"), ("l2.c3 fwd", 28, 128, 512, 1, "stats"), ("l2.c1 dgrad", 28, 128, 512, 1, "res"),
               ("l3.c3 fwd", 14, 256, 1024, 1, "stats"), ("l3.c1 fwd", 14, 1024, 256, 1, "stats"), ("l3.c1 dgrad", 14, 256, 1024, 1, "res"),
-              ("l3.c3 dgrad", 14, 1024, 256, 1, "bnb"), ("l3.c2 fwd", 14, 256, 256, 3, "stats"), ("l3.c2 dgrad", 14, 256, 256, 3, "bnb"),
+              ("l3.c3 dgrad", 14, 1024, 256, 1, "bnb"), ("l3.c1 dgrad+sums (proxy)", 14, 256, 1024, 1, "bnb"), ("l3.c2 fwd", 14, 256, 256, 3, "stats"), ("l3.c2 dgrad", 14, 256, 256, 3, "bnb"),
               ("l4.c3 fwd", 7, 512, 2048, 1, "stats"), ("l2.c2 fwd", 28, 128, 128, 3, "stats"), ("l1.c2 fwd", 56, 64, 64, 3, "stats"),
               ("l1.c3 apply", 56, 64, 256, 1, "infer_res"), ("l2.c3 apply", 28, 128, 512, 1, "infer_res"), ("l3.c3 apply", 14, 256, 1024, 1, "infer_res"),
               ("l4.c3 apply", 7, 512, 2048, 1, "infer_res"), ("l3.c3 plain", 14, 256, 1024, 1, "plain"), ("l2.c3 plain", 28, 128, 512, 1, "plain"),
