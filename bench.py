@@ -231,7 +231,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
     def dbs1(self, out, m, a_in, a_pitch, g, bits, bn, part, ns):      # [r4] conv3 again + bn3 backward sums on the one-branch form of pw_sums_pair
         return (2.0 * m * self.cout * self.cin, "bwd-sums M%d N%d K%d" % (m, self.cout, self.cin), esz * (m * self.cin + m * self.cout + self.w.numel()) + m * self.cout // 4)
 
-    def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None, out_gate=None):
+    def ddgr(self, out, dz, n, ho, wo, h, w, residual=None, res_c0=0, res_bits=None, out_gate=None, gsum=None):
         fl = 2.0 * n * ho * wo * self.cout * self.kh * self.kw * self.cin          # algorithmic = the forward conv's MACs
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * self.cin * (2 if residual is not None else 1) + self.w.numel())
         return (fl, "dgrad M%d N%d K%d s%d" % (n * h * w, self.cin, self.kh * self.kw * self.cout, self.stride), nbytes)
@@ -278,7 +278,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         nb = esz * m * self.c * 8 + 2 * (m * self.c // 4) + nx * (esz * m * conv_a.cin + 4 * conv_a.w.numel())
         return (2.0 * nx * m * self.c * conv_a.cin, "bn bwd pair + %d wgrad M%d C%d K%d" % (nx, m, self.c, conv_a.cin), nb)
 
-    def dmvf(self, out, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits, out_gate=None):
+    def dmvf(self, out, d, src, src_c, dst, dst_c, flip, addend, addend_c, addend_bits, out_gate=None, gsum=None):
         m = d.nt * d.h * d.w
         nb = esz * m * d.cs * (3 if addend is not None else 2)          # slice read + slice write (+ the gated skip-connection slice)
         taps = 3 * bin(d.mode).count("1")

@@ -169,6 +169,13 @@ int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const v
 int mvf_conv2d_nhwc_fwd_resmask_gate(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                                      const void* residual, const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y,
                                      void* ws, size_t ws_bytes, void* stream);
+/* [r5] ... and the BatchNorm-backward sums of the gated output in the same epilogue: with gm = y (as stored) on channels >= d->res_c0, sums_part
+ * CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] = per-128-row column sums of gm and gm * (bn_z - bn_mean) * bn_invstd, bn_z = the stored input of the
+ * BatchNorm whose output gradient y is (bn3 of the block below, resnet.py:236-244) -> mvf_bn_bwd_finalize on the channel range [res_c0, cout): that block's
+ * sums pass over (gm, z3) disappears.  (Channels below res_c0 get meaningless partial rows: finalize the range only.) */
+int mvf_conv2d_nhwc_fwd_resmask_gate_sums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* residual,
+                                          const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y, const void* bn_z,
+                                          const float* bn_mean, const float* bn_invstd, float* sums_part, void* ws, size_t ws_bytes, void* stream);
 /* Stride-1 data gradient whose output da feeds the backward of a = ReLU(BN(z)): besides y = dgrad(dz) it accumulates that
  * BatchNorm's backward sums in the epilogue -- sums_part, CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] = per-128-row column sums of gm and
  * gm * xhat with gm = y * [bn_scale*z + bn_shift > 0], xhat = (z - bn_mean) * bn_invstd (z: the forward conv output the BN
@@ -405,6 +412,13 @@ int mvf_nhwc_stencil_gate(const mvf_desc_t* d, const void* x, int x_c, void* out
                           const float* w_h, const float* w_w, const float* scale, const float* shift, int flip,
                           const void* addend, int addend_c, const unsigned char* addend_sign_bits,
                           const unsigned char* out_gate_bits, void* stream);
+/* [r5] mvf_nhwc_stencil_gate + the BatchNorm-backward sums of the gated slice: sums_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] =
+ * per-workgroup sums of gm and gm * (bn_z - bn_mean) * bn_invstd (bn_z pitch out_c) -> mvf_bn_bwd_finalize: the slice's share of
+ * mvf_conv2d_nhwc_fwd_resmask_gate_sums. */
+int mvf_nhwc_stencil_gate_sums(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
+                               const float* w_w, int flip, const void* addend, int addend_c, const unsigned char* addend_sign_bits,
+                               const unsigned char* out_gate_bits, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sums_part,
+                               void* stream);
 /* [r5] the plain stencil (no activation) that also accumulates the batch statistics of MVF's BatchNorm3d (MVF.py:131-134, training mode) over the
  * values it stores: stats_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] = per-workgroup sums of (y - K), (y - K)^2, K =
  * stats_shift (the old running mean; NULL = 0) -> mvf_bn_train_finalize.  Replaces the statistics pass over y. */

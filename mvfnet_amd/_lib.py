@@ -85,6 +85,10 @@ def _load():
     i64_ = C.c_long
     lib.mvf_conv2d_nhwc_fwd_resmask_gate.restype = i32
     lib.mvf_conv2d_nhwc_fwd_resmask_gate.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, vp, vp, sz, vp]
+    lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums.restype = i32
+    lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums.argtypes = [cp, vp, vp, vp, vp, vp, vp, vp, vp, fp, fp, fp, vp, sz, vp]
+    lib.mvf_nhwc_stencil_gate_sums.restype = i32
+    lib.mvf_nhwc_stencil_gate_sums.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, i32, vp, i32, vp, vp, vp, fp, fp, fp, vp]
     lib.mvf_conv2d_nhwc_dgrad_bnsums_split.restype = i32
     lib.mvf_conv2d_nhwc_dgrad_bnsums_split.argtypes = [cp, vp, vp, vp, fp, vp, vp, fp, fp, fp, fp, fp, vp, sz, vp]
     lib.mvf_bn_bwd_dzfree_prep.restype = i32

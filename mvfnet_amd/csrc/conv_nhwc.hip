@@ -55,6 +55,10 @@ struct ConvArgs {
     // [r5] optional [M][Cout/4] bytes in the same layout: the OUTPUT (accumulator + residual) of channels >= res_c0 is gated by them before the
     // store -- the data gradient then hands the block below gm = g * [out > 0] instead of g + sign bits (mvf_conv2d_nhwc_fwd_resmask_gate)
     const unsigned char* out_gate;
+    // [r5] EPI 11 = EPI 3 (data gradient + gated residual) + the output gate + the BatchNorm-backward sums of the bn3 the gated output belongs to: per-128-row
+    // column sums of gm (the stored, gated output) and gm * (gs_z - gs_mean) * gs_invstd into stats_part; gs_z = that BatchNorm's stored input (the output's shape)
+    const char* gs_z;
+    const float *gs_mean, *gs_invstd;
     int x_c0;      // [r5] split operand: x holds channels [split_c, Cin) of the contraction at column (channel - x_c0) of its rows (0: at their own offset)
     int mask_lds;  // stage the gate bytes in LDS (experiment switch MVF_MASK_LDS=0)
     int prio;      // experiment switch MVF_CONV_PRIO=1: raise the wave priority around the MFMA phase of the LDS-DMA loops; in
@@ -1032,7 +1036,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
     // residual loads.
     const bool e_bias = EPI == 0 ? a.bias != nullptr : (EPI == 4 || EPI == 5 || (EPI == 6 && a.bias != nullptr));   // ([r5] EPI 6 + bias: mvf_conv2d_nhwc_dgrad_bnsums_split)
-    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8 || EPI == 9 || EPI == 10);
+    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8 || EPI == 9 || EPI == 10 || EPI == 11);
+    constexpr bool e_gs = EPI == 11;                     // [r5] gated output + the BatchNorm-backward sums of the block below
     constexpr bool e_bw = EPI == 9 || EPI == 10;         // BatchNorm backward on the recomputed conv output (g and its sign-bit gate arrive as the residual operand)
     const bool e_relu = EPI == 0 ? a.relu != 0 : (EPI == 4 || EPI == 5);
     constexpr bool e_apply = EPI == 8;                   // BatchNorm apply + residual + ReLU + sign bits on the rounded accumulators
@@ -1063,6 +1068,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         if (a.ap_rscale) { ap_rs = *reinterpret_cast<const float4*>(a.ap_rscale + col); ap_rb = *reinterpret_cast<const float4*>(a.ap_rshift + col); }
     }
     float4 b_mu = st1, b_rs = st1, b_sc = st1, b_sh = st1;
+    if (e_gs && col < a.Cout) { b_mu = *reinterpret_cast<const float4*>(a.gs_mean + col); b_rs = *reinterpret_cast<const float4*>(a.gs_invstd + col); }
     if (e_bnb && col < a.Cout) {
         b_mu = *reinterpret_cast<const float4*>(a.bn_mean + col); b_rs = *reinterpret_cast<const float4*>(a.bn_invstd + col);
         b_sc = *reinterpret_cast<const float4*>(a.bn_scale + col); b_sh = *reinterpret_cast<const float4*>(a.bn_shift + col);
@@ -1102,6 +1108,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         (void*)(a.out_gate ? a.out_gate + (long)m0 * (a.Cout / 4) : (const unsigned char*)a.y), 0,
         (unsigned)min((long)(a.M - m0) * (a.Cout / 4), 0x7ffffff0L), 0x00020000);
     const bool e_gate = e_res && !e_apply && !e_bw && a.out_gate != nullptr;
+    __amdgpu_buffer_rsrc_t rs_gz = rs_gate;
+    if constexpr (e_gs) {
+        const long base = (long)m0 * a.Cout * ESZ, left = (long)a.M * a.Cout * ESZ - base;
+        rs_gz = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gs_z + base), 0, (unsigned)(left < 0x7ffffff0L ? left : 0x7ffffff0L), 0x00020000);
+    }
     (void)y; (void)res;
     // The tile's gate bytes (BM rows x BN/4) are staged in LDS behind the C tile with ONE 16-byte load per thread (instead of a
     // byte load per thread per row, which made the gated data gradient 35 % slower than the ungated one); visible after the
@@ -1286,6 +1297,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         typedef typename std::conditional<sizeof(ET) == 2, u32x2, u32x4>::type raw_t;
         unsigned offs[NPS];
         raw_t rraw[NPS];
+        raw_t gzraw[e_gs ? NPS : 1];
+        (void)gzraw;
         {
             const int mrow0 = m0 + hf * HR + r0;
             const bool cok2 = col < a.Cout;              // Cout % 4 == 0 (checked on the host)
@@ -1305,6 +1318,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     const unsigned roff = (e_bnb || col >= a.res_c0) ? offs[ps] : kOOB;       // skipped columns read zeros
                     if constexpr (sizeof(ET) == 2) rraw[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, roff, 0, 0);
                     else rraw[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0);
+                }
+                if constexpr (e_gs) {
+                    if constexpr (sizeof(ET) == 2) gzraw[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_gz, offs[ps], 0, 0);
+                    else gzraw[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_gz, offs[ps], 0, 0);
                 }
             }
         }
@@ -1393,6 +1410,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     pk.x = __float_as_uint(v.x); pk.y = __float_as_uint(v.y); pk.z = __float_as_uint(v.z); pk.w = __float_as_uint(v.w);
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, off, 0, 0);
                 }
+                if constexpr (e_gs) {                // v = the stored (rounded, gated) gradient gm; z = the block below's stored z3
+                    const float4 zv = unpack(gzraw[ps]);
+                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    st1.x += v.x; st1.y += v.y; st1.z += v.z; st1.w += v.w;
+                    st2.x += v.x * ((zv.x - b_mu.x) * b_rs.x); st2.y += v.y * ((zv.y - b_mu.y) * b_rs.y);
+                    st2.z += v.z * ((zv.z - b_mu.z) * b_rs.z); st2.w += v.w * ((zv.w - b_mu.w) * b_rs.w);
+                }
                 if constexpr (e_bnb) {               // v = the stored (rounded) gradient; z was fetched in phase A
                     const float4 zv = unpack(rraw[ps]);
                     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1410,7 +1434,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 }
             }
         }
-        if ((e_stats || e_bnb || EPI == 10) && (hf + 1) % HPP == 0) {   // column sums over the RPP row-threads, fixed order, one writer per column
+        if ((e_stats || e_bnb || EPI == 10 || e_gs) && (hf + 1) % HPP == 0) {   // column sums over the RPP row-threads, fixed order, one writer per column
             __syncthreads();
             float4* red = reinterpret_cast<float4*>(smem);
             red[(r0 * 2 + 0) * TPR + cq] = st1;
@@ -1782,6 +1806,7 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     shift[i] = beta[i] - mean[i] * s;
 }
 
+static inline bool contiguous_ok(const ConvArgs& a) { return a.o_s <= 0; }
 struct SkHost {
     void* ws;
     size_t ws_bytes;
@@ -1928,11 +1953,11 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
-    if (a.bn_z || a.ap_scale || a.bw_mode) sk_wins = false;   // the BatchNorm-backward / BatchNorm-apply epilogues live in the single-buffer kernels only
+    if (a.bn_z || a.ap_scale || a.bw_mode || a.gs_z) sk_wins = false;   // the BatchNorm-backward / BatchNorm-apply epilogues live in the single-buffer kernels only
     // fp32 on the bf16 matrix cores: the single-buffer register-staged kernel carries it (x3_on)
     const bool x3 = sizeof(ET) == 4 && x3_on(a);
     if (x3) sk_wins = false;
-    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale || a.bw_mode || x3) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
+    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale || a.bw_mode || a.gs_z || x3) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();
         static const int epi_spec = getenv("MVF_CONV_EPI") ? atoi(getenv("MVF_CONV_EPI")) : 3;     // A/B switch: bit 0 epilogues, bit 1 pointwise loader
         const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
@@ -1940,6 +1965,22 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         const bool train_like = contiguous && !a.bias && !a.relu;
         const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
         const bool bnsum_epi = (epi_spec & 1) && a.bn_z && !a.relu && !a.res;      // contiguous or a scattered parity class ([r5] + an optional bias)
+        if (a.gs_z) {        // [r5] EPI 11: on the register-staged single-buffer kernel (3 workgroups per CU: the sums' registers spill under the 4-per-CU bound)
+            MVF_REQUIRE(contiguous_ok(a) && a.res && a.out_gate && a.stats_part && !a.bias && !a.relu && !a.bn_z && !a.ap_scale && !a.bw_mode, MVF_EINVAL,
+                        "conv2d gated output + sums: needs a residual, the gate bits, a partial buffer and a contiguous bf16 / fp32 output");
+            static const int gs_glds = getenv("MVF_GSUM_GLDS") ? atoi(getenv("MVF_GSUM_GLDS")) : 0;     // A/B: 1 = the single-buffer LDS-DMA kernel (4 workgroups per CU) up to 8 chunks
+            if constexpr (sizeof(ET) == 2) {
+                if (gs_glds && a.nchunks <= 8) {
+                    const int rc = launch_glds<ET, WM, WN, TM, TN, 11>(1, tiles, st, a);
+                    if (rc != MVF_OK) return rc;
+                    MVF_LAUNCH_CHECK();
+                    return MVF_OK;
+                }
+            }
+            launch_lowk<ET, WM, WN, TM, TN, 11>(pw, tiles, lds_lk, st, a);
+            MVF_LAUNCH_CHECK();
+            return MVF_OK;
+        }
         // long K, wide output: the 256 x 128 LDS-DMA tile (MVF_CONV_BIG = <min chunks>, 0 = off)
         if (BN == 128 && sizeof(ET) == 2 && g_big2_min > 0 && a.nchunks >= g_big2_min && a.Cout % 256 == 0 && a.o_s <= 0 && !a.ap_scale && !a.bw_mode) {
             const long t2 = (long)((a.M + 255) / 256) * (a.Cout / 256);
@@ -2099,6 +2140,10 @@ struct BnBwdRecompute {       // optional: BatchNorm backward on the recomputed 
     int mode;                 // 9 apply (y = dz), 10 sums (stats_part)
     const float *mean, *invstd, *gamma, *dgamma, *dbeta;
 };
+struct GatedSums {            // optional ([r5], with out_gate): the BatchNorm-backward sums of the gated output (see ConvArgs::gs_z)
+    const void* z;
+    const float *mean, *invstd;
+};
 struct BnApply {              // optional: the epilogue applies a BatchNorm + residual + ReLU and writes the sign bits (see ConvArgs::ap_scale)
     const float *scale, *shift, *rscale, *rshift;
     unsigned char* bits;
@@ -2106,7 +2151,7 @@ struct BnApply {              // optional: the epilogue applies a BatchNorm + re
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
                          void* stream, const unsigned char* res_mask = nullptr, const BnBwdSums* bnb = nullptr, const MvfFuse* mf = nullptr,
-                         const BnApply* ap = nullptr, const BnBwdRecompute* bw = nullptr, const unsigned char* out_gate = nullptr);
+                         const BnApply* ap = nullptr, const BnBwdRecompute* bw = nullptr, const unsigned char* out_gate = nullptr, const GatedSums* gs = nullptr);
 
 int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void* w_packed, const float* bias, const float* mvf_coef,
                             int cs, int n_segment, int act, void* y, void* ws, size_t ws_bytes, void* stream) {
@@ -2176,6 +2221,16 @@ int mvf_conv2d_nhwc_fwd_resmask_gate(const mvf_conv_desc_t* d, const void* x, co
     return conv_fwd_impl(d, x, x2, w_packed, bias, residual, y, nullptr, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits);
 }
 
+int mvf_conv2d_nhwc_fwd_resmask_gate_sums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* residual,
+                                          const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y, const void* bn_z,
+                                          const float* bn_mean, const float* bn_invstd, float* sums_part, void* ws, size_t ws_bytes, void* stream) {
+    MVF_REQUIRE(d && residual && out_gate_bits && bn_z && bn_mean && bn_invstd && sums_part && d->in_dil <= 1 && !d->relu, MVF_EINVAL,
+                "conv2d_resmask_gate_sums: needs a residual, the gate bits, the BatchNorm's input / mean / invstd, a partial buffer and a stride-1 launch without ReLU");
+    MVF_REQUIRE(((uintptr_t)bn_mean | (uintptr_t)bn_invstd | (uintptr_t)bn_z) % 16 == 0, MVF_EINVAL, "conv2d_resmask_gate_sums: bn_z / bn_mean / bn_invstd must be 16-byte aligned");
+    const GatedSums gs = {bn_z, bn_mean, bn_invstd};
+    return conv_fwd_impl(d, x, x2, w_packed, nullptr, residual, y, sums_part, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits, &gs);
+}
+
 int mvf_conv2d_nhwc_dgrad_bnsums_split(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias, void* y,
                                        const void* bn_z, const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_shift,
                                        float* sums_part, void* ws, size_t ws_bytes, void* stream) {
@@ -2214,7 +2269,7 @@ int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const voi
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
                          void* stream, const unsigned char* res_mask, const BnBwdSums* bnb, const MvfFuse* mf, const BnApply* ap, const BnBwdRecompute* bw,
-                         const unsigned char* out_gate) {
+                         const unsigned char* out_gate, const GatedSums* gs) {
     MVF_REQUIRE(d && x && w_packed && (y || (stats_part && !bnb)), MVF_EINVAL, "conv2d: NULL argument");      // (y may be NULL for a statistics-only pass)
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -2249,6 +2304,7 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     a.res_c0 = d->res_c0 > 0 ? d->res_c0 : 0;
     a.res_mask = res_mask;
     a.out_gate = out_gate;
+    if (gs) { a.gs_z = (const char*)gs->z; a.gs_mean = gs->mean; a.gs_invstd = gs->invstd; }
     MVF_REQUIRE(d->x_c0 == 0 || (d->split_c > 0 && d->x_c0 > 0 && d->x_c0 <= d->split_c && d->x_c0 % ue == 0 && d->x_pix_stride >= d->cin - d->x_c0), MVF_EINVAL,
                 "conv2d: x_c0=%d needs a split operand (split_c=%d), 0 < x_c0 <= split_c, a multiple of %d, and x rows of >= cin - x_c0 channels", d->x_c0, d->split_c, ue);
     a.x_c0 = d->x_c0;

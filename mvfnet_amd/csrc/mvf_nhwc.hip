@@ -40,6 +40,8 @@ struct NhwcArgs {
     int add_c;
     const unsigned char* add_mask;   // optional gate bits of the addend: [pixels][add_c/4] bytes, bit j of byte k = channel 4k+j
     float* stats_part;               // [r5] optional (chunked kernel): CHANNEL-MAJOR [cs][gridDim.x][2] column sums of (y - K), (y - K)^2 over the workgroup's outputs AS STORED
+    const void* gs_z;                // [r5] with stats_part and out_gate: the sums become the BatchNorm-backward sums of the gated output -- sum gm, sum gm (gs_z - gs_mean) gs_invstd,
+    const float *gs_mean, *gs_invstd;     //      gs_z = that BatchNorm's stored input (pitch out_c), as mvf_conv2d_nhwc_fwd_resmask_gate_sums does for the channels >= cs
     const float* stats_shift;        //      K per channel (the BatchNorm's old running mean; NULL = 0): the statistics pass of MVF's BatchNorm3d without a pass over y
     const unsigned char* out_gate;   // [r5] optional gate bits of the OUTPUT (after the addend): [pixels][out_c/4] bytes, same layout (VEC = 4 kernels only)
     int tsplit;    // 1: one frame per workgroup (grid.z = T) instead of sliding along t -- 7 loads, one round trip, T x the threads
@@ -173,9 +175,14 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
     const bool vh = a.mode & MVF_VIEW_H, vw = a.mode & MVF_VIEW_W;
     const bool hs = a.scale != nullptr;
     float wt[VEC][3], wh[VEC][3], ww[VEC][3], sc[VEC], sh[VEC];
-    float st1[VEC], st2[VEC], kk[VEC];
+    float st1[VEC], st2[VEC], kk[VEC], gmu[VEC], grs[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { st1[i] = st2[i] = 0.f; kk[i] = (a.stats_part && a.stats_shift) ? a.stats_shift[c0 + i] : 0.f; }
+    for (int i = 0; i < VEC; ++i) {
+        st1[i] = st2[i] = 0.f;
+        kk[i] = (a.stats_part && a.stats_shift) ? a.stats_shift[c0 + i] : 0.f;
+        gmu[i] = a.gs_z ? a.gs_mean[c0 + i] : 0.f;
+        grs[i] = a.gs_z ? a.gs_invstd[c0 + i] : 0.f;
+    }
     {
         auto load12 = [&](const float* p, bool on, float (&dst)[VEC][3]) {
             float f[12];
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
         const bool ok_up = vh && hh > 0, ok_dn = vh && hh < H - 1, ok_lf = vw && wv > 0, ok_rt = vw && wv < W - 1;
         const long d_up = ok_up ? -(long)W * C : 0, d_dn = ok_dn ? (long)W * C : 0, d_lf = ok_lf ? -(long)C : 0, d_rt = ok_rt ? (long)C : 0;
         for (int t0 = 0; t0 < T; t0 += TB) {
-            float cen[TB + 2][VEC], up[TB][VEC], dn[TB][VEC], lf[TB][VEC], rt[TB][VEC], ad[TB][VEC];
+            float cen[TB + 2][VEC], up[TB][VEC], dn[TB][VEC], lf[TB][VEC], rt[TB][VEC], ad[TB][VEC], zz[TB][VEC];
             unsigned mb[TB], gb[TB];
 #pragma unroll
             for (int k = 0; k < TB + 2; ++k) {                 // frames t0 - 1 .. t0 + TB (clamped into the clip; zeroed below where outside)
@@ -235,6 +242,7 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
                 mb[k] = 0xfu;
                 gb[k] = 0xfu;
                 if (a.out_gate) gb[k] = a.out_gate[(((long)n * T + t) * HW + pix) * (a.out_c / 4) + c0 / 4] >> (c0 & 3);
+                if (a.gs_z) Vec<ET, VEC>::load(reinterpret_cast<const ET*>(a.gs_z) + (((long)n * T + t) * HW + pix) * a.out_c + c0, zz[k]);
                 if (a.add) {
                     const long apix = ((long)n * T + t) * HW + pix;
                     Vec<ET, VEC>::load(reinterpret_cast<const ET*>(a.add) + apix * a.add_c + c0, ad[k]);
@@ -268,9 +276,14 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
                     for (int i = 0; i < VEC; ++i) {
                         float v = y[i];
                         if constexpr (sizeof(ET) == 2) v = bf16_to_f32(f32_to_bf16(v));
-                        const float dlt = v - kk[i];
-                        st1[i] += dlt;
-                        st2[i] += dlt * dlt;
+                        if (a.gs_z) {                          // BatchNorm-backward sums of the gated output
+                            st1[i] += v;
+                            st2[i] += v * ((zz[k][i] - gmu[i]) * grs[i]);
+                        } else {
+                            const float dlt = v - kk[i];
+                            st1[i] += dlt;
+                            st2[i] += dlt * dlt;
+                        }
                     }
                 }
             }
@@ -313,7 +326,8 @@ __global__ void copy_tail_nhwc(const ET* src, ET* dst, long npix, int c, int cs)
 
 }  // namespace
 
-struct NhwcFlip { int flip; const void* add; int add_c; const unsigned char* add_mask; const unsigned char* out_gate; float* stats_part; const float* stats_shift; int rows_only; };
+struct NhwcFlip { int flip; const void* add; int add_c; const unsigned char* add_mask; const unsigned char* out_gate; float* stats_part; const float* stats_shift; int rows_only;
+                  const void* gs_z; const float* gs_mean; const float* gs_invstd; };
 int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
                              const float* ww, const float* scale, const float* shift, NhwcFlip fl, hipStream_t st) {
     // In-place hazard: a workgroup re-reads neighbour pixels that another workgroup may already have overwritten.
@@ -332,6 +346,7 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     a.out_gate = fl.out_gate;
     a.stats_part = fl.stats_part;
     a.stats_shift = fl.stats_shift;
+    a.gs_z = fl.gs_z; a.gs_mean = fl.gs_mean; a.gs_invstd = fl.gs_invstd;
     const int esz = d->dtype == MVF_F32 ? 4 : 2;
     const bool vec = (d->cs % 4 == 0) && (d->c % 4 == 0) && (out_c % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % (4 * esz) == 0) &&
                      (!fl.add || (fl.add_c % 4 == 0 && (uintptr_t)fl.add % (4 * esz) == 0));
@@ -386,7 +401,7 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
 
 int mvf_nhwc_fwd_infer_impl(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
                             const float* ww, const float* scale, const float* shift, hipStream_t st) {
-    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     return mvf_nhwc_fwd_infer_impl2(d, x, out, out_c, wt, wh, ww, scale, shift, f, st);
 }
 
@@ -711,7 +726,7 @@ int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int
     MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil: gate bits need an addend with pitch % 4 == 0");
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, nullptr, nullptr, nullptr, 0};
+    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, scale, shift, f, (hipStream_t)stream);
 }
 
@@ -726,8 +741,24 @@ int mvf_nhwc_stencil_gate(const mvf_desc_t* d, const void* x, int x_c, void* out
     MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil_gate: gate bits need an addend with pitch % 4 == 0");
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, out_gate_bits, nullptr, nullptr, 0};
+    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, out_gate_bits, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, scale, shift, f, (hipStream_t)stream);
+}
+
+// [r5] mvf_nhwc_stencil_gate that ALSO accumulates the BatchNorm-backward sums of the gated slice it stores: sums_part CHANNEL-MAJOR
+// [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] = per-workgroup sums of gm and gm * (bn_z - bn_mean) * bn_invstd (bn_z: the stored input of the
+// BatchNorm the gated gradient belongs to, pitch out_c) -> mvf_bn_bwd_finalize.  The slice's share of mvf_conv2d_nhwc_fwd_resmask_gate_sums.
+int mvf_nhwc_stencil_gate_sums(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
+                               const float* w_w, int flip, const void* addend, int addend_c, const unsigned char* addend_sign_bits,
+                               const unsigned char* out_gate_bits, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sums_part, void* stream) {
+    MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs && out_gate_bits && bn_z && bn_mean && bn_invstd && sums_part, MVF_EINVAL,
+                "nhwc_stencil_gate_sums: bad argument");
+    MVF_REQUIRE(!addend || addend_c >= d->cs, MVF_EINVAL, "nhwc_stencil_gate_sums: addend pitch < cs");
+    MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil_gate_sums: gate bits need an addend with pitch % 4 == 0");
+    mvf_desc_t dd = *d;
+    dd.c = x_c;
+    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, out_gate_bits, sums_part, nullptr, 0, bn_z, bn_mean, bn_invstd};
+    return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, nullptr, nullptr, f, (hipStream_t)stream);
 }
 
 // [r5] the plain stencil (y = taps * x-slice, no activation) that ALSO accumulates the batch statistics of MVF's BatchNorm3d (MVF.py:131-134, training
@@ -737,7 +768,7 @@ int mvf_nhwc_stencil_stats_rows(const mvf_desc_t* d, int x_c, int out_c) {
     if (!d || d->cs <= 0 || d->nt <= 0) return 0;
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 1};
+    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr};
     return mvf_nhwc_fwd_infer_impl2(&dd, (const void*)16, (void*)32, out_c, (const float*)16, (const float*)16, (const float*)16, nullptr, nullptr, f, nullptr);
 }
 int mvf_nhwc_stencil_stats(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
@@ -745,7 +776,7 @@ int mvf_nhwc_stencil_stats(const mvf_desc_t* d, const void* x, int x_c, void* ou
     MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs && stats_part, MVF_EINVAL, "nhwc_stencil_stats: bad argument");
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, stats_part, stats_shift, 0};
+    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, stats_part, stats_shift, 0, nullptr, nullptr, nullptr};
     return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, nullptr, nullptr, f, (hipStream_t)stream);
 }
 

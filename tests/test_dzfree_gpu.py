@@ -229,3 +229,69 @@ def test_stencil_with_fused_statistics_equals_stencil_plus_statistics_pass(case)
     assert torch.equal(out[True][0], out[False][0])
     for a, b in zip(out[True][1] + [out[True][2], out[True][3]], out[False][1] + [out[False][2], out[False][3]]):
         assert torch.isfinite(a).all() and rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("case", [(2, 14, 14, 256, 1024, 128), (3, 7, 9, 128, 512, 0), (1, 28, 28, 64, 256, 64)], ids=str)
+def test_gated_data_gradient_with_fused_sums_equals_gate_then_sums_pass(case):
+    """[r5] mvf_conv2d_nhwc_fwd_resmask_gate_sums: the output bit for bit mvf_conv2d_nhwc_fwd_resmask_gate's, and the finalised sums of the channels
+    >= res_c0 equal to mvf_bn_bwd_reduce (mask mode 0) over that stored output and the BatchNorm's input (fp32 summation order)."""
+    lib, check, ConvDesc, _ = _lib()
+    n, h, w, cin, cout, c0 = case
+    m = n * h * w
+    gen = torch.Generator().manual_seed(m + cout + 1)
+    x = torch.randn(m, cin, generator=gen).cuda().to(BF)
+    wp = (torch.randn(cout, cin, generator=gen) * 0.05).cuda().to(BF)
+    res = torch.randn(m, cout, generator=gen).cuda().to(BF)
+    rbits = torch.randint(0, 16, (m, cout // 4), generator=gen, dtype=torch.uint8).cuda()
+    gate = torch.randint(0, 16, (m, cout // 4), generator=gen, dtype=torch.uint8).cuda()
+    z = (torch.randn(m, cout, generator=gen) * 1.2 + 0.3).cuda().to(BF)
+    mean, invstd = (torch.randn(cout, generator=gen) * 0.3).cuda(), (torch.rand(cout, generator=gen) + 0.4).cuda()
+    ws = torch.empty(lib.mvf_conv2d_workspace_bytes(None), dtype=torch.uint8, device="cuda")
+    d = ConvDesc(n, h, w, cin, cout, 1, 1, 1, 0, h, w, cin, 1, 0, 0, 0, 0, c0)
+    y0, y1 = torch.empty(m, cout, device="cuda", dtype=BF), torch.empty(m, cout, device="cuda", dtype=BF)
+    check(lib.mvf_conv2d_nhwc_fwd_resmask_gate(C.byref(d), P(x), None, P(wp), None, P(res), P(rbits), P(gate), P(y0), P(ws), ws.numel(), None))
+    rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+    part = torch.full((cout, rows, 2), float("nan"), device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums(C.byref(d), P(x), None, P(wp), P(res), P(rbits), P(gate), P(y1), P(z), P(mean), P(invstd), P(part), P(ws),
+                                                    ws.numel(), None))
+    dg, db = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda")
+    check(lib.mvf_bn_bwd_finalize(P(part[c0:]), rows, cout - c0, P(dg[c0:]), P(db[c0:]), None))
+    ws_bn = torch.empty(lib.mvf_bn_workspace_bytes(m, cout), dtype=torch.uint8, device="cuda")
+    dg0, db0 = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
+    check(lib.mvf_bn_bwd_reduce(P(y0), cout, P(z), None, m, cout, P(mean), P(invstd), None, None, 0, None, P(dg0), P(db0), P(ws_bn), ws_bn.numel(), 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    assert rel_l2(dg[c0:].cpu().numpy(), dg0[c0:].cpu().numpy()) < 1e-5 and rel_l2(db[c0:].cpu().numpy(), db0[c0:].cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(2, 4, 14, 14, 1024, 128), (1, 8, 7, 7, 512, 64)], ids=str)
+def test_gated_stencil_with_fused_sums_equals_gate_then_sums_pass(case):
+    """[r5] mvf_nhwc_stencil_gate_sums: the slice bit for bit mvf_nhwc_stencil_gate's, its finalised sums equal to mvf_bn_bwd_reduce (mask mode 0) over
+    the stored slice and the BatchNorm's input (a pitch-c tensor)."""
+    lib, check, _, MvfDesc = _lib()
+    from mvfnet_amd import _lib as L
+    nc, t, h, w, c, cs = case
+    nt, m = nc * t, nc * t * h * w
+    gen = torch.Generator().manual_seed(m + 7)
+    dy = torch.randn(m, cs, generator=gen).cuda().to(BF)
+    add = torch.randn(m, c, generator=gen).cuda().to(BF)
+    abits = torch.randint(0, 16, (m, c // 4), generator=gen, dtype=torch.uint8).cuda()
+    gate = torch.randint(0, 16, (m, c // 4), generator=gen, dtype=torch.uint8).cuda()
+    z = (torch.randn(m, c, generator=gen) * 1.2 + 0.3).cuda().to(BF)
+    mean, invstd = (torch.randn(c, generator=gen) * 0.3).cuda(), (torch.rand(c, generator=gen) + 0.4).cuda()
+    wt, wh, ww = (torch.randn(cs, 3, generator=gen).cuda() for _ in range(3))
+    d = MvfDesc(nt, c, h, w, t, cs, L.MODE_BITS["THW"], L.MVF_NHWC, L.MVF_BF16)
+    o0, o1 = torch.zeros(m, c, device="cuda", dtype=BF), torch.zeros(m, c, device="cuda", dtype=BF)
+    check(lib.mvf_nhwc_stencil_gate(C.byref(d), P(dy), cs, P(o0), c, P(wt), P(wh), P(ww), None, None, 1, P(add), c, P(abits), P(gate), None))
+    rows = lib.mvf_nhwc_stencil_stats_rows(C.byref(d), cs, c)
+    part = torch.full((cs, rows, 2), float("nan"), device="cuda")
+    check(lib.mvf_nhwc_stencil_gate_sums(C.byref(d), P(dy), cs, P(o1), c, P(wt), P(wh), P(ww), 1, P(add), c, P(abits), P(gate), P(z), P(mean), P(invstd), P(part), None))
+    dg, db = torch.empty(cs, device="cuda"), torch.empty(cs, device="cuda")
+    check(lib.mvf_bn_bwd_finalize(P(part), rows, cs, P(dg), P(db), None))
+    ws_bn = torch.empty(lib.mvf_bn_workspace_bytes(m, cs), dtype=torch.uint8, device="cuda")
+    dg0, db0 = torch.empty(cs, device="cuda"), torch.empty(cs, device="cuda")
+    o0s, zs = o0[:, :cs].contiguous(), z[:, :cs].contiguous()
+    check(lib.mvf_bn_bwd_reduce(P(o0s), cs, P(zs), None, m, cs, P(mean), P(invstd), None, None, 0, None, P(dg0), P(db0), P(ws_bn), ws_bn.numel(), 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
+    assert rel_l2(dg.cpu().numpy(), dg0.cpu().numpy()) < 1e-5 and rel_l2(db.cpu().numpy(), db0.cpu().numpy()) < 1e-5
