@@ -639,6 +639,7 @@ def other_configs(seconds):
     region; same JSON contract, 5 timed steps): so that the driver's record carries them, not only the builder's notes."""
     import subprocess
     runs = {"C3 in fp32 (the reference's shipped training precision): R50 8x8, 32 clips, fp32 train step": ["--mode", "train", "--dtype", "f32"],
+            "C3 at the reference's own recipe (videos_per_gpu=12, configs/MVFNet/K400/mvf_kinetics400_2d_rgb_r50_dense.py:121-123): R50 8x8, 12 clips/GPU, bf16 train step": ["--mode", "train", "--dtype", "bf16", "--clips", "12"],
             "C2 configs[1]: R50 8x8, 32 clips, fp32, forward only": ["--mode", "infer", "--dtype", "f32"],
             "C4 configs[3]: R101 16x4, 16 clips/GPU, bf16 train step": ["--mode", "train", "--dtype", "bf16", "--depth", "101", "--frames", "16", "--clips", "16"],
             "C5 configs[4]: R50 8x8, one video = 10 clips x 3 crops of 256^2, fcn_testing, fp32": ["--mode", "video", "--dtype", "f32"],

@@ -799,6 +799,7 @@ class _TBlock(object):
             w3_done = True
         else:
             dz3 = self.b3.backward(g, self.c3.cout, s["z3"], m2, eng, 4, ymask=bits)
+        eng.issue_marked()         # [r5] the block above's side launches, enqueued behind this block's first launch-stream kernels (see side_late)
         fuse = eng.fuse_bn_bwd_sums
         if dz3 is None:
             pass       # the fused pass above already produced da2 and bn2's sums
@@ -868,7 +869,7 @@ class _TBlock(object):
             self.io = dict(x=s["x"], out=s["out"], g=g, dx=dx, h=h, w=w, c=c, ho=ho, wo=wo, g_gated=g_gated, dx_gated=self.gated_out)
         self.saved = None
         if not getattr(eng, "_hold_side", False):
-            eng.flush_side()
+            eng.flush_side(late=True)
         return dx
 
 
@@ -1050,14 +1051,45 @@ class _ParamStore(object):
         with _on_stream(side):
             launch()
 
-    def flush_side(self):
+    # [r5] side_late: the hand-over is MARKED at the block's end (an event on the launch stream) but the side launches are ENQUEUED only after the next
+    # block's first launch-stream kernels -- host order only, the device-side dependencies are the same.  Why: the side stream's first kernel after a hand-over
+    # is a 256 x 256 weight-gradient tile (512 threads x 256 registers: a workgroup owns its CU's whole register file), and with ~14 side launches between the
+    # event and the next launch-stream kernel in HOST order that kernel reached its queue after the tile had taken every CU: the launch queue then idled 21-51 us
+    # at every MVF block boundary once the dz3-free path had lengthened the side list (tools/gap_dump.py, profiles/r05_step_timeline_gaps.txt): 0.25 ms of queue
+    # idle per step.  With the late enqueue the gaps are back at the 7 us of a hand-over (main-queue idle 0.45 -> 0.20 ms per step) -- and the STEP does not move
+    # (19.27 vs 19.27 ms, C4 33.63 vs 33.63, 12 clips 10.00 vs 10.00: three alternations): the two queues share the chip work-conservingly, the kernel that
+    # started late had only been waiting for CUs the other queue was using.  Kept for the cleaner timeline; MVF_SIDE_LATE=0 = enqueue at the block's end.
+    side_late = os.environ.get("MVF_SIDE_LATE", "1") != "0"
+
+    def flush_side(self, late=False):
         pend = getattr(self, "_side_pending", None)
+        marked = getattr(self, "_side_marked", None)
+        if late and self.side_late and pend:
+            # mark now, enqueue later (issue_marked)
+            ev = torch.cuda.Event()
+            ev.record(self.main_stream())
+            if marked is None:
+                marked = self._side_marked = []
+            marked.append((ev, list(pend)))
+            del pend[:]
+            return
+        self.issue_marked()
         if pend:
             self._side.wait_stream(self.main_stream())
             with _on_stream(self._side):
                 for launch in pend:
                     launch()
             del pend[:]
+
+    def issue_marked(self):
+        marked = getattr(self, "_side_marked", None)
+        if marked:
+            for ev, launches in marked:
+                self._side.wait_event(ev)
+                with _on_stream(self._side):
+                    for launch in launches:
+                        launch()
+            del marked[:]
 
     def join_side(self):
         self.flush_side()

@@ -8,8 +8,10 @@ vals = synth.synth_state_dict({"r50/" + k: tuple(v.shape) for k, v in sd.items()
 m.load_state_dict({k: torch.from_numpy(vals["r50/" + k]) for k in sd}, strict=True)
 m = m.cuda().train()
 eng = m.train_engine(dtype=torch.bfloat16)
-imgs = torch.from_numpy(synth.synth_clip_batch(32, 8, 224, 224)).cuda()
-labels = torch.from_numpy(synth.synth_labels(32)).cuda()
+CLIPS = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+imgs = torch.from_numpy(synth.synth_clip_batch(CLIPS, 8, 224, 224)).cuda()
+labels = torch.from_numpy(synth.synth_labels(CLIPS)).cuda()
+print('clips', CLIPS)
 def timeit(fn, n=10):
     for _ in range(2): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
