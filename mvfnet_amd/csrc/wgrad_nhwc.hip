@@ -1210,10 +1210,10 @@ static bool wg_big_shape(const mvf_conv_desc_t* d) {
     return big_env && d->dtype == MVF_BF16 && d->cout % 256 == 0 && K % 256 == 0 && d->cin % 8 == 0 && d->x_pix_stride % 4 == 0 &&
            (d->split_c == 0 || (d->split_c % 256 == 0 && d->cin % 256 == 0));
 }
-static int wg_big_rows(const mvf_conv_desc_t* d) {
+static int wg_big_rows(const mvf_conv_desc_t* d, int wgs_override = 0) {
     const int M = d->n * d->ho * d->wo, K = d->kh * d->kw * d->cin;
     static const int big_wgs = getenv("MVF_WGRAD_BIG_WGS") ? std::max(32, atoi(getenv("MVF_WGRAD_BIG_WGS"))) : 256;      // A/B switch
-    return plan_split(M, (d->cout / 256) * (K / 256), big_wgs);
+    return plan_split(M, (d->cout / 256) * (K / 256), wgs_override > 0 ? wgs_override : big_wgs);
 }
 
 // [r4] layer1's 3x3 (64 -> 64 channels, stride 1, pad 1, bf16) on the direct kernel of wgrad3x3_c64.hip (MVF_WGRAD3X3_DIRECT=0: the implicit GEMM)
@@ -1271,11 +1271,18 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     a.split_c = d->split_c; a.x2ps = d->x2_pix_stride;
     a.M = d->n * d->ho * d->wo; a.K = d->kh * d->kw * d->cin;
     WgTile t = pick_tile(d->cout, a.K);
+    // [r5] a Gram matrix (dz == x: a^T a of ONE tensor, the dz3-free BatchNorm backward's A2, bn_dzfree.hip): its output is a single small tile, so the usual
+    // plan -- one workgroup per CU -- spends 256 x 256 KB of fp32 slabs (written, then read by the reduce) on a 256 KB result: 128 MB of traffic per call, 2.4 GB per
+    // C3 step.  It runs on the side stream with slack, so it takes MVF_GRAM_WGS (default 32) workgroups instead: an eighth of the slabs and of the CUs.  Measured in the
+    // step (alternating runs; ms, C3 / C4): 256 workgroups 18.64 / 32.2, 128: 18.68 / 32.45, 64: 18.75 / 32.6, 32: 18.59 / 31.8 on one box; 32: 19.10 / 33.08, 24: 19.08 /
+    // 33.1, 16: 19.16 / 33.3, 8: 19.30 / 33.6 on another.
+    static const int gram_env = getenv("MVF_GRAM_WGS") ? std::max(8, atoi(getenv("MVF_GRAM_WGS"))) : 32;
+    const int gram_wgs = (dz == x && !x2 && d->kh == 1 && d->kw == 1 && d->cin == d->cout) ? gram_env : 0;
     // 256 x 256 tile: the shapes of wg_big_shape() when the LDS-DMA address ranges and alignments hold and every split has >= 4 chunks
     bool big = wg_big_shape(d) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
                (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 2 < 0x7ffffff0L;
     if (big) {
-        const int rows = wg_big_rows(d);
+        const int rows = wg_big_rows(d, gram_wgs);
         big = rows >= 4 * 64 && ((long)rows + 6 * 64) * d->cout * 2 < 0x7ffffff0L;
         if (big) t = WgTile{256, 256};
     }
@@ -1288,9 +1295,9 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     bool x3 = d->dtype == MVF_F32 && x3_env && d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride % 4 == 0 && d->split_c % 4 == 0 &&
               (d->x2_pix_stride % 4 == 0 || !d->split_c) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0;
     static const bool wgs_forced = getenv("MVF_WGRAD_WGS") != nullptr;
-    a.rows_per_split = big ? wg_big_rows(d) : plan_split(a.M, tiles, x3 && !wgs_forced ? 768 : 0);
+    a.rows_per_split = big ? wg_big_rows(d, gram_wgs) : plan_split(a.M, tiles, gram_wgs ? gram_wgs : (x3 && !wgs_forced ? 768 : 0));
     x3 = x3 && ((long)a.rows_per_split + 64) * d->cout * 4 < 0x7ffffff0L;
-    if (d->dtype == MVF_F32 && !x3 && !wgs_forced) a.rows_per_split = plan_split(a.M, tiles);
+    if (d->dtype == MVF_F32 && !x3 && !wgs_forced && !gram_wgs) a.rows_per_split = plan_split(a.M, tiles);
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
     a.tiles = tiles;
     a.nsplit = nsplit;
