@@ -1033,7 +1033,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* part, i
     const long K = (long)kh * kwp * cinp;
     const long total = (long)cout * K;
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + e;
+    const long nblk = (total + 63) / 64;
+    for (long bid = blockIdx.x; bid < nblk; bid += gridDim.x) {        // ([r5] a capped grid walks the blocks: MVF_WGRAD_REDUCE_WGS)
+    if (bid != (long)blockIdx.x) __syncthreads();
+    const long i = bid * 64 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < total) {
         int k = sl;
@@ -1055,12 +1058,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* part, i
         const int co = (int)(t / kh);
         if (ci < cin && x < kw) dw[(((long)co * cin + ci) * kh + y) * kw + x] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
+    }
 }
 int launch_wgrad_reduce(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp, float* dw, hipStream_t st) {
     static const int r4 = getenv("MVF_WGRAD_REDUCE4") ? atoi(getenv("MVF_WGRAD_REDUCE4")) : 0;
     const long total = (long)cout * kh * kwp * cinp;
     if (!r4 || total % 4 || ((uintptr_t)part | (uintptr_t)dw) % 16) {
-        hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, part, nsplit, cout, cin, kh, kw, kwp, cinp, dw);
+        static const int cap = getenv("MVF_WGRAD_REDUCE_WGS") ? atoi(getenv("MVF_WGRAD_REDUCE_WGS")) : 0;      // [r5] A/B: at most this many workgroups (0 = one per 64 elements)
+        const long nblk = (total + 63) / 64;
+        hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((int)(cap > 0 ? std::min<long>(nblk, cap) : nblk)), dim3(256), 0, st, part, nsplit, cout, cin, kh, kw, kwp, cinp, dw);
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
