@@ -1218,7 +1218,11 @@ static bool wg_big_shape(const mvf_conv_desc_t* d) {
 }
 static int wg_big_rows(const mvf_conv_desc_t* d, int wgs_override = 0) {
     const int M = d->n * d->ho * d->wo, K = d->kh * d->kw * d->cin;
-    static const int big_wgs = getenv("MVF_WGRAD_BIG_WGS") ? std::max(32, atoi(getenv("MVF_WGRAD_BIG_WGS"))) : 256;      // A/B switch
+    // [r5] 128 workgroups (half the CUs), not one per CU: these GEMMs run on the side stream beside the launch stream's kernels, and the two queues share the chip
+    // work-conservingly -- what the weight gradients cost the step is their FOOTPRINT (a 256 x 256 workgroup owns its CU's whole register file), not their own
+    // length.  Measured in the step (alternating runs; ms, C3 / C4): 256 workgroups 19.20 / 33.08, 192: 18.95 / 32.72, 128: 18.88 / 32.36 on one box; 128: 18.34 / 31.45,
+    // 96: 18.35 / 31.91, 64: 18.50 / 32.38 on another.  (Round 2 measured 128 = 256 on a step whose launch stream still carried 7 ms of BatchNorm passes.)
+    static const int big_wgs = getenv("MVF_WGRAD_BIG_WGS") ? std::max(32, atoi(getenv("MVF_WGRAD_BIG_WGS"))) : 128;      // A/B switch
     return plan_split(M, (d->cout / 256) * (K / 256), wgs_override > 0 ? wgs_override : big_wgs);
 }
 
@@ -1301,7 +1305,10 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     bool x3 = d->dtype == MVF_F32 && x3_env && d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride % 4 == 0 && d->split_c % 4 == 0 &&
               (d->x2_pix_stride % 4 == 0 || !d->split_c) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0;
     static const bool wgs_forced = getenv("MVF_WGRAD_WGS") != nullptr;
-    a.rows_per_split = big ? wg_big_rows(d, gram_wgs) : plan_split(a.M, tiles, gram_wgs ? gram_wgs : (x3 && !wgs_forced ? 768 : 0));
+    // [r5] bf16 128 x 128 plans aim at 256 workgroups instead of 1024 for the same reason (with the big tile at 128; ms, C3 / C4: 1024: 18.34 / 31.45, 512: 18.20 / 31.29,
+    // 384: 18.21 / 31.23, 256: 18.15 / 31.30)
+    const int bf16_wgs = (d->dtype == MVF_BF16 && !wgs_forced) ? 256 : 0;
+    a.rows_per_split = big ? wg_big_rows(d, gram_wgs) : plan_split(a.M, tiles, gram_wgs ? gram_wgs : (x3 && !wgs_forced ? 768 : bf16_wgs));
     x3 = x3 && ((long)a.rows_per_split + 64) * d->cout * 4 < 0x7ffffff0L;
     if (d->dtype == MVF_F32 && !x3 && !wgs_forced && !gram_wgs) a.rows_per_split = plan_split(a.M, tiles);
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
