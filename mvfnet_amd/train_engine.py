@@ -25,9 +25,37 @@ from ._lib import ConvDesc, MvfDesc, check, lib
 
 F32 = _lib.MVF_F32
 
+# [r5] Descriptors are memoised by their field values (shapes are static from step to step): building a 19-field ctypes structure per launch and asking the library for
+# mvf_conv2d_stats_rows each time was ~1.5 ms of host time per step (~300 + ~100 calls).
+_ConvDescT, _MvfDescT = ConvDesc, MvfDesc
+_DESC_CACHE, _ROWS_CACHE = {}, {}
+
+
+def ConvDesc(*a):      # noqa: F811
+    d = _DESC_CACHE.get(a)
+    if d is None:
+        d = _DESC_CACHE[a] = _ConvDescT(*a)
+    return d
+
+
+def MvfDesc(*a):       # noqa: F811
+    k = ("mvf",) + a
+    d = _DESC_CACHE.get(k)
+    if d is None:
+        d = _DESC_CACHE[k] = _MvfDescT(*a)
+    return d
+
+
+def _stats_rows(d):
+    r = _ROWS_CACHE.get(id(d))
+    if r is None:
+        r = _ROWS_CACHE[id(d)] = lib.mvf_conv2d_stats_rows(C.byref(d))
+    return r
+
 
 def _p(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    # a plain int (every entry point declares its argtypes, so ctypes converts it): ~3500 calls per step, the c_void_p object each used to build was 0.5 ms of host time
+    return t.data_ptr() if t is not None else None
 
 
 _STREAM = [None]      # cached HIP stream handle of the stream the engine is launching on (torch.cuda.current_stream() costs ~8 us)
@@ -52,6 +80,7 @@ class _on_stream(object):
 
 
 _SIDE_WS = {}
+_MAINH = [None]      # handle of the engine's launch stream (set at every entry point: torch.cuda.current_stream() in _conv_ws was 115 calls = 0.9 ms of host time per step)
 
 
 def _conv_ws(device):
@@ -59,7 +88,7 @@ def _conv_ws(device):
     must not share the partial-tile slots and flags)."""
     from .engine import _sk_workspace
     h = _STREAM[0]
-    if h is None or h.value == torch.cuda.current_stream().cuda_stream:
+    if h is None or h.value == (_MAINH[0] if _MAINH[0] is not None else torch.cuda.current_stream().cuda_stream):
         return _sk_workspace(device)
     key = (str(device), h.value)
     ws = _SIDE_WS.get(key)
@@ -275,7 +304,7 @@ class _TConv(object):
             if bn is not None:
                 bn.stats(z, n * ho * wo, self.eng)
             return z, ho, wo
-        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        rows = _stats_rows(d)
         part = self.eng.buf((id(self), "part"), (rows, self.cout, 2), torch.float32)
         self.launch_fwd(d, x, x2, z, ws, part, bn.mod.running_mean)
         bn.finalize(part, rows, n * ho * wo)
@@ -302,7 +331,7 @@ class _TConv(object):
         d = self.desc(n, h, w, ho, wo, self.cin)
         m = n * ho * wo
         ws = _conv_ws(a_in.device)
-        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        rows = _stats_rows(d)
         part = self.eng.buf((id(self), "bwpart"), (rows, self.cout, 2), torch.float32)
         self.launch_bwd_sums(d, a_in, g, bits, bn, part, ws)
         check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cout, _p(bn.dgamma), _p(bn.dbeta), _st()), "mvf_bn_bwd_finalize")
@@ -324,7 +353,7 @@ class _TConv(object):
         d = self.desc(n, h, w, h, w, pitch)
         m = n * h * w
         ws = _conv_ws(a_in.device)
-        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        rows = _stats_rows(d)
         ns = lib.mvf_conv1x1_bwd_fused_splits(m, self.cout, self.cin)
         if not sums_done and self.eng.pair_ds_sums & 2:          # [r4] the one-branch form of csrc/pw_sums_pair.hip instead of pw_sums.hip
             part = self.eng.buf((id(self), "bwpart_pair"), (self.cout, 2 * ns, 2), torch.float32)
@@ -419,7 +448,7 @@ class _TConv(object):
                      self.stride if self.stride > 1 else 0, 0)
         dx = self.eng.buf((id(self), "dx"), (n * h * w, self.cin))
         ws = _conv_ws(dz.device)
-        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        rows = _stats_rows(d)
         part = self.eng.buf((id(self), "bnsums"), (rows, self.cin, 2), torch.float32)
         self.launch_dgrad_bnsums(d, dz, dx, z, bn, part, ws)
         check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cin, _p(bn.dgamma), _p(bn.dbeta), _st()), "bn bwd finalize")
@@ -441,7 +470,7 @@ class _TConv(object):
         if out_gate is not None and gsum is not None:
             # [r5] ... + the BatchNorm-backward sums of the block below's bn3 (gsum: dict(z3, bn)) over the gated gradient, channels >= res_c0
             bn = gsum["bn"]
-            rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+            rows = _stats_rows(d)
             part = self.eng.buf((id(bn), "gsum_conv"), (self.cin, rows, 2), torch.float32)
             check(lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums(C.byref(d), _p(dz), None, _p(self.wd), _p(residual), _p(res_bits), _p(out_gate), _p(dx), _p(gsum["z3"]),
                                                             _p(bn.mean), _p(bn.invstd), _p(part), _p(ws), ws.numel(), _st()), "conv dgrad (gated output + bn sums)")
@@ -473,7 +502,7 @@ class _TConv(object):
         d = ConvDesc(n, h, w, c + k, k, 1, 1, 1, 0, h, w, k, eng.dt, 0, c, c, 0, 0, c)        # x = a_in (pitch k, columns c .. c + k), x2 = gm (pitch c)
         dx = eng.buf((id(self), "dx"), (m, k))
         ws = _conv_ws(gm.device)
-        rows = lib.mvf_conv2d_stats_rows(C.byref(d))
+        rows = _stats_rows(d)
         part = eng.buf((id(self), "bnsums"), (rows, k, 2), torch.float32)
         self.launch_dzfree_dgrad(d, a_in, gm, bd, bias, dx, z_in, bn_in, part, ws)
         check(lib.mvf_bn_bwd_finalize(_p(part), rows, k, _p(bn_in.dgamma), _p(bn_in.dbeta), _st()), "bn bwd finalize")
@@ -1228,6 +1257,7 @@ class BlockTrainer(_ParamStore):
         nt, c, h, w = x_nchw.shape
         self.nt = nt
         self._main = torch.cuda.current_stream()
+        _MAINH[0] = self._main.cuda_stream
         for cv in self.blk.convs():
             cv.pack()
         x = x_nchw.permute(0, 2, 3, 1).contiguous().view(nt * h * w, c).to(self.tdtype)
@@ -1321,6 +1351,7 @@ class TrainEngine(_ParamStore):
         if not imgs.is_cuda or imgs.dtype not in (torch.float32, torch.uint8):
             raise RuntimeError("TrainEngine.forward: float32 (or uint8 frames) GPU input required")
         self._main = torch.cuda.current_stream()
+        _MAINH[0] = self._main.cuda_stream
         self.forward_count += 1
         with _on_stream(self._main):
             return self._forward(imgs, labels, stages)
@@ -1413,6 +1444,7 @@ class TrainEngine(_ParamStore):
         """exchange=True (train_step): this engine also owns the data-parallel gradient exchange and may start it during
         backward; False (autograd API / external optimizer hooks): gradients are only produced."""
         self._main = torch.cuda.current_stream()
+        _MAINH[0] = self._main.cuda_stream
         self._exchange = bool(exchange)
         with _on_stream(self._main):
             self._backward()
