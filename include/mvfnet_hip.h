@@ -172,7 +172,8 @@ int mvf_conv2d_nhwc_fwd_resmask_gate(const mvf_conv_desc_t* d, const void* x, co
 /* [r5] ... and the BatchNorm-backward sums of the gated output in the same epilogue: with gm = y (as stored) on channels >= d->res_c0, sums_part
  * CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] = per-128-row column sums of gm and gm * (bn_z - bn_mean) * bn_invstd, bn_z = the stored input of the
  * BatchNorm whose output gradient y is (bn3 of the block below, resnet.py:236-244) -> mvf_bn_bwd_finalize on the channel range [res_c0, cout): that block's
- * sums pass over (gm, z3) disappears.  (Channels below res_c0 get meaningless partial rows: finalize the range only.) */
+ * sums pass over (gm, z3) disappears.  (Channels below res_c0 get meaningless partial rows: finalize the range only.)  bn_z = NULL: the column sums of gm and
+ * gm^2 instead (no read of z3 at all): mvf_bn_bwd_dzfree_sums completes them with the weight-gradient GEMM. */
 int mvf_conv2d_nhwc_fwd_resmask_gate_sums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* residual,
                                           const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y, const void* bn_z,
                                           const float* bn_mean, const float* bn_invstd, float* sums_part, void* ws, size_t ws_bytes, void* stream);
@@ -256,6 +257,12 @@ int mvf_bn_bwd_dzfree_prep(const void* w_packed_dgrad, int c, int k, const float
                            const float* dbeta, long m, void* w_out, float* bias_out, int dtype, void* stream);
 int mvf_bn_bwd_dzfree_wgrad(float* dw, const void* w_packed, const float* gram, const float* a_mean, const float* gamma, const float* mean,
                             const float* invstd, const float* dgamma, const float* dbeta, long m, int c, int k, int dtype, void* stream);
+/* _sums : dgamma / dbeta WITHOUT the pass over (gm, z3) either: sum_m gm z3 = sum_k W[c][k] Q[c][k] (Q = the weight-gradient GEMM of _wgrad, taken FIRST) and
+ *         sum_m gm from the column sums the kernels that stored gm took in their epilogues -- part_lo [c_split][rows_lo][2] (the MVF stencil's slice,
+ *         mvf_nhwc_stencil_gate_sums with bn_z = NULL) and part_hi [c][rows_hi][2] indexed by the absolute channel (mvf_conv2d_nhwc_fwd_resmask_gate_sums
+ *         with bn_z = NULL); element [.][.][0] is read.  dgamma[c] = invstd (W[c].Q[c] - mean sum gm), dbeta[c] = sum gm. */
+int mvf_bn_bwd_dzfree_sums(const float* q, const void* w_packed, int c, int k, const float* mean, const float* invstd, const float* part_lo, int rows_lo,
+                           int c_split, const float* part_hi, int rows_hi, float* dgamma, float* dbeta, int dtype, void* stream);
 size_t mvf_bn_workspace_bytes(long m, int c);
 /* batch mean / biased var of z over m -> save_mean, save_invstd, scale = gamma*invstd, shift = beta - mean*scale;
  * running_mean/var updated in place (unbiased var).  Shifted single-pass sums (shift = old running_mean). */
@@ -384,6 +391,10 @@ size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d);
 int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real,
                           int cin_real, int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes,
                           void* stream);
+/* [r5] the same GEMM with the workgroup count to aim at named by the caller (the library's own plans size weight gradients for a side stream: half the
+ * chip); results differ from mvf_conv2d_nhwc_wgrad only by the fp32 summation order of the pixel split. */
+int mvf_conv2d_nhwc_wgrad_wgs(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real,
+                              int cin_real, int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, int wgs, void* stream);
 /* Every weight pack of a training step in one launch.  jobs_dev = DEVICE array of njobs records sorted by first_block;
  * job k owns workgroups [first_block, first_block + ceil(elements / 2048)), total_blocks = their sum.  kind 0 = the forward
  * pack of mvf_pack_conv_weight (no scale), kind 1 = the data-gradient pack of mvf_pack_conv_weight_dgrad.  kind 2 / 3 = the
@@ -414,7 +425,7 @@ int mvf_nhwc_stencil_gate(const mvf_desc_t* d, const void* x, int x_c, void* out
                           const unsigned char* out_gate_bits, void* stream);
 /* [r5] mvf_nhwc_stencil_gate + the BatchNorm-backward sums of the gated slice: sums_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] =
  * per-workgroup sums of gm and gm * (bn_z - bn_mean) * bn_invstd (bn_z pitch out_c) -> mvf_bn_bwd_finalize: the slice's share of
- * mvf_conv2d_nhwc_fwd_resmask_gate_sums. */
+ * mvf_conv2d_nhwc_fwd_resmask_gate_sums (bn_z = NULL: sums of gm and gm^2, as there). */
 int mvf_nhwc_stencil_gate_sums(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
                                const float* w_w, int flip, const void* addend, int addend_c, const unsigned char* addend_sign_bits,
                                const unsigned char* out_gate_bits, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sums_part,

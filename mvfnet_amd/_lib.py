@@ -95,6 +95,8 @@ def _load():
     lib.mvf_bn_bwd_dzfree_prep.argtypes = [vp, i32, i32, fp, fp, fp, fp, fp, i64_, vp, fp, i32, vp]
     lib.mvf_bn_bwd_dzfree_wgrad.restype = i32
     lib.mvf_bn_bwd_dzfree_wgrad.argtypes = [fp, vp, fp, fp, fp, fp, fp, fp, fp, i64_, i32, i32, i32, vp]
+    lib.mvf_bn_bwd_dzfree_sums.restype = i32
+    lib.mvf_bn_bwd_dzfree_sums.argtypes = [fp, vp, i32, i32, fp, fp, fp, i32, i32, fp, i32, fp, fp, i32, vp]
     lib.mvf_nhwc_stencil_stats_rows.restype = i32
     lib.mvf_nhwc_stencil_stats_rows.argtypes = [dp, i32, i32]
     lib.mvf_nhwc_stencil_stats.restype = i32
@@ -180,6 +182,8 @@ def _load():
     lib.mvf_conv2d_wgrad_workspace_bytes.argtypes = [cp]
     lib.mvf_conv2d_nhwc_wgrad.restype = i32
     lib.mvf_conv2d_nhwc_wgrad.argtypes = [cp, vp, vp, vp, i32, i32, i32, i32, fp, vp, sz, vp]
+    lib.mvf_conv2d_nhwc_wgrad_wgs.restype = i32
+    lib.mvf_conv2d_nhwc_wgrad_wgs.argtypes = [cp, vp, vp, vp, i32, i32, i32, i32, fp, vp, sz, i32, vp]
     lib.mvf_pack_conv_weight_dgrad.restype = i32
     lib.mvf_pack_conv_weight_dgrad.argtypes = [fp, i32, i32, i32, i32, vp, i32, vp]
     lib.mvf_nhwc_stencil.restype = i32

@@ -1036,12 +1036,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
     // residual loads.
     const bool e_bias = EPI == 0 ? a.bias != nullptr : (EPI == 4 || EPI == 5 || (EPI == 6 && a.bias != nullptr));   // ([r5] EPI 6 + bias: mvf_conv2d_nhwc_dgrad_bnsums_split)
-    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8 || EPI == 9 || EPI == 10 || EPI == 11);
+    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8 || EPI == 9 || EPI == 10 || EPI == 11 || EPI == 12);
     constexpr bool e_gs = EPI == 11;                     // [r5] gated output + the BatchNorm-backward sums of the block below
     constexpr bool e_bw = EPI == 9 || EPI == 10;         // BatchNorm backward on the recomputed conv output (g and its sign-bit gate arrive as the residual operand)
     const bool e_relu = EPI == 0 ? a.relu != 0 : (EPI == 4 || EPI == 5);
     constexpr bool e_apply = EPI == 8;                   // BatchNorm apply + residual + ReLU + sign bits on the rounded accumulators
-    const bool e_stats = EPI == 0 ? a.stats_part != nullptr : EPI == 1;
+    const bool e_stats = EPI == 0 ? a.stats_part != nullptr : (EPI == 1 || EPI == 12);      // ([r5] EPI 12: residual + gate + the column sums of what is stored)
     constexpr bool e_bnb = EPI == 6;                     // BatchNorm-backward sums instead of forward statistics
     const bool e_scatter = (EPI == 0 || EPI == 6) && a.o_s > 0;      // a strided data gradient's parity class (plain or + BN sums)
     constexpr int CP = BN * 4 + 16;                      // C-tile pitch in bytes
@@ -2048,6 +2048,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
             else if (bnsum_epi) rc = launch_glds<ET, WM, WN, TM, TN, 6>(1, tiles, st, a);
             else if (train_like && !a.stats_part && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 2>(1, tiles, st, a);
             else if (train_like && !a.stats_part && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 3>(1, tiles, st, a);
+            else if (train_like && a.stats_part && a.res && a.out_gate && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 12>(1, tiles, st, a);
             else if (infer_like && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 4>(1, tiles, st, a);
             else if (infer_like && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 5>(1, tiles, st, a);
             else rc = launch_glds<ET, WM, WN, TM, TN, 0>(1, tiles, st, a);
@@ -2065,6 +2066,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
             else if (bnsum_epi) rc = launch_glds<ET, WM, WN, TM, TN, 6>(g_glds_nb, tiles, st, a);
             else if (train_like && !a.stats_part && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 2>(g_glds_nb, tiles, st, a);
             else if (train_like && !a.stats_part && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 3>(g_glds_nb, tiles, st, a);
+            else if (train_like && a.stats_part && a.res && a.out_gate && !a.bn_z) rc = launch_glds<ET, WM, WN, TM, TN, 12>(g_glds_nb, tiles, st, a);
             else if (infer_like && !a.res) rc = launch_glds<ET, WM, WN, TM, TN, 4>(g_glds_nb, tiles, st, a);
             else if (infer_like && a.res) rc = launch_glds<ET, WM, WN, TM, TN, 5>(g_glds_nb, tiles, st, a);
             else rc = launch_glds<ET, WM, WN, TM, TN, 0>(g_glds_nb, tiles, st, a);
@@ -2079,6 +2081,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         else if (bnsum_epi) launch_lowk<ET, WM, WN, TM, TN, 6>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && !a.res) launch_lowk<ET, WM, WN, TM, TN, 2>(pw, tiles, lds_lk, st, a);
         else if (train_like && !a.stats_part && a.res) launch_lowk<ET, WM, WN, TM, TN, 3>(pw, tiles, lds_lk, st, a);
+        else if (train_like && a.stats_part && a.res && a.out_gate && !a.bn_z) launch_lowk<ET, WM, WN, TM, TN, 12>(pw, tiles, lds_lk, st, a);
         else if (infer_like && !a.res) launch_lowk<ET, WM, WN, TM, TN, 4>(pw, tiles, lds_lk, st, a);
         else if (infer_like && a.res) launch_lowk<ET, WM, WN, TM, TN, 5>(pw, tiles, lds_lk, st, a);
         else launch_lowk<ET, WM, WN, TM, TN, 0>(pw, tiles, lds_lk, st, a);
@@ -2224,8 +2227,11 @@ int mvf_conv2d_nhwc_fwd_resmask_gate(const mvf_conv_desc_t* d, const void* x, co
 int mvf_conv2d_nhwc_fwd_resmask_gate_sums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* residual,
                                           const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y, const void* bn_z,
                                           const float* bn_mean, const float* bn_invstd, float* sums_part, void* ws, size_t ws_bytes, void* stream) {
-    MVF_REQUIRE(d && residual && out_gate_bits && bn_z && bn_mean && bn_invstd && sums_part && d->in_dil <= 1 && !d->relu, MVF_EINVAL,
-                "conv2d_resmask_gate_sums: needs a residual, the gate bits, the BatchNorm's input / mean / invstd, a partial buffer and a stride-1 launch without ReLU");
+    MVF_REQUIRE(d && residual && out_gate_bits && sums_part && d->in_dil <= 1 && !d->relu, MVF_EINVAL,
+                "conv2d_resmask_gate_sums: needs a residual, the gate bits, a partial buffer and a stride-1 launch without ReLU");
+    if (!bn_z)       // column sums only: [.][.][0] = sum gm, [.][.][1] = sum gm^2 (the dz3-free backward takes dgamma from its weight-gradient GEMM: mvf_bn_bwd_dzfree_sums)
+        return conv_fwd_impl(d, x, x2, w_packed, nullptr, residual, y, sums_part, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits);
+    MVF_REQUIRE(bn_mean && bn_invstd, MVF_EINVAL, "conv2d_resmask_gate_sums: bn_z needs bn_mean / bn_invstd");
     MVF_REQUIRE(((uintptr_t)bn_mean | (uintptr_t)bn_invstd | (uintptr_t)bn_z) % 16 == 0, MVF_EINVAL, "conv2d_resmask_gate_sums: bn_z / bn_mean / bn_invstd must be 16-byte aligned");
     const GatedSums gs = {bn_z, bn_mean, bn_invstd};
     return conv_fwd_impl(d, x, x2, w_packed, nullptr, residual, y, sums_part, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits, &gs);

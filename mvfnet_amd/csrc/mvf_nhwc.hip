@@ -751,8 +751,8 @@ int mvf_nhwc_stencil_gate(const mvf_desc_t* d, const void* x, int x_c, void* out
 int mvf_nhwc_stencil_gate_sums(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
                                const float* w_w, int flip, const void* addend, int addend_c, const unsigned char* addend_sign_bits,
                                const unsigned char* out_gate_bits, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sums_part, void* stream) {
-    MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs && out_gate_bits && bn_z && bn_mean && bn_invstd && sums_part, MVF_EINVAL,
-                "nhwc_stencil_gate_sums: bad argument");
+    MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs && out_gate_bits && sums_part && (!bn_z || (bn_mean && bn_invstd)), MVF_EINVAL,
+                "nhwc_stencil_gate_sums: bad argument");      // (bn_z = NULL: the column sums of gm and gm^2 only -- mvf_bn_bwd_dzfree_sums takes dgamma from the weight-gradient GEMM)
     MVF_REQUIRE(!addend || addend_c >= d->cs, MVF_EINVAL, "nhwc_stencil_gate_sums: addend pitch < cs");
     MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil_gate_sums: gate bits need an addend with pitch % 4 == 0");
     mvf_desc_t dd = *d;

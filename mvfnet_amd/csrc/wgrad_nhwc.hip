@@ -1253,8 +1253,9 @@ size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
 
 // dw_oihw (cout, cin_real, kh, kw_real) fp32 <- dz (n,ho,wo,cout), x as in the forward descriptor.
 // kw_real/cin_real < packed extents only for the stem view (kh x 1 x 32 over the padded NHWC4 input = 7 x 8 x 4).
-int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real, int cin_real,
-                          int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, void* stream) {
+}  // extern "C"
+static int wgrad_impl(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real, int cin_real,
+                      int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, void* stream, int wgs_target) {
     MVF_REQUIRE(d && dz && x && dw_oihw, MVF_EINVAL, "wgrad: NULL argument");
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "wgrad: bad dtype");
     MVF_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride > 0, MVF_ESHAPE, "wgrad: cin/cout must be multiples of 4");
@@ -1287,7 +1288,8 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     // step (alternating runs; ms, C3 / C4): 256 workgroups 18.64 / 32.2, 128: 18.68 / 32.45, 64: 18.75 / 32.6, 32: 18.59 / 31.8 on one box; 32: 19.10 / 33.08, 24: 19.08 /
     // 33.1, 16: 19.16 / 33.3, 8: 19.30 / 33.6 on another.
     static const int gram_env = getenv("MVF_GRAM_WGS") ? std::max(8, atoi(getenv("MVF_GRAM_WGS"))) : 32;
-    const int gram_wgs = (dz == x && !x2 && d->kh == 1 && d->kw == 1 && d->cin == d->cout) ? gram_env : 0;
+    // (wgs_target > 0, mvf_conv2d_nhwc_wgrad_wgs: the caller names the workgroup count to aim at -- a GEMM the LAUNCH stream waits for wants the whole chip)
+    const int gram_wgs = wgs_target > 0 ? wgs_target : (dz == x && !x2 && d->kh == 1 && d->kw == 1 && d->cin == d->cout) ? gram_env : 0;
     // 256 x 256 tile: the shapes of wg_big_shape() when the LDS-DMA address ranges and alignments hold and every split has >= 4 chunks
     bool big = wg_big_shape(d) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
                (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 2 < 0x7ffffff0L;
@@ -1312,6 +1314,7 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     x3 = x3 && ((long)a.rows_per_split + 64) * d->cout * 4 < 0x7ffffff0L;
     if (d->dtype == MVF_F32 && !x3 && !wgs_forced && !gram_wgs) a.rows_per_split = plan_split(a.M, tiles);
     const int nsplit = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+    MVF_REQUIRE(ws_bytes >= (size_t)nsplit * d->cout * a.K * sizeof(float), MVF_EWS, "wgrad: workspace too small for %d slabs", nsplit);
     a.tiles = tiles;
     a.nsplit = nsplit;
     static const int map_env = getenv("MVF_WGRAD_MAP") ? atoi(getenv("MVF_WGRAD_MAP")) : -1;      // A/B: 0 balanced ranges everywhere, 1 round-robin wherever legal
@@ -1358,6 +1361,20 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
     MVF_LAUNCH_CHECK();
     const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);
     return launch_wgrad_reduce(a.part, nsplit, d->cout, cin_real, kh_p, kw_real, kw_packed, cin_packed, dw_oihw, st);
+}
+extern "C" {
+
+int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real, int cin_real,
+                          int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_impl(d, dz, x, x2, kw_real, cin_real, kw_packed, cin_packed, dw_oihw, ws, ws_bytes, stream, 0);
+}
+
+// [r5] the same GEMM with the workgroup count to aim at named by the caller (the library's own policy sizes weight gradients for the SIDE stream: half the chip);
+// same results up to the fp32 summation order of the pixel split
+int mvf_conv2d_nhwc_wgrad_wgs(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real, int cin_real,
+                              int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, int wgs, void* stream) {
+    MVF_REQUIRE(wgs >= 8 && wgs <= 4096, MVF_EINVAL, "wgrad_wgs: wgs=%d outside 8 .. 4096", wgs);
+    return wgrad_impl(d, dz, x, x2, kw_real, cin_real, kw_packed, cin_packed, dw_oihw, ws, ws_bytes, stream, wgs);
 }
 
 int mvf_pack_conv_weights_batched(const mvf_pack_job_t* jobs_dev, int njobs, int total_blocks, int dtype, void* stream) {

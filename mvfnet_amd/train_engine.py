@@ -472,6 +472,11 @@ class _TConv(object):
             bn = gsum["bn"]
             rows = _stats_rows(d)
             part = self.eng.buf((id(bn), "gsum_conv"), (self.cin, rows, 2), torch.float32)
+            if gsum["sums"] == "s1":         # column sums of gm only (no read of z3): the block below completes them from its weight-gradient GEMM (dzfree_q_sums)
+                check(lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums(C.byref(d), _p(dz), None, _p(self.wd), _p(residual), _p(res_bits), _p(out_gate), _p(dx), None, None,
+                                                                None, _p(part), _p(ws), ws.numel(), _st()), "conv dgrad (gated output + column sums)")
+                bn._s1 = [None, 0, res_c0, part, rows]
+                return dx
             check(lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums(C.byref(d), _p(dz), None, _p(self.wd), _p(residual), _p(res_bits), _p(out_gate), _p(dx), _p(gsum["z3"]),
                                                             _p(bn.mean), _p(bn.invstd), _p(part), _p(ws), ws.numel(), _st()), "conv dgrad (gated output + bn sums)")
             check(lib.mvf_bn_bwd_finalize(_p(part[res_c0:]), rows, self.cin - res_c0, _p(bn.dgamma[res_c0:]), _p(bn.dbeta[res_c0:]), _st()), "bn bwd finalize")
@@ -513,11 +518,31 @@ class _TConv(object):
         check(lib.mvf_conv2d_nhwc_dgrad_bnsums_split(C.byref(d), _p(a_in), _p(gm), _p(bd), _p(bias), _p(dx), _p(z_in), _p(bn_in.mean), _p(bn_in.invstd),
                                                      _p(bn_in.scale), _p(bn_in.shift), _p(part), _p(ws), ws.numel(), _st()), "conv dgrad on [gm | a] + bn sums")
 
-    def dzfree_wgrad(self, gm, a_in, bn, n, h, w, eng, frozen_zero=None):
+    def dzfree_q_sums(self, gm, a_in, bn, n, h, w, eng):
+        """[r5] bn's dgamma / dbeta with NO pass over (gm, z3): Q = gm^T a_in (the weight-gradient GEMM of dzfree_wgrad, taken first and on the LAUNCH stream,
+        sized for the whole chip) gives sum gm z3 = sum_k W Q, and the kernels that stored gm left its column sums (bn._s1: the block above's conv1 data
+        gradient for the channels >= its MVF slice, its transposed stencil for the slice)."""
+        c, k = self.cout, self.cin
+        d = self.desc(n, h, w, h, w, k, 0)
+        ws = eng.workspace(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)))
+        self.launch_q(d, gm, a_in, ws, eng.dzfree_q_wgs)
+        lo, rows_lo, c_split, hi, rows_hi = bn._s1
+        assert c_split == 0 or lo is not None, "the MVF slice's column sums are missing"
+        check(lib.mvf_bn_bwd_dzfree_sums(_p(self.dw), _p(self.wp), c, k, _p(bn.mean), _p(bn.invstd), _p(lo), rows_lo, c_split, _p(hi), rows_hi, _p(bn.dgamma),
+                                         _p(bn.dbeta), eng.dt, _st()), "bn backward sums from the weight-gradient GEMM")
+        bn._s1 = None
+
+    def launch_q(self, d, gm, a_in, ws, wgs):
+        """One weight-gradient GEMM (+ its slab reduce) on the launch stream (bench.py brackets this call with HIP events)."""
+        check(lib.mvf_conv2d_nhwc_wgrad_wgs(C.byref(d), _p(gm), _p(a_in), None, self.kw, self.cin, self.kw, self.cin, _p(self.dw), _p(ws), ws.numel(), wgs, _st()),
+              "conv wgrad (launch stream)")
+
+    def dzfree_wgrad(self, gm, a_in, bn, n, h, w, eng, frozen_zero=None, q_done=False):
         """dW = dz^T a_in without dz: Q = gm^T a_in (the usual weight-gradient GEMM, into dw), A2 = a_in^T a_in and the column means of a_in, then the
         correction kernel -- all on the side stream (they only feed the optimizer)."""
         c, k, m = self.cout, self.cin, n * h * w
-        self.wgrad(gm, a_in, n, h, w, h, w, eng)
+        if not q_done:         # (dzfree_q_sums already left Q in dw)
+            self.wgrad(gm, a_in, n, h, w, h, w, eng)
         gram = eng.buf((id(self), "gram"), (k, k), torch.float32)
         amean = eng.buf((id(self), "amean"), (4, k), torch.float32)            # rows: mean, and three outputs of the statistics call nobody reads
         d = ConvDesc(n, h, w, k, k, 1, 1, 1, 0, h, w, k, eng.dt, 0, 0, 0, 0)
@@ -619,6 +644,11 @@ class _TMvf(object):
             bn = gsum["bn"]
             rows = lib.mvf_nhwc_stencil_stats_rows(C.byref(d), src_c, dst_c)
             part = self.eng.buf((id(bn), "gsum_mvf"), (self.cs, rows, 2), torch.float32)
+            if gsum["sums"] == "s1":
+                check(lib.mvf_nhwc_stencil_gate_sums(C.byref(d), _p(src), src_c, _p(dst), dst_c, _p(self.wt), _p(self.wh), _p(self.ww), flip, _p(addend), addend_c,
+                                                     _p(addend_bits), _p(out_gate), None, None, None, _p(part), _st()), "mvf stencil (gated output + column sums)")
+                bn._s1[0], bn._s1[1] = part, rows
+                return
             check(lib.mvf_nhwc_stencil_gate_sums(C.byref(d), _p(src), src_c, _p(dst), dst_c, _p(self.wt), _p(self.wh), _p(self.ww), flip, _p(addend), addend_c,
                                                  _p(addend_bits), _p(out_gate), _p(gsum["z3"]), _p(bn.mean), _p(bn.invstd), _p(part), _st()), "mvf stencil (gated output + bn sums)")
             check(lib.mvf_bn_bwd_finalize(_p(part), rows, self.cs, _p(bn.dgamma), _p(bn.dbeta), _st()), "bn bwd finalize")
@@ -703,7 +733,12 @@ class _TBlock(object):
         if s is None or not eng.gate_producer or not self.dzfree(eng, s["out"].shape[0]):
             return None
         # sums: the block above also takes bn3's backward sums over what it stores (eng.gate_sums), so this block's sums pass over (gm, z3) disappears
-        return dict(bits=s["bits"], z3=s["z3"], bn=self.b3, sums=bool(eng.gate_sums))
+        # [r5] dzfree_q: only the column sums of gm ("s1"); the other half comes from this block's weight-gradient GEMM (_TConv.dzfree_q_sums)
+        # (1: planes <= 256 only -- the GEMM costs 2 m c k flops against the sums pass's 4 m c bytes: half the pass at k = 128, even at 256, twice at 512)
+        # and only where the pass it replaces is long enough to pay for the GEMM's extra launches on the launch stream: >= 160 MB of (gm, z3))
+        q = eng.dzfree_q == 2 or (eng.dzfree_q == 1 and self.c3.cin <= 256 and s["out"].shape[0] * self.c3.cout * 4 >= 160e6)
+        sums = True if eng.gate_sums else ("s1" if (q and not self.b3.frozen) else False)
+        return dict(bits=s["bits"], z3=s["z3"], bn=self.b3, sums=sums)
 
     def launch_sums_pair(self, a2, x, x_pitch, g, bits, m, eng):
         """Exactly one launch (bench.py brackets this call with HIP events) + the two finalizes."""
@@ -811,16 +846,20 @@ class _TBlock(object):
         elif self.dzfree(eng, m2):
             # [r5] no dz3: bn3's sums on gm and z3, then the data gradient on [gm | a2] (+ bn2's sums) and, on the side stream, the weight gradient on gm
             b3 = self.b3
+            q_done = False
             if g_gated:
                 gm = g
-                if not sums_done:
+                if sums_done == "s1":
+                    self.c3.dzfree_q_sums(gm, s["a2"], b3, nt, ho, wo, eng)
+                    q_done = True
+                elif not sums_done:
                     b3._reduce(gm, self.c3.cout, s["z3"], m2, eng, 0, None, None)
             else:
                 gm = eng.buf((id(b3), "gm"), s["z3"].shape, s["z3"].dtype)
                 b3._reduce(g, self.c3.cout, s["z3"], m2, eng, 4, bits, gm)
             fz = b3._zero if b3.frozen else None
             da2 = self.c3.dzfree_dgrad(gm, s["a2"], b3, nt, ho, wo, self.b2, s["z2"], frozen_zero=fz)
-            self.c3.dzfree_wgrad(gm, s["a2"], b3, nt, ho, wo, eng, frozen_zero=fz)
+            self.c3.dzfree_wgrad(gm, s["a2"], b3, nt, ho, wo, eng, frozen_zero=fz, q_done=q_done)
             dz3, w3_done = None, True
             del gm
         elif (eng.fuse_bnwg & 1) and self.c3.fuses_wgrad(eng, m2, self.c3.cout, 4):
@@ -872,7 +911,7 @@ class _TBlock(object):
             del dzd
         if self.mvf is None:
             dx = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid, res_bits=rbits, out_gate=out_gate, gsum=gsum)
-            self.gated_out, self.sums_out = out_gate is not None, gsum is not None
+            self.gated_out, self.sums_out = out_gate is not None, (gsum["sums"] if gsum is not None else False)
             if not w1_done:
                 self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c)
         else:
@@ -882,7 +921,7 @@ class _TBlock(object):
             og = out_gate if fuse else None
             gs = gsum if fuse else None
             dxp = self.c1.dgrad(dz1, nt, h, w, h, w, residual=resid if fuse else None, res_c0=self.mvf.cs, res_bits=rbits if fuse else None, out_gate=og, gsum=gs)
-            self.gated_out, self.sums_out = og is not None, gs is not None
+            self.gated_out, self.sums_out = og is not None, (gs["sums"] if gs is not None else False)
             if self.split_ok:
                 self.c1.wgrad(dz1, s["x"], nt, h, w, h, w, eng, x_pitch=c, x2=s["o"], split_c=self.mvf.cs)
             else:
@@ -1026,6 +1065,14 @@ class _ParamStore(object):
     # 18.59 ms, C4 32.36 -> 32.43 ms (alternating runs on one box; on the 4-workgroups-per-CU kernel, MVF_GSUM_GLDS=1: 19.40 -> 19.38 / 33.75 -> 34.02) -- the sums
     # epilogue costs the data gradient what the sums pass over (gm, z3) took.  Off by default.
     gate_sums = os.environ.get("MVF_GATE_SUMS", "0") != "0"
+    # [r5] dzfree_q: bn3's backward sums of a dz3-free block without ANY pass over (gm, z3): the block above leaves the column sums of gm (its epilogues) and
+    # sum gm z3 = sum_k W Q comes from the weight-gradient GEMM Q = gm^T a2, which moves from the side stream to the launch stream, ahead of the data gradient
+    # (dzfree_q_wgs workgroups: the launch stream waits for it, so it takes the whole chip).  The sums pass (gm + z3 read once more) disappears.
+    # 0 off, 1 planes <= 256 and >= 160 MB of (gm, z3), 2 every dz3-free block.  Measured in the step (three alternations on one box; ms, 0 / 1-without-the-size-rule / 2):
+    # C4 32.31-32.46 / 31.62-31.91 / 31.68-31.81; C3 18.52-18.66 / 18.54-18.67 / 18.52-18.68 (its side stream has slack: shedding work there buys nothing);
+    # 12 clips 9.37-9.41 / 9.55-9.57 (launch-bound: two more launches per block on the launch stream cost more than the short pass) -- hence the size rule.
+    dzfree_q = int(os.environ.get("MVF_DZFREE_Q", "1"))
+    dzfree_q_wgs = int(os.environ.get("MVF_DZFREE_Q_WGS", "256"))
 
     def side_stream(self):
         if not self.overlap_wgrad:
@@ -1247,21 +1294,26 @@ class _ParamStore(object):
 
 
 class BlockTrainer(_ParamStore):
-    """Train-mode forward/backward of ONE mvfnet_amd Bottleneck (with or without MVF) -- used by the parity tests."""
+    """Train-mode forward/backward of ONE mvfnet_amd Bottleneck (with or without MVF), or of a torch.nn.Sequential of them chained the way
+    TrainEngine._backward chains a stage (gated hand-down, column sums) -- used by the parity tests."""
 
     def __init__(self, block, dtype=torch.float32, rehome=True):
         self._init_store(block, dtype, rehome)
-        self.blk = _TBlock(block, self)
+        self.blks = [_TBlock(b, self) for b in block] if isinstance(block, torch.nn.Sequential) else [_TBlock(block, self)]
+        self.blk = self.blks[0]
 
     def forward(self, x_nchw):
         nt, c, h, w = x_nchw.shape
         self.nt = nt
         self._main = torch.cuda.current_stream()
         _MAINH[0] = self._main.cuda_stream
-        for cv in self.blk.convs():
-            cv.pack()
-        x = x_nchw.permute(0, 2, 3, 1).contiguous().view(nt * h * w, c).to(self.tdtype)
-        out, ho, wo, co = self.blk.forward(x, nt, h, w, c, self)
+        for b in self.blks:
+            for cv in b.convs():
+                cv.pack()
+        out = x_nchw.permute(0, 2, 3, 1).contiguous().view(nt * h * w, c).to(self.tdtype)
+        ho, wo, co = h, w, c
+        for b in self.blks:
+            out, ho, wo, co = b.forward(out, nt, ho, wo, co, self)
         return out.view(nt, ho, wo, co).permute(0, 3, 1, 2)
 
     def backward(self, g_nchw):
@@ -1269,7 +1321,12 @@ class BlockTrainer(_ParamStore):
         s = self.blk.saved
         h, w, c = s["h"], s["w"], s["c"]
         g = g_nchw.permute(0, 2, 3, 1).contiguous().view(nt * ho * wo, co).to(self.tdtype)
-        dx = self.blk.backward(g, nt, self)
+        gated = sums = False
+        for i in range(len(self.blks) - 1, -1, -1):
+            req = self.blks[i - 1].wants_gated_gradient(self) if i > 0 else None
+            g = self.blks[i].backward(g, nt, self, g_gated=gated, gate=req, sums_done=sums)
+            gated, sums = self.blks[i].gated_out, self.blks[i].sums_out
+        dx = g
         self.join_side()
         return dx.view(nt, h, w, c).permute(0, 3, 1, 2)
 

@@ -295,3 +295,109 @@ def test_gated_stencil_with_fused_sums_equals_gate_then_sums_pass(case):
     torch.cuda.synchronize()
     assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
     assert rel_l2(dg.cpu().numpy(), dg0.cpu().numpy()) < 1e-5 and rel_l2(db.cpu().numpy(), db0.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(2, 4, 14, 14, 256, 1024, 128), (1, 4, 7, 9, 128, 512, 0), (1, 4, 28, 28, 64, 256, 64), (2, 4, 7, 7, 512, 2048, 256)], ids=str)
+def test_sums_from_the_weight_gradient_gemm_equal_the_sums_pass(case):
+    """[r5] bn3's backward sums with no pass over (gm, z3) (eng.dzfree_q): the producers' bn_z = NULL form (output bit for bit the gated one, partial rows =
+    the column sums of what is stored) + Q = gm^T a2 on a caller-named workgroup count (mvf_conv2d_nhwc_wgrad_wgs == mvf_conv2d_nhwc_wgrad up to the
+    summation order) + mvf_bn_bwd_dzfree_sums, against mvf_bn_bwd_reduce over gm and the STORED z3 = bf16(a2 W^T) and against fp64 on the unrounded z3."""
+    lib, check, ConvDesc, MvfDesc = _lib()
+    from mvfnet_amd import _lib as L
+    nc, t, h, w, k, c, cs = case
+    nt = nc * t
+    m = nt * h * w
+    gen = torch.Generator().manual_seed(m + c + 3)
+    # the block above: conv1's data gradient (planes_above -> c channels) + residual, gated; its MVF slice [0, cs) through the transposed stencil
+    pa = 64
+    dz1 = torch.randn(m, pa, generator=gen).cuda().to(BF)
+    wd1 = (torch.randn(c, pa, generator=gen) * 0.1).cuda().to(BF)
+    res = torch.randn(m, c, generator=gen).cuda().to(BF)
+    rbits = torch.randint(0, 16, (m, c // 4), generator=gen, dtype=torch.uint8).cuda()
+    gate = torch.randint(0, 16, (m, c // 4), generator=gen, dtype=torch.uint8).cuda()
+    ws = torch.empty(lib.mvf_conv2d_workspace_bytes(None), dtype=torch.uint8, device="cuda")
+    d1 = ConvDesc(nt, h, w, pa, c, 1, 1, 1, 0, h, w, pa, 1, 0, 0, 0, 0, cs)
+    g0, gm = torch.empty(m, c, device="cuda", dtype=BF), torch.empty(m, c, device="cuda", dtype=BF)
+    check(lib.mvf_conv2d_nhwc_fwd_resmask_gate(C.byref(d1), P(dz1), None, P(wd1), None, P(res), P(rbits), P(gate), P(g0), P(ws), ws.numel(), None))
+    rows_hi = lib.mvf_conv2d_stats_rows(C.byref(d1))
+    part_hi = torch.full((c, rows_hi, 2), float("nan"), device="cuda")
+    check(lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums(C.byref(d1), P(dz1), None, P(wd1), P(res), P(rbits), P(gate), P(gm), None, None, None, P(part_hi), P(ws),
+                                                    ws.numel(), None))
+    part_lo, rows_lo = None, 0
+    if cs:
+        dy = torch.randn(m, cs, generator=gen).cuda().to(BF)
+        wt, wh, ww = (torch.randn(cs, 3, generator=gen).cuda() for _ in range(3))
+        dm = MvfDesc(nt, c, h, w, t, cs, L.MODE_BITS["THW"], L.MVF_NHWC, L.MVF_BF16)
+        check(lib.mvf_nhwc_stencil_gate(C.byref(dm), P(dy), cs, P(g0), c, P(wt), P(wh), P(ww), None, None, 1, P(res), c, P(rbits), P(gate), None))
+        rows_lo = lib.mvf_nhwc_stencil_stats_rows(C.byref(dm), cs, c)
+        part_lo = torch.full((cs, rows_lo, 2), float("nan"), device="cuda")
+        check(lib.mvf_nhwc_stencil_gate_sums(C.byref(dm), P(dy), cs, P(gm), c, P(wt), P(wh), P(ww), 1, P(res), c, P(rbits), P(gate), None, None, None, P(part_lo), None))
+    torch.cuda.synchronize()
+    assert torch.equal(g0.view(torch.int16), gm.view(torch.int16))
+    colsum = gm.double().sum(0)
+    got = torch.cat([part_lo[:, :, 0].double().sum(1), part_hi[cs:, :, 0].double().sum(1)]) if cs else part_hi[:, :, 0].double().sum(1)
+    assert rel_l2(got.cpu().numpy(), colsum.cpu().numpy()) < 1e-6
+    # this block: z3 = a2 W^T stored in bf16, its BatchNorm's statistics
+    a2 = torch.relu(torch.randn(m, k, generator=gen)).cuda().to(BF)
+    w3 = (torch.randn(c, k, generator=gen) * 0.08).cuda().to(BF)
+    z3x = a2.double() @ w3.double().t()
+    z3 = z3x.to(BF)
+    mean, invstd = z3x.mean(0).float(), (1.0 / torch.sqrt(z3x.var(0, unbiased=False) + 1e-5)).float()
+    d3 = ConvDesc(nt, h, w, k, c, 1, 1, 1, 0, h, w, k, 1, 0, 0, 0, 0)
+    wsw = torch.empty(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d3)), dtype=torch.uint8, device="cuda")
+    q0, q = torch.empty(c, k, device="cuda"), torch.empty(c, k, device="cuda")
+    check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d3), P(gm), P(a2), None, 1, k, 1, k, P(q0), P(wsw), wsw.numel(), None))
+    check(lib.mvf_conv2d_nhwc_wgrad_wgs(C.byref(d3), P(gm), P(a2), None, 1, k, 1, k, P(q), P(wsw), wsw.numel(), 256, None))
+    dg, db = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    check(lib.mvf_bn_bwd_dzfree_sums(P(q), P(w3), c, k, P(mean), P(invstd), P(part_lo), rows_lo, cs, P(part_hi), rows_hi, P(dg), P(db), L.MVF_BF16, None))
+    ws_bn = torch.empty(lib.mvf_bn_workspace_bytes(m, c), dtype=torch.uint8, device="cuda")
+    dg0, db0 = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    check(lib.mvf_bn_bwd_reduce(P(gm), c, P(z3), None, m, c, P(mean), P(invstd), None, None, 0, None, P(dg0), P(db0), P(ws_bn), ws_bn.numel(), 1, None))
+    torch.cuda.synchronize()
+    ref_q = gm.double().t() @ a2.double()
+    assert rel_l2(q.cpu().numpy(), ref_q.cpu().numpy()) < 1e-5 and rel_l2(q.cpu().numpy(), q0.cpu().numpy()) < 1e-5
+    ref_dg = (gm.double() * (z3x - mean.double()) * invstd.double()).sum(0)
+    e_pass, e_q = rel_l2(dg0.cpu().numpy(), ref_dg.cpu().numpy()), rel_l2(dg.cpu().numpy(), ref_dg.cpu().numpy())
+    print("case %s: dgamma vs fp64 on the unrounded z3: sums pass (bf16 z3) %.2e, from Q %.2e; dbeta %.2e" %
+          (case, e_pass, e_q, rel_l2(db.cpu().numpy(), colsum.cpu().numpy())))
+    assert e_q < 2e-4 and e_q < 2 * e_pass + 1e-5          # (the Q form never sees the rounding of z3: it is the more accurate of the two)
+    assert rel_l2(db.cpu().numpy(), db0.cpu().numpy()) < 1e-5 and rel_l2(dg.cpu().numpy(), dg0.cpu().numpy()) < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(1024, 256, 14, True), (1024, 256, 14, False), (512, 128, 28, True)], ids=str)
+def test_two_block_backward_with_sums_from_the_weight_gradient_gemm(shape):
+    """Two plain bottlenecks in a row through TrainEngine's own block loop (the upper block gates what it hands down and leaves the column sums; the lower
+    block takes Q first): eng.dzfree_q on / off give the same dx and parameter gradients within bf16 noise."""
+    from mvfnet_amd.backbones.resnet import Bottleneck
+    from mvfnet_amd.modules.MVF import MVF
+    from mvfnet_amd.train_engine import BlockTrainer
+    cin, planes, hw, with_mvf = shape
+    res = {}
+    for mode in (0, 2):            # (2: every dz3-free block; 1 adds the size rule of the product default, which these small shapes do not meet)
+        torch.manual_seed(11)
+        blks = []
+        for _ in range(2):
+            blk = Bottleneck(cin, planes)
+            if with_mvf:
+                blk.conv1 = MVF(blk.conv1, 4, cin, 0.125)
+            with torch.no_grad():
+                for bn in (blk.bn1, blk.bn2, blk.bn3):
+                    bn.weight.uniform_(0.5, 1.5)
+                    bn.bias.normal_(0, 0.2)
+            blks.append(blk)
+        seq = torch.nn.Sequential(*blks).cuda().train()
+        tr = BlockTrainer(seq, dtype=torch.bfloat16)
+        tr.dzfree_q = mode
+        x = torch.relu(torch.randn(8, cin, hw, hw, device="cuda"))
+        dy = torch.randn(8, cin, hw, hw, device="cuda")
+        y = tr.forward(x).float().clone()
+        dx = tr.backward(dy).float().clone()
+        torch.cuda.synchronize()
+        assert tr.blks[1].sums_out == ("s1" if mode else False) and tr.blks[1].gated_out
+        names = [n for n, _ in seq.named_parameters()]
+        res[mode] = (y, dx, {n: tr.grad_of(p).clone() for n, p in seq.named_parameters()}, names)
+    assert torch.equal(res[0][0], res[2][0])
+    e_dx = rel_l2(res[2][1].cpu().numpy(), res[0][1].cpu().numpy())
+    worst = max((rel_l2(res[2][2][n].cpu().numpy(), res[0][2][n].cpu().numpy()), n) for n in res[0][3])
+    print("shape %s: dx %.2e, worst parameter gradient %.2e (%s)" % (shape, e_dx, worst[0], worst[1]))
+    assert e_dx < 1e-2 and worst[0] < 1.5e-2, (e_dx, worst)

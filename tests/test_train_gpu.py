@@ -1046,6 +1046,8 @@ def test_engine_switch_variants_reproduce_the_default_step(dtype):
     assert got[0] == ref[0] and torch.equal(got[1], ref[1])
     got = run(steps=1, gate_sums=True)             # bn3's backward sums taken in the gating epilogues of the block above (off by default: measured neutral): summation order
     assert got[0] == ref[0] and rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-6 if dtype == torch.float32 else 1e-2)
+    got = run(steps=1, dzfree_q=2)                 # [r5] bn3's backward sums from the producers' column sums + the weight-gradient GEMM in EVERY dz3-free block (default: large ones) instead of a pass over (gm, z3)
+    assert got[0] == ref[0] and rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-6 if dtype == torch.float32 else 1e-2)
     got = run(steps=1, fuse_mvf_stats=False)            # [r5] MVF's BatchNorm statistics from a pass over y instead of the stencil launch: fp32 summation order
     assert abs(got[0][0] - ref[0][0]) < (1e-6 if dtype == torch.float32 else 1e-2) * abs(ref[0][0])
     assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-3 if dtype == torch.float32 else 1e-2)      # (batch statistics in another summation order, amplified by the 2-clip network)
