@@ -1291,7 +1291,8 @@ static int wgrad_impl(const mvf_conv_desc_t* d, const void* dz, const void* x, c
     // (wgs_target > 0, mvf_conv2d_nhwc_wgrad_wgs: the caller names the workgroup count to aim at -- a GEMM the LAUNCH stream waits for wants the whole chip)
     const int gram_wgs = wgs_target > 0 ? wgs_target : (dz == x && !x2 && d->kh == 1 && d->kw == 1 && d->cin == d->cout) ? gram_env : 0;
     // 256 x 256 tile: the shapes of wg_big_shape() when the LDS-DMA address ranges and alignments hold and every split has >= 4 chunks
-    bool big = wg_big_shape(d) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
+    static const int tgt_big = getenv("MVF_WGRAD_WGS_BIG") ? atoi(getenv("MVF_WGRAD_WGS_BIG")) : 0;      // A/B: 0 = a caller-named workgroup count takes the 128 x 128 plans
+    bool big = wg_big_shape(d) && (wgs_target <= 0 || tgt_big) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
                (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 2 < 0x7ffffff0L;
     if (big) {
         const int rows = wg_big_rows(d, gram_wgs);

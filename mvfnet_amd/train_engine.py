@@ -736,7 +736,7 @@ class _TBlock(object):
         # [r5] dzfree_q: only the column sums of gm ("s1"); the other half comes from this block's weight-gradient GEMM (_TConv.dzfree_q_sums)
         # (1: planes <= 256 only -- the GEMM costs 2 m c k flops against the sums pass's 4 m c bytes: half the pass at k = 128, even at 256, twice at 512)
         # and only where the pass it replaces is long enough to pay for the GEMM's extra launches on the launch stream: >= 160 MB of (gm, z3))
-        q = eng.dzfree_q == 2 or (eng.dzfree_q == 1 and self.c3.cin <= 256 and s["out"].shape[0] * self.c3.cout * 4 >= 160e6)
+        q = eng.dzfree_q == 2 or (eng.dzfree_q == 1 and self.c3.cin <= eng.dzfree_q_maxk and s["out"].shape[0] * self.c3.cout * 4 >= 160e6)
         sums = True if eng.gate_sums else ("s1" if (q and not self.b3.frozen) else False)
         return dict(bits=s["bits"], z3=s["z3"], bn=self.b3, sums=sums)
 
@@ -1073,6 +1073,7 @@ class _ParamStore(object):
     # 12 clips 9.37-9.41 / 9.55-9.57 (launch-bound: two more launches per block on the launch stream cost more than the short pass) -- hence the size rule.
     dzfree_q = int(os.environ.get("MVF_DZFREE_Q", "1"))
     dzfree_q_wgs = int(os.environ.get("MVF_DZFREE_Q_WGS", "256"))
+    dzfree_q_maxk = int(os.environ.get("MVF_DZFREE_Q_MAXK", "256"))
 
     def side_stream(self):
         if not self.overlap_wgrad:
