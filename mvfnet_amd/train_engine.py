@@ -698,6 +698,8 @@ class _TBlock(object):
             return self.z3_free_ds(eng, m2)
         if not (eng.z3_free and self.fuse_apply(eng) and eng.fuse_stats and not self.b3.frozen):
             return False
+        if self.q_z3_free(eng, m2):
+            return True            # [r5] its backward reads no z3 at all (dzfree_q): the first conv3 pass only takes the statistics
         if (eng.fuse_bnwg & 8) and eng.tdtype == torch.bfloat16 and lib.mvf_bn_bwd_wgrad_splits(m2, self.c3.cout, self.c3.cin, 1, 4) > 0:
             return False           # A/B: stored z3 + conv3's weight gradient in bn3's backward apply instead
         # measured per block in the bf16 step (us; stored-z3 path -> recompute path): statistics-only pass 148 -> 79 (layer1) / 75 -> 52 (layer2),
@@ -719,12 +721,31 @@ class _TBlock(object):
         # kernel (stride 1: the downsample branch sees the same m2 pixels) refuses the shape
         return lib.mvf_conv1x1_bwd_fused_splits(m2, self.c3.cout, self.c3.cin) > 0
 
+    above = None       # the block whose backward produces this block's output gradient (set by the engine / BlockTrainer over a chain)
+
+    def q_policy(self, eng, m2):
+        """eng.dzfree_q: 0 off, 1 planes <= dzfree_q_maxk (the GEMM costs 2 m c k flops against the sums pass's 4 m c bytes: half the pass at k = 128, even at
+        256, twice at 512) and only where that pass is long enough to pay for the GEMM's extra launches on the launch stream (>= 160 MB of (gm, z3)), 2 every block."""
+        return eng.dzfree_q == 2 or (eng.dzfree_q == 1 and self.c3.cin <= eng.dzfree_q_maxk and m2 * self.c3.cout * 4 >= 160e6)
+
+    def _dzfree_base(self, eng, m2):
+        if not eng.dzfree or self.cd is not None or not eng.fuse_bn_bwd_sums or not self.c3.dzfree_ok(m2 or (1 << 16)):
+            return False
+        return eng.dzfree == 2 or self.c3.cin >= 256
+
+    def q_z3_free(self, eng, m2):
+        """[r5] A dz3-free block whose bn3 sums come from the producers' column sums + Q (dzfree_q) reads z3 nowhere in backward, so where bn3's apply
+        already is a second conv3 pass (fuse_apply) the first pass need not store it (eng.dzfree_q_z3free).  Decided at forward time; should the block
+        above not deliver the column sums after all, backward falls back to bn3's backward on the recomputed conv."""
+        return bool(eng.dzfree_q_z3free and eng.gate_producer and not eng.gate_sums and self.above is not None and not self.b3.frozen and self.fuse_apply(eng)
+                    and self._dzfree_base(eng, m2) and self.q_policy(eng, m2))
+
     def dzfree(self, eng, m2=None):
         """[r5] bn3's backward without the dz3 tensor (csrc/bn_dzfree.hip): plain blocks (no downsample branch) with a STORED z3 whose last conv
         is pointwise; eng.dzfree: 0 off, 1 planes >= 256 (where dz3 is the widest tensor and no fused pass exists), 2 every eligible block."""
-        if not eng.dzfree or self.cd is not None or self.z3_free(eng, m2) or not eng.fuse_bn_bwd_sums or not self.c3.dzfree_ok(m2 or (1 << 16)):
+        if self.cd is not None or (self.z3_free(eng, m2) and not self.q_z3_free(eng, m2 or (1 << 16))):
             return False
-        return eng.dzfree == 2 or self.c3.cin >= 256
+        return self._dzfree_base(eng, m2)
 
     def wants_gated_gradient(self, eng):
         """The sign bits of this block's output when its backward wants gm = g * [out > 0] as a tensor (the dz3-free path reads it by LDS-DMA):
@@ -734,10 +755,10 @@ class _TBlock(object):
             return None
         # sums: the block above also takes bn3's backward sums over what it stores (eng.gate_sums), so this block's sums pass over (gm, z3) disappears
         # [r5] dzfree_q: only the column sums of gm ("s1"); the other half comes from this block's weight-gradient GEMM (_TConv.dzfree_q_sums)
-        # (1: planes <= 256 only -- the GEMM costs 2 m c k flops against the sums pass's 4 m c bytes: half the pass at k = 128, even at 256, twice at 512)
-        # and only where the pass it replaces is long enough to pay for the GEMM's extra launches on the launch stream: >= 160 MB of (gm, z3))
-        q = eng.dzfree_q == 2 or (eng.dzfree_q == 1 and self.c3.cin <= eng.dzfree_q_maxk and s["out"].shape[0] * self.c3.cout * 4 >= 160e6)
+        q = self.q_policy(eng, s["out"].shape[0])
         sums = True if eng.gate_sums else ("s1" if (q and not self.b3.frozen) else False)
+        if s["z3"] is None and sums != "s1":
+            return None            # (z3 was not stored: only the column-sum form can do without it)
         return dict(bits=s["bits"], z3=s["z3"], bn=self.b3, sums=sums)
 
     def launch_sums_pair(self, a2, x, x_pitch, g, bits, m, eng):
@@ -815,6 +836,7 @@ class _TBlock(object):
         # instead of fighting the data-gradient GEMM for the matrix cores.
         dzd = resid_aux = aux = resid_ds = None
         w3_done = wd_done = False        # [r4] weight gradient already taken inside the BatchNorm-backward pass
+        q_first = s["z3"] is None and g_gated and sums_done == "s1"       # [r5] z3 neither stored nor needed (q_z3_free)
         if self.cd is not None and s["z3"] is None:
             # [r4] z3-free downsample block: each branch = sums pass + one-pass backward on the recomputed conv; neither dz3 nor dz_d exists
             pair = bool(eng.pair_ds_sums & 1)
@@ -837,11 +859,11 @@ class _TBlock(object):
                 aux.wait_stream(eng.main_stream())
                 with _on_stream(aux):
                     resid_aux = self.cd.dgrad(dzd, nt, ho, wo, h, w)
-        elif s["z3"] is None and eng.fuse_c3_bwd and eng.fuse_bn_bwd_sums and self.c3.bwd_fused_ok(m2):
+        elif s["z3"] is None and not q_first and eng.fuse_c3_bwd and eng.fuse_bn_bwd_sums and self.c3.bwd_fused_ok(m2):
             # [r4] z3 never stored AND dz3 never stored: one pass forms it per 64-pixel chunk and contracts it three ways
             da2 = self.c3.bwd_fused(s["a2"], g, bits, nt, ho, wo, self.b3, self.b2, s["z2"])
             dz3, w3_done = None, True
-        elif s["z3"] is None:          # z3 was never stored: bn3's backward on the recomputed conv3
+        elif s["z3"] is None and not q_first:          # z3 was never stored: bn3's backward on the recomputed conv3
             dz3 = self.c3.bwd_recompute(s["a2"], g, bits, nt, ho, wo, self.b3)
         elif self.dzfree(eng, m2):
             # [r5] no dz3: bn3's sums on gm and z3, then the data gradient on [gm | a2] (+ bn2's sums) and, on the side stream, the weight gradient on gm
@@ -855,6 +877,7 @@ class _TBlock(object):
                 elif not sums_done:
                     b3._reduce(gm, self.c3.cout, s["z3"], m2, eng, 0, None, None)
             else:
+                assert s["z3"] is not None
                 gm = eng.buf((id(b3), "gm"), s["z3"].shape, s["z3"].dtype)
                 b3._reduce(g, self.c3.cout, s["z3"], m2, eng, 4, bits, gm)
             fz = b3._zero if b3.frozen else None
@@ -1074,6 +1097,9 @@ class _ParamStore(object):
     dzfree_q = int(os.environ.get("MVF_DZFREE_Q", "1"))
     dzfree_q_wgs = int(os.environ.get("MVF_DZFREE_Q_WGS", "256"))
     dzfree_q_maxk = int(os.environ.get("MVF_DZFREE_Q_MAXK", "256"))
+    # ... and such a block need not store z3 where bn3's apply is a second conv3 pass (_TBlock.q_z3_free: layer2's plain blocks).  Measured (ms, off / on, three
+    # alternations): C3 17.93-17.95 / 17.96-17.99, C4 30.43-30.47 / 30.45-30.69 -- the statistics-only pass is no shorter in the step than the storing one; off.
+    dzfree_q_z3free = os.environ.get("MVF_DZFREE_Q_Z3FREE", "0") != "0"
 
     def side_stream(self):
         if not self.overlap_wgrad:
@@ -1302,6 +1328,8 @@ class BlockTrainer(_ParamStore):
         self._init_store(block, dtype, rehome)
         self.blks = [_TBlock(b, self) for b in block] if isinstance(block, torch.nn.Sequential) else [_TBlock(block, self)]
         self.blk = self.blks[0]
+        for lo, hi in zip(self.blks[:-1], self.blks[1:]):
+            lo.above = hi
 
     def forward(self, x_nchw):
         nt, c, h, w = x_nchw.shape
@@ -1344,6 +1372,8 @@ class TrainEngine(_ParamStore):
         bb = model.backbone
         self.stem, self.stem_bn = _TConv(bb.conv1, self, stem=True), _BN(bb.bn1, self, "bn1")
         self.blocks = [_TBlock(blk, self) for name in bb.res_layers for blk in getattr(bb, name)]
+        for lo, hi in zip(self.blocks[:-1], self.blocks[1:]):
+            lo.above = hi
         head = model.cls_head
         self.fc_w, self.fc_b = head.new_fc.weight, head.new_fc.bias
         self.dfc_w, self.dfc_b = self.grad_of(head.new_fc.weight), self.grad_of(head.new_fc.bias)

@@ -388,9 +388,12 @@ def test_two_block_backward_with_sums_from_the_weight_gradient_gemm(shape):
         seq = torch.nn.Sequential(*blks).cuda().train()
         tr = BlockTrainer(seq, dtype=torch.bfloat16)
         tr.dzfree_q = mode
+        tr.dzfree_q_z3free = True          # (off by default: measured neutral)
         x = torch.relu(torch.randn(8, cin, hw, hw, device="cuda"))
         dy = torch.randn(8, cin, hw, hw, device="cuda")
         y = tr.forward(x).float().clone()
+        # the lower block stores no z3 where bn3's apply is a second conv3 pass (planes <= 128) and its backward sums come from Q (q_z3_free)
+        assert (tr.blks[0].saved["z3"] is None) == (mode == 2 and planes <= 128) and tr.blks[1].saved["z3"] is not None
         dx = tr.backward(dy).float().clone()
         torch.cuda.synchronize()
         assert tr.blks[1].sums_out == ("s1" if mode else False) and tr.blks[1].gated_out
