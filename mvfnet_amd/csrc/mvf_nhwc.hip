@@ -45,7 +45,12 @@ struct NhwcArgs {
     const float* stats_shift;        //      K per channel (the BatchNorm's old running mean; NULL = 0): the statistics pass of MVF's BatchNorm3d without a pass over y
     const unsigned char* out_gate;   // [r5] optional gate bits of the OUTPUT (after the addend): [pixels][out_c/4] bytes, same layout (VEC = 4 kernels only)
     int tsplit;    // 1: one frame per workgroup (grid.z = T) instead of sliding along t -- 7 loads, one round trip, T x the threads
+    int rb, cw, lbands;   // [r5] LDS-tiled kernel (mvf_nhwc_apply_lds): rows per band, channels per workgroup, bands per clip
+    unsigned fdw_mul, fdw_shr, fdrw_mul, fdrw_shr;      // host-made magic for n / w and n / ((rb + 2) w)
 };
+
+// one 3-tap view with the contraction spelled out: every stencil kernel of this file rounds the same way whatever the compiler would fuse on its own
+__device__ __forceinline__ float tap3(float w0, float w1, float w2, float a, float b, float c) { return __builtin_fmaf(w2, c, __builtin_fmaf(w1, b, w0 * a)); }
 
 template <typename ET, int VEC>
 struct Vec;
@@ -123,12 +128,12 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply(NhwcArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                float yt = wt[i][0] * prev[i] + wt[i][1] * cur[i] + wt[i][2] * next[i];
-                float yh = wh[i][0] * up[i] + wh[i][1] * cur[i] + wh[i][2] * dn[i];
-                float yw = ww[i][0] * lf[i] + ww[i][1] * cur[i] + ww[i][2] * rt[i];
+                float yt = tap3(wt[i][0], wt[i][1], wt[i][2], prev[i], cur[i], next[i]);
+                float yh = tap3(wh[i][0], wh[i][1], wh[i][2], up[i], cur[i], dn[i]);
+                float yw = tap3(ww[i][0], ww[i][1], ww[i][2], lf[i], cur[i], rt[i]);
                 float v = (yt + yh) + yw;
                 if (hs) {
-                    float u = sc[i] * v + sh[i];
+                    float u = __builtin_fmaf(sc[i], v, sh[i]);
                     v = u * (fminf(fmaxf(u + 3.0f, 0.0f), 6.0f) / 6.0f);
                 }
                 y[i] = v;
@@ -259,12 +264,12 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
                 for (int i = 0; i < VEC; ++i) {
                     const float pv = ok_pv ? cen[k][i] : 0.f, cu = cen[k + 1][i], nx = ok_nx ? cen[k + 2][i] : 0.f;
                     const float u_ = ok_up ? up[k][i] : 0.f, d_ = ok_dn ? dn[k][i] : 0.f, l_ = ok_lf ? lf[k][i] : 0.f, r_ = ok_rt ? rt[k][i] : 0.f;
-                    float yt = wt[i][0] * pv + wt[i][1] * cu + wt[i][2] * nx;
-                    float yh = wh[i][0] * u_ + wh[i][1] * cu + wh[i][2] * d_;
-                    float yw = ww[i][0] * l_ + ww[i][1] * cu + ww[i][2] * r_;
+                    float yt = tap3(wt[i][0], wt[i][1], wt[i][2], pv, cu, nx);
+                    float yh = tap3(wh[i][0], wh[i][1], wh[i][2], u_, cu, d_);
+                    float yw = tap3(ww[i][0], ww[i][1], ww[i][2], l_, cu, r_);
                     float v = (yt + yh) + yw;
                     if (hs) {
-                        float u = sc[i] * v + sh[i];
+                        float u = __builtin_fmaf(sc[i], v, sh[i]);
                         v = u * (fminf(fmaxf(u + 3.0f, 0.0f), 6.0f) / 6.0f);
                     }
                     if (a.add) v += ((mb[k] >> i) & 1u) ? ad[k][i] : 0.f;
@@ -310,6 +315,244 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
             }
         }
     }
+}
+
+// [r5] The same stencil through an LDS tile (bf16): the chunked kernel above needs every operand of a chunk in registers at once (66 8-byte loads in flight per
+// thread, 256 VGPRs + 44 AGPRs, ONE wave per SIMD) and still fetches every element 5.25 times through L1 -- 32 / 48 us per layer3 launch for 26 / 52 MB
+// (0.8 TB/s), three occupancy-1 rounds of "issue, wait, compute".  Here a workgroup owns (clip, band of RB rows, CW channels, ALL T frames): phase 1 copies the
+// band + one halo row on each side into LDS with 16-byte loads (<= 16 per thread, all in flight, rows clamped into the image), phase 2 gives every thread
+// (pixel, 4 channels) items that walk t with a (prev, cur, next) window and read the four in-plane neighbours from LDS (ds_read_b64, lanes along channels:
+// conflict-free).  The addend / gate bytes of an item are streamed from global memory, issued before the walk.  ~100 VGPRs, <= 64 KB of LDS: two workgroups per
+// CU, 448 workgroups on the 14 x 14 stages.  Same arithmetic, same order per output element: results bit-identical to the chunked kernel; the statistics'
+// partial rows follow this kernel's own grid (mvf_nhwc_stencil_stats_rows asks the same plan).
+// n / d for small n with host-made magic (as conv_nhwc.hip's fd_div): l = ceil(log2 d), mul = floor(2^32 (2^l - d) / d) + 1, q = (mulhi(n, mul) + n) >> l
+__device__ __forceinline__ int fdiv(int n, unsigned mul, unsigned shr) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shr); }
+inline void fdiv_make(unsigned d, unsigned& mul, unsigned& shr) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    shr = l;
+}
+
+template <int TT, int CW>
+__global__ __launch_bounds__(kThreads, 2) void mvf_nhwc_apply_lds(NhwcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds_tile[];
+    constexpr int VEC = 4, NG = CW / VEC, PPT = CW / 8;        // 4-channel groups per pixel, 16-byte pieces per pixel
+    const int W = a.w, H = a.h, HW = H * W, C = a.c, RB = a.rb, RP = RB + 2;
+    const int n = blockIdx.x / a.lbands, band = blockIdx.x % a.lbands;
+    const int cbase = blockIdx.y * CW, h0 = band * RB;
+    const int tid = threadIdx.x;
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(a.x);
+    bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+    // ---- phase 1: global -> LDS by LDS-DMA (no staging registers), piece index = ((t * RP + r) * W + w) * PPT + q, 16 bytes each; the LDS image is linear
+    // in it, so wave v's k-th instruction fills bytes [(k * 256 + 64 v) * 16, + 1 KiB).  Pieces past the tile read out of the descriptor's range (zeros).
+    {
+        const int npieces = TT * RP * W * PPT;
+        const bf16_t* clip = x + (long)n * TT * HW * C + cbase;
+        const i32x4 rs = rsrc_words(clip, (unsigned)(((long)TT * HW * C - cbase) * 2));
+        const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_tile + (unsigned)(tid >> 6) * 1024u));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (__builtin_amdgcn_readfirstlane(k * kThreads + (tid & ~63)) < npieces) {          // (wave-uniform)
+                const int idx = tid + k * kThreads;
+                const int q = idx % PPT, pw = idx / PPT;
+                const int t = fdiv(pw, a.fdrw_mul, a.fdrw_shr), rem = pw - t * RP * W;
+                const int r = fdiv(rem, a.fdw_mul, a.fdw_shr), w = rem - r * W;
+                int h = h0 - 1 + r;
+                h = h < 0 ? 0 : (h > H - 1 ? H - 1 : h);           // (rows outside the image are never used: ok_up / ok_dn below)
+                const unsigned voff = idx < npieces ? (unsigned)(((t * HW + h * W + w) * C + q * 8) * 2) : 0xffffffffu;
+                glds16(rs, lds0 + (unsigned)(k * kThreads * 16), voff);
+            }
+        }
+    }
+    // ---- per-thread constants: every item of a thread has the same channel group (kThreads % NG == 0)
+    const int g = tid % NG, c0 = cbase + g * VEC;
+    const bool vh = a.mode & MVF_VIEW_H, vw = a.mode & MVF_VIEW_W;
+    const bool hs = a.scale != nullptr;
+    float wt[VEC][3], wh[VEC][3], ww[VEC][3], sc[VEC], sh[VEC], st1[VEC], st2[VEC], kk[VEC], gmu[VEC], grs[VEC];
+    {
+        auto load12 = [&](const float* p, bool on, float (&dst)[VEC][3]) {
+            float f[12];
+            if (on) {
+                const float4 q0 = *reinterpret_cast<const float4*>(p + c0 * 3), q1 = *reinterpret_cast<const float4*>(p + c0 * 3 + 4),
+                             q2 = *reinterpret_cast<const float4*>(p + c0 * 3 + 8);
+                f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w; f[4] = q1.x; f[5] = q1.y; f[6] = q1.z; f[7] = q1.w;
+                f[8] = q2.x; f[9] = q2.y; f[10] = q2.z; f[11] = q2.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) f[k] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                dst[i][0] = a.flip ? f[i * 3 + 2] : f[i * 3];
+                dst[i][1] = f[i * 3 + 1];
+                dst[i][2] = a.flip ? f[i * 3] : f[i * 3 + 2];
+            }
+        };
+        load12(a.wt, true, wt);
+        load12(a.wh, vh, wh);
+        load12(a.ww, vw, ww);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sc[i] = hs ? a.scale[c0 + i] : 1.f;
+            sh[i] = hs ? a.shift[c0 + i] : 0.f;
+            st1[i] = st2[i] = 0.f;
+            kk[i] = (a.stats_part && a.stats_shift) ? a.stats_shift[c0 + i] : 0.f;
+            gmu[i] = a.gs_z ? a.gs_mean[c0 + i] : 0.f;
+            grs[i] = a.gs_z ? a.gs_invstd[c0 + i] : 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- phase 2
+    const bf16_t* tile = reinterpret_cast<const bf16_t*>(lds_tile);
+    const int nitems = RB * W * NG;
+    const int fs = RP * W * CW;                                    // one frame of the tile, in elements
+#pragma unroll 1
+    for (int it = tid; it < nitems; it += kThreads) {
+        const int p = it / NG, r = fdiv(p, a.fdw_mul, a.fdw_shr), w = p - r * W, h = h0 + r;
+        if (h >= H) break;                                         // (items are ordered by row: the rest of this thread's items are below the image too)
+        const long pix0 = (long)n * TT * HW + h * W + w;           // (n, t = 0, h, w)
+        constexpr int TC = 4;                                      // frames per batch of streamed operands (addend, gate bytes, bn_z): one batch ahead
+        struct Side { uint2 ad[TC], zz[TC]; unsigned mb[TC], gb[TC]; };
+        auto load_side = [&](int tc, Side& sd) {
+#pragma unroll
+            for (int k = 0; k < TC; ++k) {
+                const long apix = pix0 + (long)(tc + k) * HW;
+                sd.mb[k] = 0xfu;
+                sd.gb[k] = 0xfu;
+                sd.ad[k] = make_uint2(0u, 0u);
+                sd.zz[k] = make_uint2(0u, 0u);
+                if (a.gs_z) sd.zz[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.gs_z) + apix * a.out_c + c0);
+                if (a.add) {
+                    sd.ad[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.add) + apix * a.add_c + c0);
+                    if (a.add_mask) sd.mb[k] = a.add_mask[apix * (a.add_c / 4) + c0 / 4];
+                }
+                if (a.out_gate) sd.gb[k] = a.out_gate[apix * (a.out_c / 4) + c0 / 4];
+            }
+        };
+        Side sd, sn;
+        load_side(0, sd);
+        const bool ok_up = vh && h > 0, ok_dn = vh && h < H - 1, ok_lf = vw && w > 0, ok_rt = vw && w < W - 1;
+        const bf16_t* ctr = tile + ((r + 1) * W + w) * CW + g * VEC;   // (t = 0, this pixel)
+        const int d_up = ok_up ? -W * CW : 0, d_dn = ok_dn ? W * CW : 0, d_lf = ok_lf ? -CW : 0, d_rt = ok_rt ? CW : 0;
+        float4 prev = make_float4(0.f, 0.f, 0.f, 0.f), cur = ld4(ctr);
+        const int t_end = a.T;                                     // (== TT; a run-time bound keeps the batches a loop: unrolled, two batches of operands per frame group stay live)
+#pragma unroll 1
+        for (int tc = 0; tc < t_end; tc += TC) {
+            if (tc + TC < t_end) load_side(tc + TC, sn);
+#pragma unroll
+            for (int k = 0; k < TC; ++k) {
+                const int t = tc + k;
+                const bf16_t* f = ctr + t * fs;
+                float4 next = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t + 1 < t_end) next = ld4(f + fs);
+                const float4 u4 = ld4(f + d_up), d4 = ld4(f + d_dn), l4 = ld4(f + d_lf), r4 = ld4(f + d_rt);
+                const float pv[VEC] = {prev.x, prev.y, prev.z, prev.w}, cu[VEC] = {cur.x, cur.y, cur.z, cur.w}, nx[VEC] = {next.x, next.y, next.z, next.w};
+                const float uu[VEC] = {u4.x, u4.y, u4.z, u4.w}, dd[VEC] = {d4.x, d4.y, d4.z, d4.w}, ll[VEC] = {l4.x, l4.y, l4.z, l4.w}, rr[VEC] = {r4.x, r4.y, r4.z, r4.w};
+                const float av[VEC] = {__uint_as_float(sd.ad[k].x << 16), __uint_as_float(sd.ad[k].x & 0xffff0000u), __uint_as_float(sd.ad[k].y << 16),
+                                       __uint_as_float(sd.ad[k].y & 0xffff0000u)};
+                float y[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float u_ = ok_up ? uu[i] : 0.f, d_ = ok_dn ? dd[i] : 0.f, l_ = ok_lf ? ll[i] : 0.f, r_ = ok_rt ? rr[i] : 0.f;
+                    float yt = tap3(wt[i][0], wt[i][1], wt[i][2], pv[i], cu[i], nx[i]);
+                    float yh = tap3(wh[i][0], wh[i][1], wh[i][2], u_, cu[i], d_);
+                    float yw = tap3(ww[i][0], ww[i][1], ww[i][2], l_, cu[i], r_);
+                    float v = (yt + yh) + yw;
+                    if (hs) {
+                        float u = __builtin_fmaf(sc[i], v, sh[i]);
+                        v = u * (fminf(fmaxf(u + 3.0f, 0.0f), 6.0f) / 6.0f);
+                    }
+                    if (a.add) v += ((sd.mb[k] >> i) & 1u) ? av[i] : 0.f;
+                    y[i] = ((sd.gb[k] >> i) & 1u) ? v : 0.f;
+                }
+                st4(out + (pix0 + (long)t * HW) * a.out_c + c0, make_float4(y[0], y[1], y[2], y[3]));
+                if (a.stats_part) {                                // statistics of what is STORED
+                    const float zv[VEC] = {__uint_as_float(sd.zz[k].x << 16), __uint_as_float(sd.zz[k].x & 0xffff0000u), __uint_as_float(sd.zz[k].y << 16),
+                                           __uint_as_float(sd.zz[k].y & 0xffff0000u)};
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float v = bf16_to_f32(f32_to_bf16(y[i]));
+                        if (a.gs_z) {                              // BatchNorm-backward sums of the gated output
+                            st1[i] += v;
+                            st2[i] += v * ((zv[i] - gmu[i]) * grs[i]);
+                        } else {
+                            const float dlt = v - kk[i];
+                            st1[i] += dlt;
+                            st2[i] += dlt * dlt;
+                        }
+                    }
+                }
+                prev = cur;
+                cur = next;
+            }
+            sd = sn;
+        }
+    }
+    if (a.stats_part) {
+        __syncthreads();                                           // the tile is dead: its first bytes carry the reduction
+        float* red = reinterpret_cast<float*>(lds_tile);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            red[(tid * VEC + i) * 2] = st1[i];
+            red[(tid * VEC + i) * 2 + 1] = st2[i];
+        }
+        __syncthreads();
+        if (tid < NG) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll 4
+                for (int q = 0; q < kThreads / NG; ++q) {           // the threads of this channel group, in order
+                    t1 += red[((q * NG + tid) * VEC + i) * 2];
+                    t2 += red[((q * NG + tid) * VEC + i) * 2 + 1];
+                }
+                reinterpret_cast<float2*>(a.stats_part)[(long)(c0 + i) * gridDim.x + blockIdx.x] = make_float2(t1, t2);
+            }
+        }
+    }
+}
+
+struct LdsPlan { int rb, cw, bands; size_t lds; };
+// the LDS-tiled kernel's plan: the widest channel chunk (64 / 32 / 16) whose band of >= 2 rows (or the whole image) + halo fits 64 KB over all T frames, taken when
+// it makes >= MVF_STENCIL_LDS_MINWG (400) workgroups; a stage whose whole planes fit (7 x 7: 128 workgroups) may halve the budget once if the chunk stays 64 wide.
+// Everything smaller stays on the chunked kernel: with few workgroups the two-phase tile (load all, then compute) has nothing to overlap with.  Measured in the
+// step (ms, chunked / tiled): C3 18.52 / 18.24-18.29, C4 31.30 / 31.03-31.05; 12 clips 9.38 / 9.42 and 16-clip inference chains 4.04 / 4.15 with tiles forced
+// on them -- which this rule leaves on the chunked kernel.
+static bool lds_plan(int T, int H, int W, int cs, int n_clips, LdsPlan& best) {
+    static const int on = getenv("MVF_STENCIL_LDS") ? atoi(getenv("MVF_STENCIL_LDS")) : 1;
+    static const int min_wg = getenv("MVF_STENCIL_LDS_MINWG") ? atoi(getenv("MVF_STENCIL_LDS_MINWG")) : 400;
+    if (!on || (T != 4 && T != 8 && T != 16)) return false;
+    auto bytes = [&](int rb, int cw) { return (((size_t)T * (rb + 2) * W * cw * 2 / 16 + 63) / 64) * 1024; };      // whole 64-piece DMA instructions
+    for (size_t budget = 65536; budget >= 32768; budget >>= 1) {
+        for (int cw = 64; cw >= 16; cw >>= 1) {
+            if (cs % cw) continue;
+            int rb = 0;
+            for (int cand = std::min(H, 8); cand >= 1; --cand)
+                if (bytes(cand, cw) <= budget) { rb = cand; break; }
+            if (!(rb >= 2 || (rb >= 1 && rb == H))) continue;
+            // even bands: the same number of them with the fewest rows each (a 14-row image in bands of 4 would end on a 2-row band)
+            const int bands = (H + rb - 1) / rb;
+            rb = (H + bands - 1) / bands;
+            const LdsPlan p = {rb, cw, bands, bytes(rb, cw)};
+            if (p.lds < (size_t)kThreads * 4 * 2 * sizeof(float)) continue;      // (the statistics' reduction reuses the tile)
+            if ((long)n_clips * bands * (cs / cw) >= min_wg && (budget == 65536 || cw == 64)) {
+                best = p;
+                return true;
+            }
+            break;
+        }
+    }
+    return false;
+}
+
+template <int TT>
+static void launch_lds(const NhwcArgs& a, const LdsPlan& p, hipStream_t st) {
+    dim3 grid(a.n_clips * p.bands, a.cs / p.cw);
+    if (p.cw == 64) hipLaunchKernelGGL((mvf_nhwc_apply_lds<TT, 64>), grid, dim3(kThreads), p.lds, st, a);
+    else if (p.cw == 32) hipLaunchKernelGGL((mvf_nhwc_apply_lds<TT, 32>), grid, dim3(kThreads), p.lds, st, a);
+    else hipLaunchKernelGGL((mvf_nhwc_apply_lds<TT, 16>), grid, dim3(kThreads), p.lds, st, a);
 }
 
 // copy channels [cs, c) of every pixel (out != x case)
@@ -372,12 +615,33 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     static const int tsplit_env = getenv("MVF_STENCIL_TSPLIT") ? atoi(getenv("MVF_STENCIL_TSPLIT")) : 0;
     a.tsplit = tsplit_env != 0 && a.T > 1;
     dim3 grid(a.n_clips * a.bands, (a.cg + cgp - 1) / cgp, a.tsplit ? a.T : 1);
+    // [r5] bf16: the LDS-tiled kernel wherever its plan exists
+    LdsPlan lp = {};
+    // (the plan depends on the shape only -- mvf_nhwc_stencil_stats_rows must name the same partial rows as the launch; operands that break its alignment
+    // rules fall back to the chunked kernel, which is an error when partial rows were asked for)
+    const bool lds_shape = d->dtype == MVF_BF16 && d->cs % 16 == 0 && d->c % 8 == 0 && out_c % 4 == 0 && (!fl.add || fl.add_c % 4 == 0) && !a.tsplit &&
+                           lds_plan(a.T, d->h, d->w, d->cs, a.n_clips, lp);
+    const bool use_lds = lds_shape && vec && (uintptr_t)x % 16 == 0 && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0 &&
+                         (!fl.gs_z || (uintptr_t)fl.gs_z % 8 == 0);
+    MVF_REQUIRE(use_lds || !lds_shape || !fl.stats_part, MVF_EINVAL, "nhwc_stencil: operands of a statistics launch must be 16-byte aligned (x, taps) / 8-byte (out, addend, bn_z)");
+    if (use_lds) {
+        if (fl.rows_only) return a.n_clips * lp.bands;
+        a.rb = lp.rb; a.cw = lp.cw; a.lbands = lp.bands;
+        fdiv_make((unsigned)d->w, a.fdw_mul, a.fdw_shr);
+        fdiv_make((unsigned)((lp.rb + 2) * d->w), a.fdrw_mul, a.fdrw_shr);
+        if (a.T == 4) launch_lds<4>(a, lp, st);
+        else if (a.T == 8) launch_lds<8>(a, lp, st);
+        else launch_lds<16>(a, lp, st);
+        MVF_LAUNCH_CHECK();
+    }
     if (fl.rows_only) return (int)grid.x;                  // mvf_nhwc_stencil_stats_rows: the partial-row count of this plan, nothing is launched
     // [r3] all of a chunk's loads in flight at once instead of the serial walk over t (MVF_STENCIL_CHUNKED=0: the walk)
     static const int chunked_env = getenv("MVF_STENCIL_CHUNKED") ? atoi(getenv("MVF_STENCIL_CHUNKED")) : 1;
     const bool chunked = chunked_env != 0 && vec && !a.tsplit && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0;
     MVF_REQUIRE(!fl.stats_part || chunked, MVF_EUNSUPPORTED, "nhwc_stencil_stats: needs the chunked 4-channel kernel (cs, pitches %% 4 == 0, 16-byte aligned taps, MVF_STENCIL_CHUNKED != 0)");
-    if (d->dtype == MVF_F32) {
+    if (use_lds) {
+        // launched above
+    } else if (d->dtype == MVF_F32) {
         if (chunked) hipLaunchKernelGGL((mvf_nhwc_apply_chunked<float, 4>), grid, dim3(kThreads), 0, st, a);
         else if (vec) hipLaunchKernelGGL((mvf_nhwc_apply<float, 4>), grid, dim3(kThreads), 0, st, a);
         else hipLaunchKernelGGL((mvf_nhwc_apply<float, 1>), grid, dim3(kThreads), 0, st, a);
