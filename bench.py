@@ -256,6 +256,10 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         m, c, k = d.n * d.h * d.w, self.cout, self.cin
         return (2.0 * m * c * k, "wgrad M%d N%d K%d s1 (launch stream)" % (m, c, k), esz * m * (c + k) + 4 * self.w.numel())
 
+    def dwgg(self, out, d, a_in, gram, ws, wgs):      # [r5] the Gram matrix a2^T a2 of conv3's input on the launch stream: bn3's batch statistics without a conv3 pass (gram_stats)
+        m, k = d.n * d.h * d.w, self.cin
+        return (2.0 * m * k * k, "gram  M%d K%d (launch stream, bn3 statistics)" % (m, k), esz * m * k + 4 * k * k)
+
     # BatchNorm streaming kernels: tensors read + written (the sign-bit byte per 4 channels where it is used)
     def dbap(self, out, z, m, act, residual=None, rbn=None, bits=False):
         nb = esz * m * self.c * (3 if residual is not None else 2) + (m * self.c // 4 if bits else 0)
@@ -294,7 +298,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
 
     undo = [tc.wrap(TE._TConv, "launch_fwd", dfwd), tm.wrap(TE._TMvf, "launch_stencil_stats", dmvs), tc.wrap(TE._TConv, "launch_fwd_apply", dfap), tc.wrap(TE._TConv, "launch_bwd_sums", dbws), tc.wrap(TE._TConv, "launch_bwd_apply", dbwa),
             tc.wrap(TE._TConv, "dgrad", ddgr), tc.wrap(TE._TConv, "launch_dgrad_bnsums", ddgb), tc.wrap(TE._TConv, "launch_dzfree_dgrad", ddzf), tc.wrap(TE._TConv, "launch_bwd_fused", dbwf), tc.wrap(TE._TBlock, "launch_sums_pair", dbsp), tc.wrap(TE._TConv, "launch_bwd_sums1", dbs1),
-            tw.wrap(TE._TConv, "wgrad", dwgr), tw.wrap(TE._TConv, "launch_q", dwgq), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
+            tw.wrap(TE._TConv, "wgrad", dwgr), tw.wrap(TE._TConv, "launch_q", dwgq), tw.wrap(TE._TConv, "launch_gram", dwgg), tb.wrap(TE._BN, "apply", dbap), tb.wrap(TE._BN, "_reduce", dbre), tb.wrap(TE._BN, "_apply_bwd", dbab),
             tb.wrap(TE._BN, "backward_pair", dbpr),
             tm.wrap(TE._TMvf, "launch_stencil", dmvf), tf.wrap(TE._BN, "_apply_bwd_wgrad", dbaw), tf.wrap(TE._BN, "backward_pair_wgrad", dbpw)]
     overlap = eng.overlap_wgrad

@@ -274,6 +274,13 @@ int mvf_bn_train_stats(const void* z, long m, int c, const float* gamma, const f
 int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const float* gamma, const float* beta, float eps,
                           float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                           float* scale, float* shift, void* stream);
+/* [r5] The same outputs for z = a W^T, the output of a POINTWISE conv (Bottleneck.conv3 -> norm3, resnet.py:236-237), WITHOUT computing z: mean_c = W[c].abar,
+ * var_c = W[c] (A2 / m - abar abar^T) W[c]^T from the Gram matrix gram [k][k] = a^T a of the conv's input (mvf_conv2d_nhwc_wgrad with dz = x = a), its
+ * column means a_mean [k] (mvf_bn_train_stats on a) and the forward pack w_packed [c][k].  Replaces the statistics pass of a block that applies this
+ * BatchNorm in a second conv pass (mvf_conv2d_nhwc_fwd_bnapply); the dz3-free backward reuses gram / a_mean.  bf16 storage, c and k multiples of 32. */
+int mvf_bn_train_stats_gram(const float* gram, const float* a_mean, const void* w_packed, long m, int c, int k, const float* gamma, const float* beta,
+                            float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
+                            float* shift, int dtype, void* stream);
 /* out = act(z*scale + shift [+ residual | + residual*rscale + rshift]); act: 0 none, 1 ReLU, 2 hard-swish */
 int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
                  const float* rscale, const float* rshift, int act, void* out, int dtype, void* stream);

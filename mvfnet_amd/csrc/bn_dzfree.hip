@@ -226,9 +226,107 @@ __global__ __launch_bounds__(256) void dzfree_sums_kernel(const float* q, const 
     }
 }
 
+// [r5] BatchNorm batch statistics of z = a W^T (a pointwise conv's output) WITHOUT the conv: sum_m z[m][c] = M W[c].abar and
+// sum_m (z[m][c] - mean_c)^2 = M W[c] Gc W[c]^T with Gc = A2 / M - abar abar^T, A2 = a^T a the Gram matrix of the conv's (narrow) input and abar its column
+// means.  One wave per 32 channels: T = W Gc on the matrix cores (Gc centred element by element in fp32, then split into three bf16 terms: 24 bits), the row-wise
+// dot with W and the reduction over k by shuffles; then what bn_stats_finalize_kernel does (train_ops.hip): save_mean / save_invstd / scale / shift and the
+// running statistics (unbiased variance).  The statistics are those of the UNROUNDED z (the stored-z path measures the bf16-rounded tensor: 1e-6 apart).
+struct GramStatsArgs {
+    const float* gram; const float* a_mean; const uint16_t* w; const float* gamma; const float* beta;
+    float* running_mean; float* running_var; float* save_mean; float* save_invstd; float* scale; float* shift;
+    int C, K; float inv_m, eps, momentum, unbias;
+};
+__global__ __launch_bounds__(256) void gram_stats_kernel(GramStatsArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, K = p.K;
+    const int blk = blockIdx.x * 4 + wave;
+    if (blk >= p.C / 32) return;
+    const int c0 = blk * 32, row = lane & 31, half = lane >> 5;
+    const uint16_t* pw = p.w + (long)(c0 + row) * K + half * 8;
+    float qacc[16], macc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) qacc[r] = macc[r] = 0.f;
+    for (int kb = 0; kb < K / 32; ++kb) {
+        const int k = kb * 32 + row;
+        const float* pg = p.gram + (long)k * K + half * 8;
+        const float* pa = p.a_mean + half * 8;
+        const float ak = p.a_mean[k];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int j = 0; j < K; j += 16) {
+            const uint4 vw = *reinterpret_cast<const uint4*>(pw + j);
+            const float4 g0 = *reinterpret_cast<const float4*>(pg + j), g1 = *reinterpret_cast<const float4*>(pg + j + 4);
+            const float4 a0 = *reinterpret_cast<const float4*>(pa + j), a1 = *reinterpret_cast<const float4*>(pa + j + 4);
+            float gc[8] = {g0.x * p.inv_m - ak * a0.x, g0.y * p.inv_m - ak * a0.y, g0.z * p.inv_m - ak * a0.z, g0.w * p.inv_m - ak * a0.w,
+                           g1.x * p.inv_m - ak * a1.x, g1.y * p.inv_m - ak * a1.y, g1.z * p.inv_m - ak * a1.z, g1.w * p.inv_m - ak * a1.w};
+            unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x0 = gc[2 * q], x1 = gc[2 * q + 1];
+                hi[q] = pack_bf16x2(x0, x1);
+                const float r0 = x0 - bf16lo(hi[q]), r1 = x1 - bf16hi(hi[q]);
+                mid[q] = pack_bf16x2(r0, r1);
+                lo[q] = pack_bf16x2(r0 - bf16lo(mid[q]), r1 - bf16hi(mid[q]));
+            }
+            bf16x8 fw, fh, fm, fl;
+            __builtin_memcpy(&fw, &vw, 16);
+            __builtin_memcpy(&fh, hi, 16);
+            __builtin_memcpy(&fm, mid, 16);
+            __builtin_memcpy(&fl, lo, 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fh, acc, 0, 0, 0);       // D[row c = 8 (r >> 2) + 4 half + (r & 3)][col k = lane & 31]
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fl, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            const float wv = __uint_as_float((unsigned)p.w[(long)c * K + k] << 16);
+            qacc[r] += acc[r] * wv;
+            macc[r] += wv * ak;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {          // over the 32 lanes (k columns) of this half: fixed order
+            qacc[r] += __shfl_xor(qacc[r], o, 64);
+            macc[r] += __shfl_xor(macc[r], o, 64);
+        }
+    }
+    if (row == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            const float mean = macc[r], var = fmaxf(qacc[r], 0.f);
+            const float invstd = 1.0f / sqrtf(var + p.eps);
+            p.save_mean[c] = mean;
+            p.save_invstd[c] = invstd;
+            const float s = p.gamma[c] * invstd;
+            p.scale[c] = s;
+            p.shift[c] = p.beta[c] - mean * s;
+            if (p.running_mean) p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+            if (p.running_var) p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (var * p.unbias);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int mvf_bn_train_stats_gram(const float* gram, const float* a_mean, const void* w_packed, long m, int c, int k, const float* gamma, const float* beta, float eps,
+                            float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift,
+                            int dtype, void* stream) {
+    MVF_REQUIRE(gram && a_mean && w_packed && gamma && beta && save_mean && save_invstd && scale && shift && m > 0, MVF_EINVAL, "bn_train_stats_gram: NULL argument");
+    MVF_REQUIRE(dtype == MVF_BF16, MVF_EUNSUPPORTED, "bn_train_stats_gram: bf16 storage only");
+    MVF_REQUIRE(c > 0 && k > 0 && c % 32 == 0 && k % 32 == 0, MVF_ESHAPE, "bn_train_stats_gram: c=%d and k=%d must be multiples of 32", c, k);
+    MVF_REQUIRE(((uintptr_t)gram | (uintptr_t)a_mean | (uintptr_t)w_packed) % 16 == 0, MVF_EINVAL, "bn_train_stats_gram: operands must be 16-byte aligned");
+    GramStatsArgs p = {gram, a_mean, (const uint16_t*)w_packed, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                       c, k, 1.0f / (float)m, eps, momentum, (float)((double)m / (double)(m > 1 ? m - 1 : 1))};
+    hipLaunchKernelGGL(gram_stats_kernel, dim3((c / 32 + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
 
 int mvf_bn_bwd_dzfree_sums(const float* q, const void* w_packed, int c, int k, const float* mean, const float* invstd, const float* part_lo, int rows_lo,
                            int c_split, const float* part_hi, int rows_hi, float* dgamma, float* dbeta, int dtype, void* stream) {

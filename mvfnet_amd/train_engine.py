@@ -537,7 +537,37 @@ class _TConv(object):
         check(lib.mvf_conv2d_nhwc_wgrad_wgs(C.byref(d), _p(gm), _p(a_in), None, self.kw, self.cin, self.kw, self.cin, _p(self.dw), _p(ws), ws.numel(), wgs, _st()),
               "conv wgrad (launch stream)")
 
-    def dzfree_wgrad(self, gm, a_in, bn, n, h, w, eng, frozen_zero=None, q_done=False):
+    def gram_ok(self):
+        """The shapes mvf_bn_train_stats_gram and its Gram GEMM take: a pointwise stride-1 conv in bf16 storage, channel counts in whole MFMA tiles."""
+        return (self.eng.tdtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and self.stride == 1 and not self.stem and
+                self.cin % 32 == 0 and self.cout % 32 == 0)
+
+    def gram_stats(self, a_in, bn, n, h, w, eng):
+        """[r5] bn's batch statistics of z = conv(a_in) WITHOUT the conv (csrc/bn_dzfree.hip: mvf_bn_train_stats_gram): the Gram matrix of a_in (one
+        k x k GEMM over the narrow tensor), its column means, and a c x k x k quadratic form.  gram / a_mean stay in their per-conv buffers: the dz3-free
+        backward's weight-gradient correction needs exactly these (dzfree_wgrad(gram_done=True))."""
+        c, k, m = self.cout, self.cin, n * h * w
+        gram = eng.buf((id(self), "gram"), (k, k), torch.float32)
+        amean = eng.buf((id(self), "amean"), (4, k), torch.float32)            # rows: mean, and three outputs of the statistics call nobody reads
+        d = ConvDesc(n, h, w, k, k, 1, 1, 1, 0, h, w, k, eng.dt, 0, 0, 0, 0)
+        ws = eng.workspace(max(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)), lib.mvf_bn_workspace_bytes(m, k), (eng.gram_stats_wgs + 8) * k * k * 4))
+        if k not in eng._ones:
+            eng._ones[k] = (torch.ones(k, device=a_in.device), torch.zeros(k, device=a_in.device))
+        one, zero = eng._ones[k]
+        self.launch_gram(d, a_in, gram, ws, eng.gram_stats_wgs)
+        check(lib.mvf_bn_train_stats(_p(a_in), m, k, _p(one), _p(zero), C.c_float(1e-5), C.c_float(0.1), None, None, _p(amean[0]), _p(amean[1]),
+                                     _p(amean[2]), _p(amean[3]), _p(ws), ws.numel(), eng.dt, _st()), "column means")
+        check(lib.mvf_bn_train_stats_gram(_p(gram), _p(amean[0]), _p(self.wp), m, c, k, _p(bn.gamma), _p(bn.beta), C.c_float(bn.eps), C.c_float(bn.momentum),
+                                          _p(bn.mod.running_mean), _p(bn.mod.running_var), _p(bn.mean), _p(bn.invstd), _p(bn.scale), _p(bn.shift), eng.dt,
+                                          _st()), "bn statistics from the Gram matrix")
+        bn._count()
+
+    def launch_gram(self, d, a_in, gram, ws, wgs):
+        """One k x k GEMM a^T a (+ its slab reduce) on the launch stream (bench.py brackets this call with HIP events)."""
+        k = self.cin
+        check(lib.mvf_conv2d_nhwc_wgrad_wgs(C.byref(d), _p(a_in), _p(a_in), None, 1, k, 1, k, _p(gram), _p(ws), ws.numel(), wgs, _st()), "gram (launch stream)")
+
+    def dzfree_wgrad(self, gm, a_in, bn, n, h, w, eng, frozen_zero=None, q_done=False, gram_done=False):
         """dW = dz^T a_in without dz: Q = gm^T a_in (the usual weight-gradient GEMM, into dw), A2 = a_in^T a_in and the column means of a_in, then the
         correction kernel -- all on the side stream (they only feed the optimizer)."""
         c, k, m = self.cout, self.cin, n * h * w
@@ -555,9 +585,10 @@ class _TConv(object):
         ws = eng.workspace(nbytes, side=side is not None)
 
         def launch():
-            check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(a_in), _p(a_in), None, 1, k, 1, k, _p(gram), _p(ws), ws.numel(), _st()), "gram")
-            check(lib.mvf_bn_train_stats(_p(a_in), m, k, _p(one), _p(zero), C.c_float(1e-5), C.c_float(0.1), None, None, _p(amean[0]), _p(amean[1]),
-                                         _p(amean[2]), _p(amean[3]), _p(ws), ws.numel(), eng.dt, _st()), "column means")
+            if not gram_done:      # (the forward's statistics already left both in place: gram_stats)
+                check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d), _p(a_in), _p(a_in), None, 1, k, 1, k, _p(gram), _p(ws), ws.numel(), _st()), "gram")
+                check(lib.mvf_bn_train_stats(_p(a_in), m, k, _p(one), _p(zero), C.c_float(1e-5), C.c_float(0.1), None, None, _p(amean[0]), _p(amean[1]),
+                                             _p(amean[2]), _p(amean[3]), _p(ws), ws.numel(), eng.dt, _st()), "column means")
             check(lib.mvf_bn_bwd_dzfree_wgrad(_p(self.dw), _p(self.wp), _p(gram), _p(amean[0]), _p(bn.gamma), _p(bn.mean), _p(bn.invstd), _p(sg), _p(sb),
                                               m, c, k, eng.dt, _st()), "weight gradient without dz: correction")
         if side is None:
@@ -733,12 +764,20 @@ class _TBlock(object):
             return False
         return eng.dzfree == 2 or self.c3.cin >= 256
 
+    def gram_fwd(self, eng, m2):
+        """[r5] bn3's batch statistics from the Gram matrix of a2 instead of a conv3 pass (eng.gram_stats): blocks that apply bn3 in a second conv3 pass
+        (fuse_apply) and never read z3 in backward -- the z3-free blocks of layer1, and the dz3-free blocks whose sums come from Q (q_z3_free)."""
+        if not (eng.gram_stats and eng.tdtype == torch.bfloat16 and self.cd is None and self.c3.gram_ok() and self.fuse_apply(eng) and eng.fuse_stats and
+                not self.b3.frozen and eng.z3_free):
+            return False
+        return self.z3_free(eng, m2)
+
     def q_z3_free(self, eng, m2):
         """[r5] A dz3-free block whose bn3 sums come from the producers' column sums + Q (dzfree_q) reads z3 nowhere in backward, so where bn3's apply
         already is a second conv3 pass (fuse_apply) the first pass need not store it (eng.dzfree_q_z3free).  Decided at forward time; should the block
         above not deliver the column sums after all, backward falls back to bn3's backward on the recomputed conv."""
-        return bool(eng.dzfree_q_z3free and eng.gate_producer and not eng.gate_sums and self.above is not None and not self.b3.frozen and self.fuse_apply(eng)
-                    and self._dzfree_base(eng, m2) and self.q_policy(eng, m2))
+        return bool((eng.dzfree_q_z3free or (eng.gram_stats and self.c3.gram_ok())) and eng.gate_producer and not eng.gate_sums and self.above is not None and
+                    not self.b3.frozen and self.fuse_apply(eng) and self._dzfree_base(eng, m2) and self.q_policy(eng, m2))
 
     def dzfree(self, eng, m2=None):
         """[r5] bn3's backward without the dz3 tensor (csrc/bn_dzfree.hip): plain blocks (no downsample branch) with a STORED z3 whose last conv
@@ -798,7 +837,12 @@ class _TBlock(object):
         z2, ho, wo = self.c2.forward(a1, nt, h, w, bn=self.b2)
         m2 = nt * ho * wo
         a2 = self.b2.apply(z2, m2, 1)
-        z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3, store=not self.z3_free(eng, m2))
+        gram = self.gram_fwd(eng, m2)
+        if gram:           # [r5] no first conv3 pass at all: bn3's statistics from the Gram matrix of a2
+            self.c3.gram_stats(a2, self.b3, nt, ho, wo, eng)
+            z3 = None
+        else:
+            z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3, store=not self.z3_free(eng, m2))
         if self.cd is not None:
             if side is not None:
                 eng.main_stream().wait_stream(side)               # the downsample branch (queued before conv1, see above)
@@ -813,7 +857,7 @@ class _TBlock(object):
             out, bits = self.c3.forward_apply(a2, nt, ho, wo, self.b3, x)
         else:
             out, bits = self.b3.apply(z3, m2, 1, residual=x, bits=True)
-        s.update(z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, out=out, bits=bits, ho=ho, wo=wo)
+        s.update(z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, out=out, bits=bits, ho=ho, wo=wo, gram=gram)
         self.saved = s
         return out, ho, wo, self.c3.cout
 
@@ -882,7 +926,7 @@ class _TBlock(object):
                 b3._reduce(g, self.c3.cout, s["z3"], m2, eng, 4, bits, gm)
             fz = b3._zero if b3.frozen else None
             da2 = self.c3.dzfree_dgrad(gm, s["a2"], b3, nt, ho, wo, self.b2, s["z2"], frozen_zero=fz)
-            self.c3.dzfree_wgrad(gm, s["a2"], b3, nt, ho, wo, eng, frozen_zero=fz, q_done=q_done)
+            self.c3.dzfree_wgrad(gm, s["a2"], b3, nt, ho, wo, eng, frozen_zero=fz, q_done=q_done, gram_done=bool(s.get("gram")))
             dz3, w3_done = None, True
             del gm
         elif (eng.fuse_bnwg & 1) and self.c3.fuses_wgrad(eng, m2, self.c3.cout, 4):
@@ -1100,6 +1144,10 @@ class _ParamStore(object):
     # ... and such a block need not store z3 where bn3's apply is a second conv3 pass (_TBlock.q_z3_free: layer2's plain blocks).  Measured (ms, off / on, three
     # alternations): C3 17.93-17.95 / 17.96-17.99, C4 30.43-30.47 / 30.45-30.69 -- the statistics-only pass is no shorter in the step than the storing one; off.
     dzfree_q_z3free = os.environ.get("MVF_DZFREE_Q_Z3FREE", "0") != "0"
+    # [r5] gram_stats: bn3's batch statistics of a block that applies bn3 in a second conv3 pass from the Gram matrix of a2 (_TBlock.gram_fwd) -- the first
+    # conv3 pass (statistics only in layer1, z3-storing in layer2) disappears; 0 = off.  gram_stats_wgs: the workgroup count of that GEMM on the launch stream.
+    gram_stats = os.environ.get("MVF_GRAM_STATS", "1") != "0"
+    gram_stats_wgs = int(os.environ.get("MVF_GRAM_STATS_WGS", "256"))
 
     def side_stream(self):
         if not self.overlap_wgrad:

@@ -351,8 +351,11 @@ def test_full_size_bf16_train_step_properties(cfg):
     rel = np.abs(n3 - n1) / np.maximum(n1, 1e-12)
     print("R%d T=%d x %d clips, permutation: loss %.6f vs %.6f, grad-norm rel diff median %.2e max %.2e" % (depth, T, clips, float(l1), float(l3), np.median(rel), rel.max()))
     assert abs(float(l3) - float(l1)) < 1e-3 * abs(float(l1))               # measured 3e-5
-    # measured C3: median 6e-3, max 0.11 (a re-ordered sum re-diverges to the bf16 floor); the 33-block R101 amplifies that further
-    assert np.median(rel) < (2e-2 if depth == 50 else 5e-2) and rel.max() < (0.25 if depth == 50 else 0.5)
+    # measured C3: median 6e-3, max 0.11 (a re-ordered sum re-diverges to the bf16 floor); the 33-block R101 amplifies that further.  [r5] with bn3's
+    # statistics of the z3-free blocks from the Gram matrix of a2 (eng.gram_stats) a re-ordering moves those statistics by ONE fp32 ulp (5e-8: measured at full
+    # size, profiles/r05_gram_stats.txt; they are at fp32 epsilon against fp64) where the pass they replace, which reduces its partial rows in double, did not
+    # move at all -- and the network amplifies that ulp like any other perturbation: median 1.8e-2, max 0.29 on C3 (5.9e-3 / 0.086 with MVF_GRAM_STATS=0)
+    assert np.median(rel) < (4e-2 if depth == 50 else 6e-2) and rel.max() < 0.5
     eng.step()
     l4 = eng.forward(imgs[perm].contiguous(), labels[perm].contiguous())
     assert float(l4) < float(l3)

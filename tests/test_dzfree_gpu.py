@@ -389,6 +389,7 @@ def test_two_block_backward_with_sums_from_the_weight_gradient_gemm(shape):
         tr = BlockTrainer(seq, dtype=torch.bfloat16)
         tr.dzfree_q = mode
         tr.dzfree_q_z3free = True          # (off by default: measured neutral)
+        tr.gram_stats = False              # (the forward stays the same in both modes; the Gram statistics have their own test below)
         x = torch.relu(torch.randn(8, cin, hw, hw, device="cuda"))
         dy = torch.randn(8, cin, hw, hw, device="cuda")
         y = tr.forward(x).float().clone()
@@ -404,3 +405,93 @@ def test_two_block_backward_with_sums_from_the_weight_gradient_gemm(shape):
     worst = max((rel_l2(res[2][2][n].cpu().numpy(), res[0][2][n].cpu().numpy()), n) for n in res[0][3])
     print("shape %s: dx %.2e, worst parameter gradient %.2e (%s)" % (shape, e_dx, worst[0], worst[1]))
     assert e_dx < 1e-2 and worst[0] < 1.5e-2, (e_dx, worst)
+
+
+@pytest.mark.parametrize("case", [(2, 4, 14, 14, 256, 1024), (1, 4, 28, 28, 128, 512), (1, 4, 56, 56, 64, 256), (3, 4, 7, 9, 96, 160)], ids=str)
+def test_batch_statistics_from_the_gram_matrix_equal_the_statistics_of_the_conv_output(case):
+    """[r5] mvf_bn_train_stats_gram: mean / invstd / scale / shift / running statistics of z = a W^T (Bottleneck.conv3 -> norm3, resnet.py:236-237) from the Gram
+    matrix of a, its column means and the packed weights -- against mvf_bn_train_stats on the stored bf16 z and against fp64 on the unrounded z."""
+    lib, check, ConvDesc, _ = _lib()
+    from mvfnet_amd import _lib as L
+    nc, t, h, w, k, c = case
+    nt = nc * t
+    m = nt * h * w
+    gen = torch.Generator().manual_seed(m + c + 11)
+    a = (torch.relu(torch.randn(m, k, generator=gen) + 0.3) * (torch.rand(k, generator=gen) + 0.5)).cuda().to(BF)
+    w3 = (torch.randn(c, k, generator=gen) * 0.08).cuda().to(BF)
+    gamma, beta = (torch.rand(c, generator=gen) + 0.5).cuda(), (torch.randn(c, generator=gen) * 0.2).cuda()
+    zx = a.double() @ w3.double().t()
+    z = zx.to(BF)
+    eps, mom = 1e-5, 0.1
+    rm0, rv0 = (torch.randn(c, generator=gen) * 0.1).cuda(), (torch.rand(c, generator=gen) + 0.5).cuda()
+    # reference path: statistics of the stored tensor
+    ws = torch.empty(max(lib.mvf_bn_workspace_bytes(m, max(c, k)), 300 * k * k * 4 + 4096), dtype=torch.uint8, device="cuda")
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    o1 = [torch.empty(c, device="cuda") for _ in range(4)]
+    check(lib.mvf_bn_train_stats(P(z), m, c, P(gamma), P(beta), C.c_float(eps), C.c_float(mom), P(rm1), P(rv1), P(o1[0]), P(o1[1]), P(o1[2]), P(o1[3]), P(ws), ws.numel(),
+                                 L.MVF_BF16, None))
+    # Gram path
+    gram, amean = torch.empty(k, k, device="cuda"), torch.empty(4, k, device="cuda")
+    one, zero = torch.ones(k, device="cuda"), torch.zeros(k, device="cuda")
+    d = ConvDesc(nt, h, w, k, k, 1, 1, 1, 0, h, w, k, 1, 0, 0, 0, 0)
+    check(lib.mvf_conv2d_nhwc_wgrad_wgs(C.byref(d), P(a), P(a), None, 1, k, 1, k, P(gram), P(ws), ws.numel(), 256, None))
+    check(lib.mvf_bn_train_stats(P(a), m, k, P(one), P(zero), C.c_float(1e-5), C.c_float(0.1), None, None, P(amean[0]), P(amean[1]), P(amean[2]), P(amean[3]), P(ws),
+                                 ws.numel(), L.MVF_BF16, None))
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    o2 = [torch.empty(c, device="cuda") for _ in range(4)]
+    check(lib.mvf_bn_train_stats_gram(P(gram), P(amean[0]), P(w3), m, c, k, P(gamma), P(beta), C.c_float(eps), C.c_float(mom), P(rm2), P(rv2), P(o2[0]), P(o2[1]), P(o2[2]),
+                                      P(o2[3]), L.MVF_BF16, None))
+    torch.cuda.synchronize()
+    mean64, var64 = zx.mean(0), zx.var(0, unbiased=False)
+    inv64 = 1.0 / torch.sqrt(var64 + eps)
+    names = ("mean", "invstd", "scale", "shift")
+    ref = (mean64, inv64, gamma.double() * inv64, beta.double() - mean64 * gamma.double() * inv64)
+    errs = {}
+    for i, nme in enumerate(names):
+        errs[nme] = (rel_l2(o2[i].cpu().numpy(), ref[i].cpu().numpy()), rel_l2(o1[i].cpu().numpy(), ref[i].cpu().numpy()))
+    e_rv = (rel_l2(rv2.cpu().numpy(), ((1 - mom) * rv0.double() + mom * var64 * m / (m - 1)).cpu().numpy()), rel_l2(rv2.cpu().numpy(), rv1.cpu().numpy()))
+    print("case %s (Gram path / stored-z path vs fp64): %s; running_var vs fp64 %.2e, vs stored-z %.2e" %
+          (case, ", ".join("%s %.1e / %.1e" % (n_, e[0], e[1]) for n_, e in errs.items()), e_rv[0], e_rv[1]))
+    for nme, (e_gram, e_z) in errs.items():
+        assert e_gram < 2e-5 and e_gram < 10 * e_z + 1e-6, (nme, e_gram, e_z)
+    assert e_rv[0] < 2e-5 and rel_l2(rm2.cpu().numpy(), rm1.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(512, 128, 28), (256, 64, 56)], ids=str)
+def test_block_forward_with_statistics_from_the_gram_matrix(shape):
+    """[r5] eng.gram_stats in a block: a z3-free lower block (layer2 shape: dz3-free + sums from Q; layer1 shape: the z3-free policy) takes bn3's batch
+    statistics from the Gram matrix of a2 instead of a conv3 pass -- mean / invstd within 1e-6 of fp64 on the unrounded z3 = a2 W^T (the pass: ~4e-5), the
+    block output within bf16 rounding flips of the pass's (measured 3.5e-4, 1 % of the elements), running statistics updated, z3 never stored."""
+    from mvfnet_amd.backbones.resnet import Bottleneck
+    from mvfnet_amd.train_engine import BlockTrainer
+    cin, planes, hw = shape
+    res = {}
+    for on in (False, True):
+        torch.manual_seed(11)
+        blks = []
+        for _ in range(2):
+            blk = Bottleneck(cin, planes)
+            with torch.no_grad():
+                for bn in (blk.bn1, blk.bn2, blk.bn3):
+                    bn.weight.uniform_(0.5, 1.5)
+                    bn.bias.normal_(0, 0.2)
+            blks.append(blk)
+        seq = torch.nn.Sequential(*blks).cuda().train()
+        tr = BlockTrainer(seq, dtype=torch.bfloat16)
+        tr.dzfree_q, tr.gram_stats = 2, on
+        x = torch.relu(torch.randn(8, cin, hw, hw, device="cuda"))
+        tr.forward(x)
+        b = tr.blks[0]
+        assert b.gram_fwd(tr, 8 * hw * hw) == on and (b.saved["z3"] is None) == (on or planes <= 64)
+        a2 = b.saved["a2"].double()
+        w = seq[0].conv3.weight.detach().view(cin, planes).to(torch.bfloat16).double()
+        zx = a2 @ w.t()
+        mean64, inv64 = zx.mean(0), 1.0 / torch.sqrt(zx.var(0, unbiased=False) + 1e-5)
+        rv64 = 0.9 + 0.1 * zx.var(0, unbiased=True)
+        torch.cuda.synchronize()
+        res[on] = (rel_l2(b.b3.mean.cpu().numpy(), mean64.cpu().numpy()), rel_l2(b.b3.invstd.cpu().numpy(), inv64.cpu().numpy()),
+                   rel_l2(seq[0].bn3.running_var.cpu().numpy(), rv64.cpu().numpy()), b.saved["out"].float().clone())
+    e_out = rel_l2(res[True][3].cpu().numpy(), res[False][3].cpu().numpy())
+    print("shape %s: mean / invstd / running_var vs fp64: pass %.1e / %.1e / %.1e, Gram %.1e / %.1e / %.1e; block output Gram vs pass %.2e" %
+          ((shape,) + res[False][:3] + res[True][:3] + (e_out,)))
+    assert max(res[True][:3]) < 1e-6 and e_out < 2e-3

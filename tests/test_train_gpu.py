@@ -1015,8 +1015,14 @@ def test_engine_switch_variants_reproduce_the_default_step(dtype):
         assert torch.equal(got[1], ref[1])
     else:
         assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < 1e-6
-        got8 = run(steps=1, fuse_bnwg=15)             # ... also with layer1's plain blocks on stored z3 + the fused pass instead of the z3-free path
-        assert abs(got8[0][0] - ref[0][0]) < 1e-2 * abs(ref[0][0]) and rel_l2(got8[1].cpu().numpy(), ref[1].cpu().numpy()) < 1e-2
+        # ... also with layer1's plain blocks on stored z3 + the fused pass instead of the z3-free path ([r5] both sides with bn3's statistics from a conv3 pass:
+        # the Gram form of the default, checked below, exists for z3-free blocks only)
+        got8, ref8 = run(steps=1, fuse_bnwg=15, gram_stats=False), run(steps=1, gram_stats=False)
+        assert abs(got8[0][0] - ref8[0][0]) < 1e-2 * abs(ref8[0][0]) and rel_l2(got8[1].cpu().numpy(), ref8[1].cpu().numpy()) < 1e-2
+        # [r5] gram_stats: bn3's batch statistics of the z3-free blocks from the Gram matrix of a2 instead of a statistics pass of conv3 -- the statistics of the
+        # UNROUNDED z3, 1e-7 of fp64 where the pass over the bf16 tensor is at 4e-5 (tests/test_dzfree_gpu.py): a 4e-5 change of two BatchNorms' statistics, which
+        # this 2-clip batch-statistics network amplifies like any other (measured: loss 1.3e-2 against the pass, parameters 6e-3)
+        assert abs(ref8[0][0] - ref[0][0]) < 3e-2 * abs(ref[0][0]) and rel_l2(ref8[1].cpu().numpy(), ref[1].cpu().numpy()) < 2e-2
     # [r4] fuse_c3_bwd: the z3-free blocks' conv3 backward in ONE pass (csrc/pw_bwd_fused.hip; bf16 only, a no-op in fp32): the same dz3 bit for bit,
     # kept on chip; its data gradient bit for bit, bn2's sums and the weight gradient summed per persistent workgroup (fp32 summation order).  (With the
     # downsample block's z3-free mode off on both sides: it depends on this switch and changes the FORWARD's statistics pass.)
@@ -1046,8 +1052,13 @@ def test_engine_switch_variants_reproduce_the_default_step(dtype):
     assert got[0] == ref[0] and torch.equal(got[1], ref[1])
     got = run(steps=1, gate_sums=True)             # bn3's backward sums taken in the gating epilogues of the block above (off by default: measured neutral): summation order
     assert got[0] == ref[0] and rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-6 if dtype == torch.float32 else 1e-2)
-    got = run(steps=1, dzfree_q=2)                 # [r5] bn3's backward sums from the producers' column sums + the weight-gradient GEMM in EVERY dz3-free block (default: large ones) instead of a pass over (gm, z3)
-    assert got[0] == ref[0] and rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-6 if dtype == torch.float32 else 1e-2)
+    # [r5] bn3's backward sums from the producers' column sums + the weight-gradient GEMM in EVERY dz3-free block (default: large ones) instead of a pass over
+    # (gm, z3): the same forward with the Gram statistics off on both sides (with them on, such a block of layer2 also drops its first conv3 pass: next line)
+    got, refq = run(steps=1, dzfree_q=2, gram_stats=False), run(steps=1, gram_stats=False)
+    assert got[0] == refq[0] and rel_l2(got[1].cpu().numpy(), refq[1].cpu().numpy()) < (1e-6 if dtype == torch.float32 else 1e-2)
+    got = run(steps=1, dzfree_q=2)
+    assert abs(got[0][0] - ref[0][0]) < (1e-6 if dtype == torch.float32 else 3e-2) * abs(ref[0][0])
+    assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-6 if dtype == torch.float32 else 2e-2)
     got = run(steps=1, fuse_mvf_stats=False)            # [r5] MVF's BatchNorm statistics from a pass over y instead of the stencil launch: fp32 summation order
     assert abs(got[0][0] - ref[0][0]) < (1e-6 if dtype == torch.float32 else 1e-2) * abs(ref[0][0])
     assert rel_l2(got[1].cpu().numpy(), ref[1].cpu().numpy()) < (1e-3 if dtype == torch.float32 else 1e-2)      # (batch statistics in another summation order, amplified by the 2-clip network)

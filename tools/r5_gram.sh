@@ -1,11 +1,5 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-
-run() { echo "## $*" >> gpurun_out/r5_gram_ab.txt; env "$@" timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs $X 2>>gpurun_out/r5_late_err.txt | tail -1 | cut -c1-330 >> gpurun_out/r5_gram_ab.txt; }
-: > gpurun_out/r5_gram_ab.txt
-X=""
-for i in 1 2; do run MVF_GRAM_WGS=32; run MVF_GRAM_WGS=16; run MVF_GRAM_WGS=8; run MVF_GRAM_WGS=24; done
-X="--depth 101 --frames 16 --clips 16"
-for i in 1 2; do run MVF_GRAM_WGS=32; run MVF_GRAM_WGS=16; run MVF_GRAM_WGS=8; run MVF_GRAM_WGS=24; done
-cat gpurun_out/r5_gram_ab.txt | grep -o '## .*\|"value": [0-9.]*\|"ms_per_step": [0-9.]*' | paste - - -
+(timeout 1200 python -m pytest tests/test_dzfree_gpu.py -q -m gpu -p no:cacheprovider -s 2>&1 | grep "Gram\|shape\|passed\|failed\|Error\|error" | tail -14)
+timeout 2400 python -m pytest tests/test_train_gpu.py tests/test_bf16_parity_gpu.py tests/test_net_gpu.py -q -m gpu -p no:cacheprovider -x > gpurun_out/gram_tests.log 2>&1; tail -5 gpurun_out/gram_tests.log

@@ -5,12 +5,14 @@ run() { timeout 300 python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline
 both() { echo -n "$1 | C3: "; run | tr '\n' ' '; echo -n " C4: "; run --depth 101 --frames 16 --clips 16; }
 for rep in 1 2; do
 both "default"
-MVF_WGRAD_BIG_WGS=96 both "big_wgs=96"
-MVF_WGRAD_BIG_WGS=160 both "big_wgs=160"
-MVF_WGRAD_WGS=192 both "wgs=192"
-MVF_WGRAD_WGS=384 both "wgs=384"
-MVF_GRAM_WGS=16 both "gram=16"
-MVF_GRAM_WGS=64 both "gram=64"
-MVF_SIDE_LATE=0 both "side_late=0"
-MVF_DZFREE=1 both "dzfree=1"
+MVF_FUSE_BN3_APPLY=0 both "bn3_apply=0"
+MVF_FUSE_BN3_APPLY=2 both "bn3_apply=2"
+MVF_Z3_FREE=0 both "z3_free=0"
+MVF_FUSE_BNWG=0 both "bnwg=0"
+MVF_FUSE_BNWG=3 both "bnwg=3"
+MVF_FUSE_BNWG=5 both "bnwg=5"
+MVF_SIDE_BATCH=2 both "side_batch=2"
+MVF_SIDE_HOLD=1 both "side_hold=1"
+MVF_STEM_WGRAD_MAIN=0 both "stem_wgrad_main=0"
+MVF_AUX_DOWNSAMPLE_BWD=1 both "aux_ds_bwd=1"
 done
