@@ -281,6 +281,11 @@ int mvf_bn_train_finalize(const float* part, int nblk, long m, int c, const floa
 int mvf_bn_train_stats_gram(const float* gram, const float* a_mean, const void* w_packed, long m, int c, int k, const float* gamma, const float* beta,
                             float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* scale,
                             float* shift, int dtype, void* stream);
+/* out = act(z * scale + shift) (mvf_bn_apply without a residual) + the column means of what it stores: a_mean for mvf_bn_train_stats_gram from the kernel that
+ * WRITES conv3's input (norm2 + relu, resnet.py:233-234) instead of a pass over it.  ws >= max(mvf_bn_workspace_bytes(m, c), 4608 * c * 8) bytes
+ * (one partial row per workgroup row band of the apply plan). */
+int mvf_bn_apply_colmeans(const void* z, long m, int c, const float* scale, const float* shift, int act, void* out, float* mean_out, void* ws,
+                          size_t ws_bytes, int dtype, void* stream);
 /* out = act(z*scale + shift [+ residual | + residual*rscale + rshift]); act: 0 none, 1 ReLU, 2 hard-swish */
 int mvf_bn_apply(const void* z, long m, int c, const float* scale, const float* shift, const void* residual,
                  const float* rscale, const float* rshift, int act, void* out, int dtype, void* stream);

@@ -133,6 +133,8 @@ def _load():
     lib.mvf_bn_train_finalize.argtypes = [fp, i32, i64, i32, fp, fp, f32, f32, fp, fp, fp, fp, fp, fp, vp]
     lib.mvf_bn_train_stats_gram.restype = i32
     lib.mvf_bn_train_stats_gram.argtypes = [fp, fp, vp, i64, i32, i32, fp, fp, f32, f32, fp, fp, fp, fp, fp, fp, i32, vp]
+    lib.mvf_bn_apply_colmeans.restype = i32
+    lib.mvf_bn_apply_colmeans.argtypes = [vp, i64, i32, fp, fp, i32, vp, fp, vp, sz, i32, vp]
     lib.mvf_bn_apply.restype = i32
     lib.mvf_bn_apply.argtypes = [vp, i64, i32, fp, fp, vp, fp, fp, i32, vp, i32, vp]
     lib.mvf_bn_apply_bits.restype = i32

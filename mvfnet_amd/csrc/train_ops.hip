@@ -302,22 +302,35 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(int C, int nblk,
     if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (double)M / (double)(M > 1 ? M - 1 : 1));
 }
 
+// [r5] column means from bn_apply_cs_kernel's partial rows ([nblk][C][2], element 0): reduce_partials' fp64 fixed-order sum, nothing else
+__global__ __launch_bounds__(256) void colmean_finalize_kernel(int C, int nblk, long M, const float* part, float* mean_out) {
+    int c;
+    double s1, s2;
+    if (!reduce_partials(part, C, nblk, c, s1, s2)) return;
+    mean_out[c] = (float)(s1 / (double)M);
+}
+
 // ---- BN apply (+ residual) (+ ReLU):  out = act(z*scale + shift [+ r] [+ r*rscale + rshift]) ----
 // Column-tiled: a lane owns VN channels (its scale/shift live in registers) and walks rows; no per-element index math.
-template <typename ET, int VN>
-__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const ET* z, long M, int C, const float* scale, const float* shift, const ET* r,
-                                                            const float* rscale, const float* rshift, int act, ET* out,
-                                                            unsigned char* bits, int cqb, int rows) {
+// CS ([r5], mvf_bn_apply_colmeans): the kernel also leaves the column sums of what it STORES, one partial row per workgroup row band ([gy][C][2], element 0:
+// bn_stats_kernel's layout) -- the column means of a2 for the Gram form of bn3's statistics without a pass over a2 (bn_dzfree.hip: gram_stats_kernel).
+template <typename ET, int VN, bool CS>
+__device__ __forceinline__ void bn_apply_body(const ET* z, long M, int C, const float* scale, const float* shift, const ET* r,
+                                              const float* rscale, const float* rshift, int act, ET* out,
+                                              unsigned char* bits, int cqb, int rows, float* csum_part, float* red) {
     const int rl = kThreads / cqb;
     const int cq = blockIdx.x * cqb + threadIdx.x % cqb, lane_r = threadIdx.x / cqb;
-    if (cq * VN >= C) return;
-    const int c = cq * VN;
-    float s[VN], b[VN], rs[VN], rb[VN];
+    const bool ok = cq * VN < C;
+    if (!CS && !ok) return;
+    const int c = ok ? cq * VN : 0;
+    float s[VN], b[VN], rs[VN], rb[VN], cs1[VN], cs2[VN];
     ldp<VN>(scale, c, s);
     ldp<VN>(shift, c, b);
     ldp<VN>(rscale, c, rs, 1.f);
     ldp<VN>(rshift, c, rb, 0.f);
-    const long r0 = (long)blockIdx.y * rows, r1 = min(M, r0 + rows);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) cs1[j] = cs2[j] = 0.f;
+    const long r0 = (long)blockIdx.y * rows, r1 = ok ? min(M, r0 + rows) : r0;
     auto one = [&](long row, float (&v)[VN], const float (&q)[VN]) {
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
@@ -326,6 +339,7 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const ET* z, long M,
             if (act == 1) t = fmaxf(t, 0.f);
             else if (act == 2) t = hswish_f(t);             // MVF activation (se_module.py:5-24)
             v[j] = t;
+            if constexpr (CS) cs1[j] += sizeof(ET) == 2 ? bf16_to_f32(f32_to_bf16(t)) : t;
         }
         stv<ET, VN>(out + row * C + c, v);
         if (bits) {                                         // sign bits of the result, one byte per 4 channels: [M][C/4]
@@ -354,6 +368,26 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const ET* z, long M,
         if (r) ldv<ET, VN>(r + row * C + c, q0);
         one(row, z0, q0);
     }
+    if constexpr (CS) {
+        rowlane_reduce<VN>(cs1, cs2, cqb, rl, red);
+        if (ok && lane_r == 0) {
+            float* p = csum_part + ((long)blockIdx.y * C + c) * 2;
+#pragma unroll
+            for (int j = 0; j < VN; ++j) { p[2 * j] = cs1[j]; p[2 * j + 1] = 0.f; }
+        }
+    }
+}
+template <typename ET, int VN>
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const ET* z, long M, int C, const float* scale, const float* shift, const ET* r,
+                                                            const float* rscale, const float* rshift, int act, ET* out,
+                                                            unsigned char* bits, int cqb, int rows) {
+    bn_apply_body<ET, VN, false>(z, M, C, scale, shift, r, rscale, rshift, act, out, bits, cqb, rows, nullptr, nullptr);
+}
+template <typename ET, int VN>
+__global__ __launch_bounds__(kThreads) void bn_apply_cs_kernel(const ET* z, long M, int C, const float* scale, const float* shift, int act, ET* out,
+                                                               int cqb, int rows, float* csum_part) {
+    __shared__ float red[2 * VN * kThreads];
+    bn_apply_body<ET, VN, true>(z, M, C, scale, shift, nullptr, nullptr, nullptr, act, out, nullptr, cqb, rows, csum_part, red);
 }
 
 // ---- BN backward reductions: gm = g * mask ; sums of gm and gm*xhat.  mask from y>0 (block output, mode 1), from its sign
@@ -1442,6 +1476,24 @@ int mvf_bn_apply_bits(const void* z, long m, int c, const float* scale, const fl
     const bool wide = c % 8 == 0 && al16(z) && al16(out) && al16(residual) && ((uintptr_t)sign_bits & 1) == 0;
     MVF_BN_DISPATCH(bn_apply_kernel, wide, 4096, (const ET*)z, m, c, scale, shift, (const ET*)residual, rscale, rshift, relu, (ET*)out, sign_bits,
                     p.cqb, p.rows);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+// [r5] out = act(z * scale + shift) AND the column means of what is stored (mean_out [c]; partial rows in ws, >= mvf_bn_workspace_bytes(m, c)): the column
+// means of conv3's input for mvf_bn_train_stats_gram without a pass over it
+int mvf_bn_apply_colmeans(const void* z, long m, int c, const float* scale, const float* shift, int act, void* out, float* mean_out, void* ws, size_t ws_bytes,
+                          int dtype, void* stream) {
+    MVF_REQUIRE(z && scale && shift && out && mean_out && ws && m > 0 && c > 0 && c % 8 == 0, MVF_EINVAL, "bn_apply_colmeans: bad argument (c %% 8?)");
+    MVF_REQUIRE(al16(z) && al16(out), MVF_EINVAL, "bn_apply_colmeans: z / out must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int gy = col_plan(m, c, dtype == MVF_F32 ? 4 : 8, 4096).gy;
+    MVF_REQUIRE(ws_bytes >= (size_t)gy * c * 2 * sizeof(float), MVF_EWS, "bn_apply_colmeans: workspace too small (%d partial rows)", gy);
+    float* part = (float*)ws;
+    const bool wide = true;
+    MVF_BN_DISPATCH(bn_apply_cs_kernel, wide, 4096, (const ET*)z, m, c, scale, shift, act, (ET*)out, p.cqb, p.rows, part);
+    MVF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colmean_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh), dim3(256), 0, st, c, gy, m, part, mean_out);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

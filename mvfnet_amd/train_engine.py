@@ -164,6 +164,15 @@ class _BN(object):
                                     _p(rbn.shift if rbn else None), act, _p(out), _p(sb), self.eng.dt, _st()), "mvf_bn_apply")
         return (out, sb) if bits else out
 
+    def apply_colmeans(self, z, m, act, mean_out):
+        """[r5] out = act(bn(z)) + the column means of what is stored into mean_out -- conv3's a_mean for the Gram form of bn3's statistics
+        (_TConv.gram_stats) without a pass over a2."""
+        out = self.eng.buf((id(self), "apply"), z.shape, z.dtype)
+        ws = self.eng.workspace(max(lib.mvf_bn_workspace_bytes(m, self.c), 4608 * self.c * 8))        # (the apply plan aims at 4096 workgroups: one partial row each)
+        check(lib.mvf_bn_apply_colmeans(_p(z), m, self.c, _p(self.scale), _p(self.shift), act, _p(out), _p(mean_out), _p(ws), ws.numel(), self.eng.dt, _st()),
+              "mvf_bn_apply_colmeans")
+        return out
+
     def backward(self, g, g_pitch, z, m, eng, mask_mode, ymask=None, gm_out=None, sums_done=False):
         """dgamma/dbeta into the flat grad buffer; returns dz.  sums_done: dgamma / dbeta were already produced by the data
         gradient that wrote g (_TConv.dgrad_bnsums)."""
@@ -542,7 +551,7 @@ class _TConv(object):
         return (self.eng.tdtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and self.stride == 1 and not self.stem and
                 self.cin % 32 == 0 and self.cout % 32 == 0)
 
-    def gram_stats(self, a_in, bn, n, h, w, eng):
+    def gram_stats(self, a_in, bn, n, h, w, eng, means_done=False):
         """[r5] bn's batch statistics of z = conv(a_in) WITHOUT the conv (csrc/bn_dzfree.hip: mvf_bn_train_stats_gram): the Gram matrix of a_in (one
         k x k GEMM over the narrow tensor), its column means, and a c x k x k quadratic form.  gram / a_mean stay in their per-conv buffers: the dz3-free
         backward's weight-gradient correction needs exactly these (dzfree_wgrad(gram_done=True))."""
@@ -555,8 +564,9 @@ class _TConv(object):
             eng._ones[k] = (torch.ones(k, device=a_in.device), torch.zeros(k, device=a_in.device))
         one, zero = eng._ones[k]
         self.launch_gram(d, a_in, gram, ws, eng.gram_stats_wgs)
-        check(lib.mvf_bn_train_stats(_p(a_in), m, k, _p(one), _p(zero), C.c_float(1e-5), C.c_float(0.1), None, None, _p(amean[0]), _p(amean[1]),
-                                     _p(amean[2]), _p(amean[3]), _p(ws), ws.numel(), eng.dt, _st()), "column means")
+        if not means_done:     # (means_done: the kernel that wrote a_in left its column means in amean[0] -- _BN.apply_colmeans)
+            check(lib.mvf_bn_train_stats(_p(a_in), m, k, _p(one), _p(zero), C.c_float(1e-5), C.c_float(0.1), None, None, _p(amean[0]), _p(amean[1]),
+                                         _p(amean[2]), _p(amean[3]), _p(ws), ws.numel(), eng.dt, _st()), "column means")
         check(lib.mvf_bn_train_stats_gram(_p(gram), _p(amean[0]), _p(self.wp), m, c, k, _p(bn.gamma), _p(bn.beta), C.c_float(bn.eps), C.c_float(bn.momentum),
                                           _p(bn.mod.running_mean), _p(bn.mod.running_var), _p(bn.mean), _p(bn.invstd), _p(bn.scale), _p(bn.shift), eng.dt,
                                           _st()), "bn statistics from the Gram matrix")
@@ -836,10 +846,15 @@ class _TBlock(object):
         a1 = self.b1.apply(z1, m, 1)
         z2, ho, wo = self.c2.forward(a1, nt, h, w, bn=self.b2)
         m2 = nt * ho * wo
-        a2 = self.b2.apply(z2, m2, 1)
         gram = self.gram_fwd(eng, m2)
+        cs = gram and eng.gram_colsums and self.b2.c % 8 == 0
+        if cs:
+            amean = eng.buf((id(self.c3), "amean"), (4, self.c3.cin), torch.float32)
+            a2 = self.b2.apply_colmeans(z2, m2, 1, amean[0])
+        else:
+            a2 = self.b2.apply(z2, m2, 1)
         if gram:           # [r5] no first conv3 pass at all: bn3's statistics from the Gram matrix of a2
-            self.c3.gram_stats(a2, self.b3, nt, ho, wo, eng)
+            self.c3.gram_stats(a2, self.b3, nt, ho, wo, eng, means_done=cs)
             z3 = None
         else:
             z3, _, _ = self.c3.forward(a2, nt, ho, wo, bn=self.b3, store=not self.z3_free(eng, m2))
@@ -1148,6 +1163,7 @@ class _ParamStore(object):
     # conv3 pass (statistics only in layer1, z3-storing in layer2) disappears; 0 = off.  gram_stats_wgs: the workgroup count of that GEMM on the launch stream.
     gram_stats = os.environ.get("MVF_GRAM_STATS", "1") != "0"
     gram_stats_wgs = int(os.environ.get("MVF_GRAM_STATS_WGS", "256"))
+    gram_colsums = os.environ.get("MVF_GRAM_COLSUMS", "1") != "0"      # ... and the column means of a2 from the bn2 apply that writes it (mvf_bn_apply_colmeans) instead of a pass over a2
 
     def side_stream(self):
         if not self.overlap_wgrad:

@@ -425,7 +425,7 @@ def test_batch_statistics_from_the_gram_matrix_equal_the_statistics_of_the_conv_
     eps, mom = 1e-5, 0.1
     rm0, rv0 = (torch.randn(c, generator=gen) * 0.1).cuda(), (torch.rand(c, generator=gen) + 0.5).cuda()
     # reference path: statistics of the stored tensor
-    ws = torch.empty(max(lib.mvf_bn_workspace_bytes(m, max(c, k)), 300 * k * k * 4 + 4096), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(max(lib.mvf_bn_workspace_bytes(m, max(c, k)), 300 * k * k * 4 + 4096, 4608 * k * 8), dtype=torch.uint8, device="cuda")
     rm1, rv1 = rm0.clone(), rv0.clone()
     o1 = [torch.empty(c, device="cuda") for _ in range(4)]
     check(lib.mvf_bn_train_stats(P(z), m, c, P(gamma), P(beta), C.c_float(eps), C.c_float(mom), P(rm1), P(rv1), P(o1[0]), P(o1[1]), P(o1[2]), P(o1[3]), P(ws), ws.numel(),
@@ -441,6 +441,19 @@ def test_batch_statistics_from_the_gram_matrix_equal_the_statistics_of_the_conv_
     o2 = [torch.empty(c, device="cuda") for _ in range(4)]
     check(lib.mvf_bn_train_stats_gram(P(gram), P(amean[0]), P(w3), m, c, k, P(gamma), P(beta), C.c_float(eps), C.c_float(mom), P(rm2), P(rv2), P(o2[0]), P(o2[1]), P(o2[2]),
                                       P(o2[3]), L.MVF_BF16, None))
+    # ... and the column means from the kernel that WRITES a (mvf_bn_apply_colmeans: a = relu(zz * s + b), bit for bit mvf_bn_apply's; means = a pass over a's)
+    if k % 8 == 0:
+        zz = torch.randn(m, k, generator=gen).cuda().to(BF)
+        s_, b_ = (torch.rand(k, generator=gen) + 0.5).cuda(), (torch.randn(k, generator=gen) * 0.3).cuda()
+        a_ref, a_cs, am_b = torch.empty(m, k, device="cuda", dtype=BF), torch.empty(m, k, device="cuda", dtype=BF), torch.empty(k, device="cuda")
+        check(lib.mvf_bn_apply(P(zz), m, k, P(s_), P(b_), None, None, None, 1, P(a_ref), L.MVF_BF16, None))
+        check(lib.mvf_bn_apply_colmeans(P(zz), m, k, P(s_), P(b_), 1, P(a_cs), P(am_b), P(ws), ws.numel(), L.MVF_BF16, None))
+        am_a = torch.empty(4, k, device="cuda")
+        check(lib.mvf_bn_train_stats(P(a_cs), m, k, P(one), P(zero), C.c_float(1e-5), C.c_float(0.1), None, None, P(am_a[0]), P(am_a[1]), P(am_a[2]), P(am_a[3]), P(ws),
+                                     ws.numel(), L.MVF_BF16, None))
+        torch.cuda.synchronize()
+        assert torch.equal(a_ref.view(torch.int16), a_cs.view(torch.int16))
+        assert rel_l2(am_b.cpu().numpy(), a_cs.double().mean(0).cpu().numpy()) < 1e-6 and rel_l2(am_b.cpu().numpy(), am_a[0].cpu().numpy()) < 1e-6
     torch.cuda.synchronize()
     mean64, var64 = zx.mean(0), zx.var(0, unbiased=False)
     inv64 = 1.0 / torch.sqrt(var64 + eps)

@@ -1,5 +1,9 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-(timeout 1200 python -m pytest tests/test_dzfree_gpu.py -q -m gpu -p no:cacheprovider -s 2>&1 | grep "Gram\|shape\|passed\|failed\|Error\|error" | tail -14)
-timeout 2400 python -m pytest tests/test_train_gpu.py tests/test_bf16_parity_gpu.py tests/test_net_gpu.py -q -m gpu -p no:cacheprovider -x > gpurun_out/gram_tests.log 2>&1; tail -5 gpurun_out/gram_tests.log
+(timeout 1200 python -m pytest tests/test_dzfree_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -6)
+run() { timeout 300 python bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*' | head -1; }
+for rep in 1 2 3; do
+for z in 0 1; do echo -n "C3 colsums=$z: "; MVF_GRAM_COLSUMS=$z run; done
+for z in 0 1; do echo -n "C4 colsums=$z: "; MVF_GRAM_COLSUMS=$z run --depth 101 --frames 16 --clips 16; done
+done
