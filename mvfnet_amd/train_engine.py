@@ -727,8 +727,10 @@ class _TBlock(object):
         1 where it measured faster in the step -- planes <= 128 (layer1: 187 vs 260 us per block, layer2: 110 vs 126): conv3 reads a quarter
         of z3's bytes and the matrix cores idle; from planes = 256 on the extra GEMM costs more than the bytes save (layer3: 71 vs 64 us) --,
         2 every block)."""
+        # ([r5] 3 = planes <= 256: with the Gram statistics (gram_fwd) layer3 would also drop its first conv3 pass -- measured WORSE, three alternations on one
+        # box: C3 17.57-17.65 -> 17.99-18.09 ms, C4 30.07-30.16 -> 31.94-32.01: the apply epilogue on the 1024-wide GEMM costs more than the byte-bound pass)
         f = eng.fuse_bn3_apply
-        return f == 2 or (f == 1 and self.c3.cin <= 128)
+        return f == 2 or (f == 1 and self.c3.cin <= 128) or (f == 3 and self.c3.cin <= 256)
 
     def z3_free(self, eng, m2=None):
         """[r3] The block never stores z3 (reference resnet.py:229-244: out = relu(bn3(conv3(a2)) + identity)): a statistics-only conv3 pass, the
