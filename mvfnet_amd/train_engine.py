@@ -779,7 +779,7 @@ class _TBlock(object):
     def gram_fwd(self, eng, m2):
         """[r5] bn3's batch statistics from the Gram matrix of a2 instead of a conv3 pass (eng.gram_stats): blocks that apply bn3 in a second conv3 pass
         (fuse_apply) and never read z3 in backward -- the z3-free blocks of layer1, and the dz3-free blocks whose sums come from Q (q_z3_free)."""
-        if not (eng.gram_stats and eng.tdtype == torch.bfloat16 and self.cd is None and self.c3.gram_ok() and self.fuse_apply(eng) and eng.fuse_stats and
+        if not (eng.gram_stats and eng.tdtype == torch.bfloat16 and (self.cd is None or eng.gram_stats_ds) and self.c3.gram_ok() and self.fuse_apply(eng) and eng.fuse_stats and
                 not self.b3.frozen and eng.z3_free):
             return False
         return self.z3_free(eng, m2)
@@ -1165,6 +1165,9 @@ class _ParamStore(object):
     # conv3 pass (statistics only in layer1, z3-storing in layer2) disappears; 0 = off.  gram_stats_wgs: the workgroup count of that GEMM on the launch stream.
     gram_stats = os.environ.get("MVF_GRAM_STATS", "1") != "0"
     gram_stats_wgs = int(os.environ.get("MVF_GRAM_STATS_WGS", "256"))
+    # ... also conv3 of the z3-free downsample block (layer1.0): measured neutral (C3 17.64-17.79 / 17.65-17.68, C4 30.18-30.27 / 30.27-30.28: its statistics pass
+    # runs beside the downsample branch's conv on the side stream) -- off
+    gram_stats_ds = os.environ.get("MVF_GRAM_STATS_DS", "0") != "0"
     gram_colsums = os.environ.get("MVF_GRAM_COLSUMS", "1") != "0"      # ... and the column means of a2 from the bn2 apply that writes it (mvf_bn_apply_colmeans) instead of a pass over a2
 
     def side_stream(self):
