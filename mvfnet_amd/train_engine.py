@@ -769,7 +769,7 @@ class _TBlock(object):
     def q_policy(self, eng, m2):
         """eng.dzfree_q: 0 off, 1 planes <= dzfree_q_maxk (the GEMM costs 2 m c k flops against the sums pass's 4 m c bytes: half the pass at k = 128, even at
         256, twice at 512) and only where that pass is long enough to pay for the GEMM's extra launches on the launch stream (>= 160 MB of (gm, z3)), 2 every block."""
-        return eng.dzfree_q == 2 or (eng.dzfree_q == 1 and self.c3.cin <= eng.dzfree_q_maxk and m2 * self.c3.cout * 4 >= 160e6)
+        return eng.dzfree_q == 2 or (eng.dzfree_q == 1 and eng.dzfree_q_mink <= self.c3.cin <= eng.dzfree_q_maxk and m2 * self.c3.cout * 4 >= 160e6)
 
     def _dzfree_base(self, eng, m2):
         if not eng.dzfree or self.cd is not None or not eng.fuse_bn_bwd_sums or not self.c3.dzfree_ok(m2 or (1 << 16)):
@@ -1158,6 +1158,7 @@ class _ParamStore(object):
     dzfree_q = int(os.environ.get("MVF_DZFREE_Q", "1"))
     dzfree_q_wgs = int(os.environ.get("MVF_DZFREE_Q_WGS", "256"))
     dzfree_q_maxk = int(os.environ.get("MVF_DZFREE_Q_MAXK", "256"))
+    dzfree_q_mink = int(os.environ.get("MVF_DZFREE_Q_MINK", "0"))
     # ... and such a block need not store z3 where bn3's apply is a second conv3 pass (_TBlock.q_z3_free: layer2's plain blocks).  Measured (ms, off / on, three
     # alternations): C3 17.93-17.95 / 17.96-17.99, C4 30.43-30.47 / 30.45-30.69 -- the statistics-only pass is no shorter in the step than the storing one; off.
     dzfree_q_z3free = os.environ.get("MVF_DZFREE_Q_Z3FREE", "0") != "0"
