@@ -516,13 +516,14 @@ __global__ __launch_bounds__(kThreads, 2) void mvf_nhwc_apply_lds(NhwcArgs a) {
 
 struct LdsPlan { int rb, cw, bands; size_t lds; };
 // the LDS-tiled kernel's plan: the widest channel chunk (64 / 32 / 16) whose band of >= 2 rows (or the whole image) + halo fits 64 KB over all T frames, taken when
-// it makes >= MVF_STENCIL_LDS_MINWG (400) workgroups; a stage whose whole planes fit (7 x 7: 128 workgroups) may halve the budget once if the chunk stays 64 wide.
+// it makes >= MVF_STENCIL_LDS_MINWG (150) workgroups; a stage whose whole planes fit (7 x 7: 128 workgroups) may halve the budget once if the chunk stays 64 wide.
 // Everything smaller stays on the chunked kernel: with few workgroups the two-phase tile (load all, then compute) has nothing to overlap with.  Measured in the
-// step (ms, chunked / tiled): C3 18.52 / 18.24-18.29, C4 31.30 / 31.03-31.05; 12 clips 9.38 / 9.42 and 16-clip inference chains 4.04 / 4.15 with tiles forced
-// on them -- which this rule leaves on the chunked kernel.
+// step (ms, chunked / tiled): C3 18.52 / 18.24-18.29, C4 31.30 / 31.03-31.05.  The threshold (400 / 150; three alternations): 12 clips per GPU (168 workgroups on
+// layer3) 9.11-9.13 / 9.06-9.09, C5 video 4.97-5.00 / 4.94-4.95, C4 30.84-30.89 / 30.76-30.86, the 16-clip inference chains (224) 4.00-4.03 / 4.02-4.05;
+// narrower 32-channel tiles forced on those small launches (budget halving without the 64-wide rule) measured 9.38 -> 9.42 and 4.04 -> 4.15.
 static bool lds_plan(int T, int H, int W, int cs, int n_clips, LdsPlan& best) {
     static const int on = getenv("MVF_STENCIL_LDS") ? atoi(getenv("MVF_STENCIL_LDS")) : 1;
-    static const int min_wg = getenv("MVF_STENCIL_LDS_MINWG") ? atoi(getenv("MVF_STENCIL_LDS_MINWG")) : 400;
+    static const int min_wg = getenv("MVF_STENCIL_LDS_MINWG") ? atoi(getenv("MVF_STENCIL_LDS_MINWG")) : 150;
     if (!on || (T != 4 && T != 8 && T != 16)) return false;
     auto bytes = [&](int rb, int cw) { return (((size_t)T * (rb + 2) * W * cw * 2 / 16 + 63) / 64) * 1024; };      // whole 64-piece DMA instructions
     for (size_t budget = 65536; budget >= 32768; budget >>= 1) {

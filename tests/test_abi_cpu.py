@@ -41,7 +41,7 @@ def test_product_modules_refuse_cpu_tensors():
 
 def test_stencil_partial_row_plan_follows_the_kernel_choice():
     """[r5] mvf_nhwc_stencil_stats_rows names the partial rows of the launch that WILL run (no launch, no GPU): the LDS-tiled bf16 kernel
-    (clips x bands of rows) where its plan exists and makes >= 400 workgroups, the register-chunked kernel's (clips x pixel bands) otherwise."""
+    (clips x bands of rows) where its plan exists and makes >= 150 workgroups, the register-chunked kernel's (clips x pixel bands) otherwise."""
     import os
     if os.environ.get("MVF_STENCIL_LDS", "1") == "0" or os.environ.get("MVF_STENCIL_LDS_MINWG"):
         pytest.skip("the plan switches are set in the environment")
@@ -51,5 +51,6 @@ def test_stencil_partial_row_plan_follows_the_kernel_choice():
     assert rows(256, 8, 14, 1024, 128, L.MVF_BF16) == 32 * 7          # layer3 at 32 clips: 64 channels x 2 rows x 8 frames in 57 KB -> 448 workgroups
     assert rows(256, 16, 14, 1024, 128, L.MVF_BF16) == 16 * 7         # C4: 32 channels x 2 rows x 16 frames
     assert rows(256, 8, 7, 2048, 256, L.MVF_BF16) == 32 * 4           # layer4: whole planes would make 128 workgroups -> the halved budget, 2-row bands
-    assert rows(96, 8, 14, 1024, 128, L.MVF_BF16) == 12 * 25          # 12 clips: 168 workgroups -> the chunked kernel (8 pixels per workgroup)
+    assert rows(96, 8, 14, 1024, 128, L.MVF_BF16) == 12 * 7           # 12 clips: 168 workgroups, still tiled
+    assert rows(32, 8, 14, 1024, 128, L.MVF_BF16) == 4 * 25           # 4 clips: 56 workgroups -> the chunked kernel (8 pixels per workgroup)
     assert rows(256, 8, 14, 1024, 128, L.MVF_F32) == 32 * 25          # fp32: chunked
