@@ -252,7 +252,7 @@ def roofline_train(eng, imgs, labels, dtype, per_layer, ms_step):
         nbytes = esz * (n * ho * wo * self.cout + n * h * w * (4 if self.stem else self.cin)) + 4 * self.w.numel()
         return (2.0 * n * ho * wo * self.cout * k_alg, "wgrad M%d N%d K%d s%d" % (n * ho * wo, self.cout, k_alg, self.stride), nbytes)
 
-    def dwgq(self, out, d, gm, a_in, ws, wgs):      # [r5] conv3's weight-gradient GEMM Q = gm^T a2 taken on the launch stream (it also yields bn3's dgamma: dzfree_q)
+    def dwgq(self, out, d, gm, a_in, ws, wgs, slabs=False):      # [r5] conv3's weight-gradient GEMM Q = gm^T a2 taken on the launch stream (it also yields bn3's dgamma: dzfree_q)
         m, c, k = d.n * d.h * d.w, self.cout, self.cin
         return (2.0 * m * c * k, "wgrad M%d N%d K%d s1 (launch stream)" % (m, c, k), esz * m * (c + k) + 4 * self.w.numel())
 

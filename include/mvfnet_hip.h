@@ -260,9 +260,12 @@ int mvf_bn_bwd_dzfree_wgrad(float* dw, const void* w_packed, const float* gram, 
 /* _sums : dgamma / dbeta WITHOUT the pass over (gm, z3) either: sum_m gm z3 = sum_k W[c][k] Q[c][k] (Q = the weight-gradient GEMM of _wgrad, taken FIRST) and
  *         sum_m gm from the column sums the kernels that stored gm took in their epilogues -- part_lo [c_split][rows_lo][2] (the MVF stencil's slice,
  *         mvf_nhwc_stencil_gate_sums with bn_z = NULL) and part_hi [c][rows_hi][2] indexed by the absolute channel (mvf_conv2d_nhwc_fwd_resmask_gate_sums
- *         with bn_z = NULL); element [.][.][0] is read.  dgamma[c] = invstd (W[c].Q[c] - mean sum gm), dbeta[c] = sum gm. */
-int mvf_bn_bwd_dzfree_sums(const float* q, const void* w_packed, int c, int k, const float* mean, const float* invstd, const float* part_lo, int rows_lo,
-                           int c_split, const float* part_hi, int rows_hi, float* dgamma, float* dbeta, int dtype, void* stream);
+ *         with bn_z = NULL); element [.][.][0] is read.  dgamma[c] = invstd (W[c].Q[c] - mean sum gm), dbeta[c] = sum gm.
+ *         q_slabs != NULL: Q arrives as the nslabs partial results of mvf_conv2d_nhwc_wgrad_slabs ([nslabs][c][k]); they are summed here in order and q [c][k]
+ *         is WRITTEN (the _wgrad correction reads it) -- the weight-gradient GEMM's own reduce launch is not needed. */
+int mvf_bn_bwd_dzfree_sums(float* q, const float* q_slabs, int nslabs, const void* w_packed, int c, int k, const float* mean, const float* invstd,
+                           const float* part_lo, int rows_lo, int c_split, const float* part_hi, int rows_hi, float* dgamma, float* dbeta, int dtype,
+                           void* stream);
 size_t mvf_bn_workspace_bytes(long m, int c);
 /* batch mean / biased var of z over m -> save_mean, save_invstd, scale = gamma*invstd, shift = beta - mean*scale;
  * running_mean/var updated in place (unbiased var).  Shifted single-pass sums (shift = old running_mean). */
@@ -407,6 +410,8 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
  * chip); results differ from mvf_conv2d_nhwc_wgrad only by the fp32 summation order of the pixel split. */
 int mvf_conv2d_nhwc_wgrad_wgs(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real,
                               int cin_real, int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, int wgs, void* stream);
+/* [r5] ... and without the slab reduce (pointwise convs): ws holds *nslabs partial results [nslabs][cout][cin] fp32 for a consumer that sums them itself. */
+int mvf_conv2d_nhwc_wgrad_slabs(const mvf_conv_desc_t* d, const void* dz, const void* x, void* ws, size_t ws_bytes, int wgs, int* nslabs, void* stream);
 /* Every weight pack of a training step in one launch.  jobs_dev = DEVICE array of njobs records sorted by first_block;
  * job k owns workgroups [first_block, first_block + ceil(elements / 2048)), total_blocks = their sum.  kind 0 = the forward
  * pack of mvf_pack_conv_weight (no scale), kind 1 = the data-gradient pack of mvf_pack_conv_weight_dgrad.  kind 2 / 3 = the

@@ -96,7 +96,7 @@ def _load():
     lib.mvf_bn_bwd_dzfree_wgrad.restype = i32
     lib.mvf_bn_bwd_dzfree_wgrad.argtypes = [fp, vp, fp, fp, fp, fp, fp, fp, fp, i64_, i32, i32, i32, vp]
     lib.mvf_bn_bwd_dzfree_sums.restype = i32
-    lib.mvf_bn_bwd_dzfree_sums.argtypes = [fp, vp, i32, i32, fp, fp, fp, i32, i32, fp, i32, fp, fp, i32, vp]
+    lib.mvf_bn_bwd_dzfree_sums.argtypes = [fp, fp, i32, vp, i32, i32, fp, fp, fp, i32, i32, fp, i32, fp, fp, i32, vp]
     lib.mvf_nhwc_stencil_stats_rows.restype = i32
     lib.mvf_nhwc_stencil_stats_rows.argtypes = [dp, i32, i32]
     lib.mvf_nhwc_stencil_stats.restype = i32
@@ -188,6 +188,8 @@ def _load():
     lib.mvf_conv2d_nhwc_wgrad.argtypes = [cp, vp, vp, vp, i32, i32, i32, i32, fp, vp, sz, vp]
     lib.mvf_conv2d_nhwc_wgrad_wgs.restype = i32
     lib.mvf_conv2d_nhwc_wgrad_wgs.argtypes = [cp, vp, vp, vp, i32, i32, i32, i32, fp, vp, sz, i32, vp]
+    lib.mvf_conv2d_nhwc_wgrad_slabs.restype = i32
+    lib.mvf_conv2d_nhwc_wgrad_slabs.argtypes = [cp, vp, vp, vp, sz, i32, C.POINTER(C.c_int), vp]
     lib.mvf_pack_conv_weight_dgrad.restype = i32
     lib.mvf_pack_conv_weight_dgrad.argtypes = [fp, i32, i32, i32, i32, vp, i32, vp]
     lib.mvf_nhwc_stencil.restype = i32

@@ -1255,14 +1255,15 @@ size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
 // kw_real/cin_real < packed extents only for the stem view (kh x 1 x 32 over the padded NHWC4 input = 7 x 8 x 4).
 }  // extern "C"
 static int wgrad_impl(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real, int cin_real,
-                      int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, void* stream, int wgs_target) {
-    MVF_REQUIRE(d && dz && x && dw_oihw, MVF_EINVAL, "wgrad: NULL argument");
+                      int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, void* stream, int wgs_target, int* nslabs_out = nullptr) {
+    MVF_REQUIRE(d && dz && x && (dw_oihw || nslabs_out), MVF_EINVAL, "wgrad: NULL argument");
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "wgrad: bad dtype");
     MVF_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride > 0, MVF_ESHAPE, "wgrad: cin/cout must be multiples of 4");
     MVF_REQUIRE(kw_packed * cin_packed == d->kw * d->cin && kw_real <= kw_packed && cin_real <= cin_packed, MVF_EINVAL, "wgrad: packed extents inconsistent");
     MVF_REQUIRE(ws && ws_bytes >= mvf_conv2d_wgrad_workspace_bytes(d), MVF_EWS, "wgrad: workspace too small");
     if (d->split_c) MVF_REQUIRE(x2 && d->kh == 1 && d->kw == 1 && d->split_c % 4 == 0, MVF_EINVAL, "wgrad: bad split_c");
     hipStream_t st0 = (hipStream_t)stream;
+    if (nslabs_out) MVF_REQUIRE(d->kh == 1 && d->kw == 1 && kw_real == kw_packed && cin_real == cin_packed, MVF_EINVAL, "wgrad_slabs: pointwise convs with unpadded packs only");
     if (wg_direct3x3(d) && kw_real == 3 && cin_real == 64 && kw_packed == 3 && cin_packed == 64 && ((uintptr_t)dz | (uintptr_t)x) % 16 == 0) {
         Wgrad3x3C64Args w = {dz, x, (float*)ws, d->n, d->h, d->w, d->x_pix_stride, mvf_internal::wgrad3x3_c64_wgs(d->n, d->h)};
         const int rc = mvf_internal::wgrad3x3_c64_launch(w, st0);
@@ -1360,6 +1361,10 @@ static int wgrad_impl(const mvf_conv_desc_t* d, const void* dz, const void* x, c
         else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 2>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
     }
     MVF_LAUNCH_CHECK();
+    if (nslabs_out) {          // the caller sums the slabs itself (ws: [nsplit][cout][cin] fp32)
+        *nslabs_out = nsplit;
+        return MVF_OK;
+    }
     const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);
     return launch_wgrad_reduce(a.part, nsplit, d->cout, cin_real, kh_p, kw_real, kw_packed, cin_packed, dw_oihw, st);
 }
@@ -1376,6 +1381,14 @@ int mvf_conv2d_nhwc_wgrad_wgs(const mvf_conv_desc_t* d, const void* dz, const vo
                               int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, int wgs, void* stream) {
     MVF_REQUIRE(wgs >= 8 && wgs <= 4096, MVF_EINVAL, "wgrad_wgs: wgs=%d outside 8 .. 4096", wgs);
     return wgrad_impl(d, dz, x, x2, kw_real, cin_real, kw_packed, cin_packed, dw_oihw, ws, ws_bytes, stream, wgs);
+}
+
+// [r5] ... without the slab reduce: ws holds nslabs partial results [nslabs][cout][cin] (fp32, in pixel-range order) for a consumer that sums them itself
+// (mvf_bn_bwd_dzfree_sums: one launch less on the launch stream).  Pointwise convs only.
+int mvf_conv2d_nhwc_wgrad_slabs(const mvf_conv_desc_t* d, const void* dz, const void* x, void* ws, size_t ws_bytes, int wgs, int* nslabs, void* stream) {
+    MVF_REQUIRE(nslabs && wgs >= 8 && wgs <= 4096, MVF_EINVAL, "wgrad_slabs: nslabs is NULL or wgs=%d outside 8 .. 4096", wgs);
+    MVF_REQUIRE(d && d->split_c == 0, MVF_EINVAL, "wgrad_slabs: no split operand");
+    return wgrad_impl(d, dz, x, nullptr, 1, d->cin, 1, d->cin, nullptr, ws, ws_bytes, stream, wgs, nslabs);
 }
 
 int mvf_pack_conv_weights_batched(const mvf_pack_job_t* jobs_dev, int njobs, int total_blocks, int dtype, void* stream) {

@@ -534,17 +534,23 @@ class _TConv(object):
         c, k = self.cout, self.cin
         d = self.desc(n, h, w, h, w, k, 0)
         ws = eng.workspace(lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d)))
-        self.launch_q(d, gm, a_in, ws, eng.dzfree_q_wgs)
+        ns = self.launch_q(d, gm, a_in, ws, eng.dzfree_q_wgs, slabs=eng.dzfree_q_slabs)
         lo, rows_lo, c_split, hi, rows_hi = bn._s1
         assert c_split == 0 or lo is not None, "the MVF slice's column sums are missing"
-        check(lib.mvf_bn_bwd_dzfree_sums(_p(self.dw), _p(self.wp), c, k, _p(bn.mean), _p(bn.invstd), _p(lo), rows_lo, c_split, _p(hi), rows_hi, _p(bn.dgamma),
+        check(lib.mvf_bn_bwd_dzfree_sums(_p(self.dw), _p(ws) if ns else None, ns, _p(self.wp), c, k, _p(bn.mean), _p(bn.invstd), _p(lo), rows_lo, c_split, _p(hi), rows_hi, _p(bn.dgamma),
                                          _p(bn.dbeta), eng.dt, _st()), "bn backward sums from the weight-gradient GEMM")
         bn._s1 = None
 
-    def launch_q(self, d, gm, a_in, ws, wgs):
-        """One weight-gradient GEMM (+ its slab reduce) on the launch stream (bench.py brackets this call with HIP events)."""
+    def launch_q(self, d, gm, a_in, ws, wgs, slabs=False):
+        """One weight-gradient GEMM on the launch stream (bench.py brackets this call with HIP events): with its slab reduce, or (slabs) leaving the partial
+        results in ws for mvf_bn_bwd_dzfree_sums to sum -- returns their count (0 = reduced into self.dw)."""
+        if slabs:
+            n = C.c_int(0)
+            check(lib.mvf_conv2d_nhwc_wgrad_slabs(C.byref(d), _p(gm), _p(a_in), _p(ws), ws.numel(), wgs, C.byref(n), _st()), "conv wgrad slabs (launch stream)")
+            return n.value
         check(lib.mvf_conv2d_nhwc_wgrad_wgs(C.byref(d), _p(gm), _p(a_in), None, self.kw, self.cin, self.kw, self.cin, _p(self.dw), _p(ws), ws.numel(), wgs, _st()),
               "conv wgrad (launch stream)")
+        return 0
 
     def gram_ok(self):
         """The shapes mvf_bn_train_stats_gram and its Gram GEMM take: a pointwise stride-1 conv in bf16 storage, channel counts in whole MFMA tiles."""
@@ -1159,6 +1165,9 @@ class _ParamStore(object):
     dzfree_q_wgs = int(os.environ.get("MVF_DZFREE_Q_WGS", "256"))
     dzfree_q_maxk = int(os.environ.get("MVF_DZFREE_Q_MAXK", "256"))
     dzfree_q_mink = int(os.environ.get("MVF_DZFREE_Q_MINK", "0"))
+    # Q's partial results summed by the sums kernel instead of a reduce launch of their own: measured 0.06-0.08 ms SLOWER on C3 (17.35 -> 17.43), neutral on C4
+    # (30.03-30.05 / 30.01-30.09): one wave per channel sums the slabs more slowly than the reduce kernel's full grid -- off
+    dzfree_q_slabs = os.environ.get("MVF_DZFREE_Q_SLABS", "0") != "0"
     # ... and such a block need not store z3 where bn3's apply is a second conv3 pass (_TBlock.q_z3_free: layer2's plain blocks).  Measured (ms, off / on, three
     # alternations): C3 17.93-17.95 / 17.96-17.99, C4 30.43-30.47 / 30.45-30.69 -- the statistics-only pass is no shorter in the step than the storing one; off.
     dzfree_q_z3free = os.environ.get("MVF_DZFREE_Q_Z3FREE", "0") != "0"

@@ -349,13 +349,19 @@ def test_sums_from_the_weight_gradient_gemm_equal_the_sums_pass(case):
     check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d3), P(gm), P(a2), None, 1, k, 1, k, P(q0), P(wsw), wsw.numel(), None))
     check(lib.mvf_conv2d_nhwc_wgrad_wgs(C.byref(d3), P(gm), P(a2), None, 1, k, 1, k, P(q), P(wsw), wsw.numel(), 256, None))
     dg, db = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-    check(lib.mvf_bn_bwd_dzfree_sums(P(q), P(w3), c, k, P(mean), P(invstd), P(part_lo), rows_lo, cs, P(part_hi), rows_hi, P(dg), P(db), L.MVF_BF16, None))
+    check(lib.mvf_bn_bwd_dzfree_sums(P(q), None, 0, P(w3), c, k, P(mean), P(invstd), P(part_lo), rows_lo, cs, P(part_hi), rows_hi, P(dg), P(db), L.MVF_BF16, None))
+    # ... and with Q handed over as the GEMM's partial results (mvf_conv2d_nhwc_wgrad_slabs): the same sums, Q written by the sums kernel
+    ns = C.c_int(0)
+    check(lib.mvf_conv2d_nhwc_wgrad_slabs(C.byref(d3), P(gm), P(a2), P(wsw), wsw.numel(), 256, C.byref(ns), None))
+    q2, dg2, db2 = torch.full((c, k), float("nan"), device="cuda"), torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    check(lib.mvf_bn_bwd_dzfree_sums(P(q2), P(wsw), ns.value, P(w3), c, k, P(mean), P(invstd), P(part_lo), rows_lo, cs, P(part_hi), rows_hi, P(dg2), P(db2), L.MVF_BF16, None))
     ws_bn = torch.empty(lib.mvf_bn_workspace_bytes(m, c), dtype=torch.uint8, device="cuda")
     dg0, db0 = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
     check(lib.mvf_bn_bwd_reduce(P(gm), c, P(z3), None, m, c, P(mean), P(invstd), None, None, 0, None, P(dg0), P(db0), P(ws_bn), ws_bn.numel(), 1, None))
     torch.cuda.synchronize()
     ref_q = gm.double().t() @ a2.double()
     assert rel_l2(q.cpu().numpy(), ref_q.cpu().numpy()) < 1e-5 and rel_l2(q.cpu().numpy(), q0.cpu().numpy()) < 1e-5
+    assert ns.value > 0 and rel_l2(q2.cpu().numpy(), ref_q.cpu().numpy()) < 1e-5 and rel_l2(dg2.cpu().numpy(), dg.cpu().numpy()) < 1e-5 and torch.equal(db2, db)
     ref_dg = (gm.double() * (z3x - mean.double()) * invstd.double()).sum(0)
     e_pass, e_q = rel_l2(dg0.cpu().numpy(), ref_dg.cpu().numpy()), rel_l2(dg.cpu().numpy(), ref_dg.cpu().numpy())
     print("case %s: dgamma vs fp64 on the unrounded z3: sums pass (bf16 z3) %.2e, from Q %.2e; dbeta %.2e" %
