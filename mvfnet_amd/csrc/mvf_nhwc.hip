@@ -621,6 +621,7 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     // (the plan depends on the shape only -- mvf_nhwc_stencil_stats_rows must name the same partial rows as the launch; operands that break its alignment
     // rules fall back to the chunked kernel, which is an error when partial rows were asked for)
     const bool lds_shape = d->dtype == MVF_BF16 && d->cs % 16 == 0 && d->c % 8 == 0 && out_c % 4 == 0 && (!fl.add || fl.add_c % 4 == 0) && !a.tsplit &&
+                           (long)a.T * d->h * d->w * d->c * 2 < 0x7ffffff0L &&          // (one clip inside a 32-bit buffer descriptor)
                            lds_plan(a.T, d->h, d->w, d->cs, a.n_clips, lp);
     const bool use_lds = lds_shape && vec && (uintptr_t)x % 16 == 0 && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0 &&
                          (!fl.gs_z || (uintptr_t)fl.gs_z % 8 == 0);
