@@ -451,6 +451,10 @@ int mvf_nhwc_stencil_gate_sums(const mvf_desc_t* d, const void* x, int x_c, void
  * values it stores: stats_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] = per-workgroup sums of (y - K), (y - K)^2, K =
  * stats_shift (the old running mean; NULL = 0) -> mvf_bn_train_finalize.  Replaces the statistics pass over y. */
 int mvf_nhwc_stencil_stats_rows(const mvf_desc_t* d, int x_c, int out_c);
+/* [r6] plan query (nothing is launched): 1 = a stencil launch of this shape (16-byte aligned operands) runs on the LDS-tiled bf16 kernel, with
+ * rows_per_band x chan_per_wg (both optional) its tile; 0 = the register-chunked kernel (fp32, slices not in 16-channel chunks, one clip of the source
+ * larger than a 32-bit buffer descriptor, fewer workgroups than the tile needs). */
+int mvf_nhwc_stencil_tile_plan(const mvf_desc_t* d, int x_c, int out_c, int* rows_per_band, int* chan_per_wg);
 int mvf_nhwc_stencil_stats(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
                            const float* w_w, float* stats_part, const float* stats_shift, void* stream);
 size_t mvf_nhwc_tapgrad_workspace_bytes(const mvf_desc_t* d);

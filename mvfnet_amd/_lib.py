@@ -50,7 +50,9 @@ def _load():
     vp, fp, sz, i32, f32 = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float
     dp = C.POINTER(MvfDesc)
     lib.mvf_abi_version.restype = i32
+    lib.mvf_abi_version.argtypes = []
     lib.mvf_last_error.restype = C.c_char_p
+    lib.mvf_last_error.argtypes = []
     lib.mvf_fwd_infer.restype = i32
     lib.mvf_fwd_infer.argtypes = [dp, vp, vp, fp, fp, fp, fp, fp, vp]
     lib.mvf_fwd_train_workspace_bytes.restype = sz
@@ -99,6 +101,8 @@ def _load():
     lib.mvf_bn_bwd_dzfree_sums.argtypes = [fp, fp, i32, vp, i32, i32, fp, fp, fp, i32, i32, fp, i32, fp, fp, i32, vp]
     lib.mvf_nhwc_stencil_stats_rows.restype = i32
     lib.mvf_nhwc_stencil_stats_rows.argtypes = [dp, i32, i32]
+    lib.mvf_nhwc_stencil_tile_plan.restype = i32
+    lib.mvf_nhwc_stencil_tile_plan.argtypes = [dp, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mvf_nhwc_stencil_stats.restype = i32
     lib.mvf_nhwc_stencil_stats.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, fp, fp, vp]
     lib.mvf_nhwc_stencil_gate.restype = i32
@@ -204,10 +208,12 @@ def _load():
     lib.mvf_sgd_nesterov_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, f32, i32, fp, vp, sz, vp]
     lib.mvf_sgd_step_segments.restype = i32
     lib.mvf_sgd_step_segments.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, f32, i32, i32, vp, i32, fp, vp, sz, vp]
+    # Callers pass device pointers as plain Python ints (train_engine._p): without declared argtypes ctypes would truncate them to c_int silently.  Every
+    # function the header declares must therefore have its signature declared above.
+    missing = [n for n in declared_symbols() if hasattr(lib, n) and getattr(lib, n).argtypes is None]
+    if missing:
+        raise ImportError("mvfnet_amd._lib: no argtypes declared for %s" % missing)
     return lib
-
-
-lib = _load()
 
 
 def check(rc, what=""):
@@ -223,3 +229,6 @@ def declared_symbols():
     txt = open(hdr).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b((?:mvf|mvfnet)_[a-z0-9_]+)\s*\(", txt)))
+
+
+lib = _load()

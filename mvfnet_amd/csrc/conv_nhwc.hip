@@ -2229,6 +2229,8 @@ int mvf_conv2d_nhwc_fwd_resmask_gate_sums(const mvf_conv_desc_t* d, const void* 
                                           const float* bn_mean, const float* bn_invstd, float* sums_part, void* ws, size_t ws_bytes, void* stream) {
     MVF_REQUIRE(d && residual && out_gate_bits && sums_part && d->in_dil <= 1 && !d->relu, MVF_EINVAL,
                 "conv2d_resmask_gate_sums: needs a residual, the gate bits, a partial buffer and a stride-1 launch without ReLU");
+    MVF_REQUIRE(((uintptr_t)out_gate_bits | (uintptr_t)(res_sign_bits ? res_sign_bits : out_gate_bits)) % 16 == 0 || d->cout % 64 != 0, MVF_EINVAL,
+                "conv2d_resmask_gate_sums: gate byte rows must be 16-byte aligned");      // (the epilogue stages both byte planes with 16-byte buffer loads, as _gate does)
     if (!bn_z)       // column sums only: [.][.][0] = sum gm, [.][.][1] = sum gm^2 (the dz3-free backward takes dgamma from its weight-gradient GEMM: mvf_bn_bwd_dzfree_sums)
         return conv_fwd_impl(d, x, x2, w_packed, nullptr, residual, y, sums_part, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits);
     MVF_REQUIRE(bn_mean && bn_invstd, MVF_EINVAL, "conv2d_resmask_gate_sums: bn_z needs bn_mean / bn_invstd");

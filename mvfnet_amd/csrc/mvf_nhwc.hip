@@ -548,6 +548,14 @@ static bool lds_plan(int T, int H, int W, int cs, int n_clips, LdsPlan& best) {
     return false;
 }
 
+// the shape rule of the LDS-tiled kernel (operand alignment is checked at the launch): bf16, a slice in whole 16-channel chunks, ONE CLIP of the source tensor
+// inside a 32-bit buffer descriptor (the tile's DMA offsets are clip-relative 32-bit byte offsets), and a plan
+static bool lds_shape_plan(const mvf_desc_t* d, int out_c, LdsPlan& lp) {
+    return d->dtype == MVF_BF16 && d->cs % 16 == 0 && d->c % 8 == 0 && out_c % 4 == 0 && d->n_segment > 0 &&
+           (long)d->n_segment * d->h * d->w * d->c * 2 < 0x7ffffff0L &&
+           lds_plan(d->n_segment, d->h, d->w, d->cs, d->nt / d->n_segment, lp);
+}
+
 template <int TT>
 static void launch_lds(const NhwcArgs& a, const LdsPlan& p, hipStream_t st) {
     dim3 grid(a.n_clips * p.bands, a.cs / p.cw);
@@ -620,9 +628,7 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     LdsPlan lp = {};
     // (the plan depends on the shape only -- mvf_nhwc_stencil_stats_rows must name the same partial rows as the launch; operands that break its alignment
     // rules fall back to the chunked kernel, which is an error when partial rows were asked for)
-    const bool lds_shape = d->dtype == MVF_BF16 && d->cs % 16 == 0 && d->c % 8 == 0 && out_c % 4 == 0 && (!fl.add || fl.add_c % 4 == 0) && !a.tsplit &&
-                           (long)a.T * d->h * d->w * d->c * 2 < 0x7ffffff0L &&          // (one clip inside a 32-bit buffer descriptor)
-                           lds_plan(a.T, d->h, d->w, d->cs, a.n_clips, lp);
+    const bool lds_shape = (!fl.add || fl.add_c % 4 == 0) && !a.tsplit && lds_shape_plan(d, out_c, lp);
     const bool use_lds = lds_shape && vec && (uintptr_t)x % 16 == 0 && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0 &&
                          (!fl.gs_z || (uintptr_t)fl.gs_z % 8 == 0);
     MVF_REQUIRE(use_lds || !lds_shape || !fl.stats_part, MVF_EINVAL, "nhwc_stencil: operands of a statistics launch must be 16-byte aligned (x, taps) / 8-byte (out, addend, bn_z)");
@@ -1030,6 +1036,20 @@ int mvf_nhwc_stencil_gate_sums(const mvf_desc_t* d, const void* x, int x_c, void
 // [r5] the plain stencil (y = taps * x-slice, no activation) that ALSO accumulates the batch statistics of MVF's BatchNorm3d (MVF.py:131-134, training
 // mode) over what it stores: stats_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, ...)][2] = per-workgroup sums of (y - K), (y - K)^2 with
 // K = stats_shift (the old running mean; NULL = 0) -> mvf_bn_train_finalize.  Replaces the separate statistics pass over y (mvf_bn_train_stats).
+// [r6] Which kernel a stencil launch of this shape takes (16-byte aligned operands assumed): 1 = the LDS-tiled kernel (rows_per_band / chan_per_wg = its tile),
+// 0 = the register-chunked kernel (fp32, slices not in 16-channel chunks, a clip larger than a 32-bit buffer descriptor, launches below the workgroup threshold).
+// A plan query for tests and tooling; nothing is launched.
+int mvf_nhwc_stencil_tile_plan(const mvf_desc_t* d, int x_c, int out_c, int* rows_per_band, int* chan_per_wg) {
+    if (!d || d->cs <= 0 || d->nt <= 0 || d->n_segment <= 0) return 0;
+    mvf_desc_t dd = *d;
+    dd.c = x_c;
+    LdsPlan lp = {};
+    if (!lds_shape_plan(&dd, out_c, lp)) return 0;
+    if (rows_per_band) *rows_per_band = lp.rb;
+    if (chan_per_wg) *chan_per_wg = lp.cw;
+    return 1;
+}
+
 int mvf_nhwc_stencil_stats_rows(const mvf_desc_t* d, int x_c, int out_c) {
     if (!d || d->cs <= 0 || d->nt <= 0) return 0;
     mvf_desc_t dd = *d;

@@ -466,6 +466,149 @@ __global__ __launch_bounds__(WMG * 128) void wgrad_bf16_kernel(WgArgs a) {
     }
 }
 
+// ---- [r6] the four-wave bf16 tile on an NS-stage LDS-DMA ring -------------------------------------------------------------------------------------
+// wgrad_bf16_kernel<.., DMA = true> keeps ONE chunk in flight (two buffers, vmcnt(0) + barrier per chunk): a chunk is 16 matrix instructions per wave = 0.2 us
+// of matrix work against ~1 us of L2 / HBM latency, and the plans give these launches one workgroup per CU (the side stream's footprint rule), so nothing else
+// on the CU hides it -- layer2's 3 x 3 (M = 200704, N = 128, K = 1152) ran 112 chunks in 126 us = 1.1 us per chunk, 19 % of the matrix rate.  Here NS - 1
+// chunks are in flight: NS buffers of [64 pixels][BCO + BK channels], the wait is a COUNTED vmcnt((NS - 2) * instructions per chunk) (loads retire in order,
+// so the oldest chunk has landed), one raw s_barrier per chunk (it also says every wave is done reading the buffer the next DMA overwrites); the look-ahead
+// DMAs past the split's last chunk are issued unconditionally with out-of-range offsets (zeros into a buffer nobody reads) so that the count stays static.
+// Same LDS images, transpose reads, accumulation order and slab layout as wgrad_bf16_kernel: results are bit-identical to it.
+template <int N>
+__device__ __forceinline__ void wg_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int TM, int TN, int NS>
+__global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgArgs a) {
+    constexpr int kThreads = 256;
+    constexpr int BCO = 2 * TM * 32, BK = 2 * TN * 32;
+    constexpr int PA = BCO * 2, PB = BK * 2;                        // LDS row pitches in bytes
+    constexpr int UA = BCO / 8, UB = BK / 8;                        // 16-B units (8 bf16) per row
+    constexpr int NA = BMR16 * UA / kThreads, NB = BMR16 * UB / kThreads;
+    constexpr int IPC = NA + NB;                                    // LDS-DMA instructions per thread per chunk
+    static_assert(NS >= 3 && (NS - 2) * IPC < 64, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    char* Ds = smem16;                                              // [NS][BMR16][PA]
+    char* Xs = smem16 + NS * BMR16 * PA;                            // [NS][BMR16][PB]
+    int wg_tile, wg_split;
+    if (!wg_map(a.tiles, a.nsplit, wg_tile, wg_split, a.xcd_rr)) return;
+    const int tile_k = wg_tile % a.tiles_k, tile_co = wg_tile / a.tiles_k;
+    const int co0 = tile_co * BCO, k0 = tile_k * BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ra0 = tid / UA, rb0 = tid / UB;
+    const int qa = (tid % UA) ^ swz16<UA>(ra0);                     // the source unit that belongs at LDS position tid % U (rows advance by multiples of 4)
+    const int qb = (tid % UB) ^ swz16<UB>(rb0);
+    const bool co_ok = co0 + qa * 8 < a.Cout;
+    const int kcol = k0 + qb * 8;
+    const bool k_ok = kcol < a.K;
+    const int tap = k_ok ? kcol / a.Cin : 0;
+    const int ci = k_ok ? kcol - tap * a.Cin : 0;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const bf16_t* dzp = reinterpret_cast<const bf16_t*>(a.dz);
+    const int m_begin = wg_split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nchunks = (m_end - m_begin + BMR16 - 1) / BMR16;
+    constexpr unsigned kOOB = 0x80000000u;
+    const int hw_o = a.Ho * a.Wo;
+    const i32x4 gs_dz = rsrc_words(dzp + (long)m_begin * a.Cout, (unsigned)min((long)(m_end - m_begin) * a.Cout * 2, 0x7ffffff0L));
+    const bool x2u = a.split_c > 0 && (k0 % a.Cin) < a.split_c;     // uniform per workgroup (host: split_c % BK == 0, cin % BK == 0)
+    const int ps = x2u ? a.x2ps : a.xps;
+    const i32x4 gs_x = rsrc_words(x2u ? a.x2 : a.x, (unsigned)min((long)a.N * a.H * a.W * ps * 2, 0x7ffffff0L));
+    const unsigned lds_d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)Ds + (wave * 64 / UA) * PA);
+    const unsigned lds_x0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)Xs + (wave * 64 / UB) * PB);
+    const unsigned dz_col = (unsigned)(qa * 8 + co0) * 2u;
+    const unsigned x_tap = (unsigned)((kh * a.W + kw) * ps + ci) * 2u;
+    auto dma_chunk = [&](int c, int buf) {
+        const int mc = m_begin + c * BMR16;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = c * BMR16 + ra0 + (kThreads / UA) * i;                       // row within the split; past its end = past the descriptor's range
+            const unsigned off = co_ok ? (unsigned)(r * a.Cout) * 2u + dz_col : kOOB;
+            glds16(gs_dz, lds_d0 + (unsigned)((buf * BMR16 + (kThreads / UA) * i) * PA), off);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int m = mc + rb0 + (kThreads / UB) * i;
+            const int img = wg_fd_div(m, a.fd_hw_mul, a.fd_hw_shr), rem = m - img * hw_o;
+            const int oh = wg_fd_div(rem, a.fd_w_mul, a.fd_w_shr), ow = rem - oh * a.Wo;
+            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+            const bool ok = m < m_end && k_ok && (unsigned)(ih0 + kh) < (unsigned)a.H && (unsigned)(iw0 + kw) < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)(((img * a.H + ih0) * a.W + iw0) * ps) * 2u + x_tap : kOOB;
+            glds16(gs_x, lds_x0 + (unsigned)((buf * BMR16 + (kThreads / UB) * i) * PB), off);
+        }
+    };
+    const int tg = lane >> 4, ti = lane & 15;
+    const int trow = (ti >> 2) + 8 * (tg >> 1);
+    const int tunit = 2 * (tg & 1) + ((ti & 3) >> 1), thalf = ti & 1;
+    int offA[TM], offB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offA[i] = trow * PA + ((((wm * TM + i) * 4 + tunit) ^ swz16<UA>(trow)) * 16) + thalf * 8;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offB[j] = trow * PB + ((((wn * TN + j) * 4 + tunit) ^ swz16<UB>(trow)) * 16) + thalf * 8;
+    auto gather = [&](const char* p, int pitch) {          // rows +0..3 and +4..7 of the lane's channel
+        typedef short v4s __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s* lds_v4s;
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p + 4 * pitch));
+        bf16x8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return v;
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < BMR16 / 16; ++ks) {
+            const int r0 = buf * BMR16 + ks * 16;
+            bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = gather(Ds + r0 * PA + offA[i], PA);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = gather(Xs + r0 * PB + offB[j], PB);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_) dma_chunk(s_, s_);
+    for (int cc = 0; cc < nchunks; cc += NS) {
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            if (cc + s_ < nchunks) {                                 // (wave-uniform)
+                wg_wait_vmcnt<(NS - 2) * IPC>();                     // chunk cc + s_ has landed (this thread's pieces) ...
+                __builtin_amdgcn_s_barrier();                        // ... everybody's; and the buffer of chunk cc + s_ - 1 is free
+                dma_chunk(cc + s_ + NS - 1, (s_ + NS - 1) % NS);
+                compute(s_);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the look-ahead DMAs target this workgroup's LDS: let them land before it is released
+    float* outp = a.part + (long)wg_split * a.Cout * a.K;
+    const int lr = lane >> 5, lc = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = k0 + (wn * TN + j) * 32 + lc;
+        if (col >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lr;
+                if (row < a.Cout) outp[(long)row * a.K + col] = acc[i][j][r];
+            }
+    }
+}
+
 // ---- [r4] fp32 operands on the BF16 matrix cores with fp32 accuracy (the weight-gradient side of conv_nhwc.hip's X3) -------------------
 // Every fp32 value of dz and x is split exactly into three bf16 terms (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid): both
 // differences are exactly representable in fp32) on its way from the staging registers into LDS, one [pixel][channel] bf16 image per term in
@@ -919,6 +1062,23 @@ int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
     static const int dma_env = getenv("MVF_WGRAD_DMA") ? atoi(getenv("MVF_WGRAD_DMA")) : 1;
     const bool dma = dma_env && (a.split_c == 0 || (dma_env != 3 && a.split_c % BK == 0 && a.Cin % BK == 0)) &&
                      (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 2 < 0x7ffffff0L && (dma_env == 2 || (a.K >= 128 && a.Cin >= 32));
+    // [r6] MVF_WGRAD_STAGES: LDS-DMA ring depth of the four-wave tile (2 = the two-buffer kernel; default 3 = two chunks in flight; 4 measured the same)
+    static const int stages_env = getenv("MVF_WGRAD_STAGES") ? atoi(getenv("MVF_WGRAD_STAGES")) : 3;
+    if (dma && stages_env >= 3) {
+        const size_t lds_p = (size_t)(stages_env >= 4 ? 4 : 3) * BMR16 * (BCO * 2 + BK * 2);
+        auto k3 = wgrad_bf16_pipe_kernel<TM, TN, 3>;
+        auto k4 = wgrad_bf16_pipe_kernel<TM, TN, 4>;
+        static bool attr_p = false;
+        if (!attr_p) {
+            MVF_HIP_OK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * BMR16 * (BCO * 2 + BK * 2))));
+            MVF_HIP_OK(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * BMR16 * (BCO * 2 + BK * 2))));
+            attr_p = true;
+        }
+        if (stages_env >= 4) hipLaunchKernelGGL(k4, dim3(nsplit * tiles), dim3(kThreads), lds_p, st, a);
+        else hipLaunchKernelGGL(k3, dim3(nsplit * tiles), dim3(kThreads), lds_p, st, a);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     if (dma) {
         auto kd = wgrad_bf16_kernel<TM, TN, true>;
         static bool attr_d = false;

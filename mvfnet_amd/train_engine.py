@@ -28,7 +28,7 @@ F32 = _lib.MVF_F32
 # [r5] Descriptors are memoised by their field values (shapes are static from step to step): building a 19-field ctypes structure per launch and asking the library for
 # mvf_conv2d_stats_rows each time was ~1.5 ms of host time per step (~300 + ~100 calls).
 _ConvDescT, _MvfDescT = ConvDesc, MvfDesc
-_DESC_CACHE, _ROWS_CACHE = {}, {}
+_DESC_CACHE = {}
 
 
 def ConvDesc(*a):      # noqa: F811
@@ -47,9 +47,11 @@ def MvfDesc(*a):       # noqa: F811
 
 
 def _stats_rows(d):
-    r = _ROWS_CACHE.get(id(d))
+    # kept ON the descriptor object (not in a table keyed by id(d): a descriptor built outside the memo and collected would hand its id -- and a stale row
+    # count, i.e. an undersized partial-sum buffer -- to the next object allocated there)
+    r = d.__dict__.get("_rows")
     if r is None:
-        r = _ROWS_CACHE[id(d)] = lib.mvf_conv2d_stats_rows(C.byref(d))
+        r = d._rows = lib.mvf_conv2d_stats_rows(C.byref(d))
     return r
 
 
@@ -59,6 +61,7 @@ def _p(t):
 
 
 _STREAM = [None]      # cached HIP stream handle of the stream the engine is launching on (torch.cuda.current_stream() costs ~8 us)
+_MAINH = [None]       # handle of the launch stream while an engine entry point is running (_on_stream(main=True)); None outside: _conv_ws asks torch then
 
 
 def _st():
@@ -66,21 +69,26 @@ def _st():
 
 
 class _on_stream(object):
-    """with _on_stream(torch_stream_or_None): every _st() inside returns that stream's handle."""
+    """with _on_stream(torch_stream_or_None): every _st() inside returns that stream's handle.  main=True (the engine's entry points): that stream also is the
+    LAUNCH stream for the duration of the block -- _conv_ws() compares against it instead of asking torch -- and stops being it on exit, so a launch made outside
+    an entry point, or by another engine on another stream, never inherits a stale handle."""
 
-    def __init__(self, stream=None):
+    def __init__(self, stream=None, main=False):
         self.h = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self.main = main
 
     def __enter__(self):
-        self.old = _STREAM[0]
+        self.old, self.oldm = _STREAM[0], _MAINH[0]
         _STREAM[0] = self.h
+        if self.main:
+            _MAINH[0] = self.h.value
 
     def __exit__(self, *a):
         _STREAM[0] = self.old
+        _MAINH[0] = self.oldm
 
 
 _SIDE_WS = {}
-_MAINH = [None]      # handle of the engine's launch stream (set at every entry point: torch.cuda.current_stream() in _conv_ws was 115 calls = 0.9 ms of host time per step)
 
 
 def _conv_ws(device):
@@ -1414,14 +1422,14 @@ class BlockTrainer(_ParamStore):
         nt, c, h, w = x_nchw.shape
         self.nt = nt
         self._main = torch.cuda.current_stream()
-        _MAINH[0] = self._main.cuda_stream
-        for b in self.blks:
-            for cv in b.convs():
-                cv.pack()
         out = x_nchw.permute(0, 2, 3, 1).contiguous().view(nt * h * w, c).to(self.tdtype)
         ho, wo, co = h, w, c
-        for b in self.blks:
-            out, ho, wo, co = b.forward(out, nt, ho, wo, co, self)
+        with _on_stream(self._main, main=True):
+            for b in self.blks:
+                for cv in b.convs():
+                    cv.pack()
+            for b in self.blks:
+                out, ho, wo, co = b.forward(out, nt, ho, wo, co, self)
         return out.view(nt, ho, wo, co).permute(0, 3, 1, 2)
 
     def backward(self, g_nchw):
@@ -1430,12 +1438,14 @@ class BlockTrainer(_ParamStore):
         h, w, c = s["h"], s["w"], s["c"]
         g = g_nchw.permute(0, 2, 3, 1).contiguous().view(nt * ho * wo, co).to(self.tdtype)
         gated = sums = False
-        for i in range(len(self.blks) - 1, -1, -1):
-            req = self.blks[i - 1].wants_gated_gradient(self) if i > 0 else None
-            g = self.blks[i].backward(g, nt, self, g_gated=gated, gate=req, sums_done=sums)
-            gated, sums = self.blks[i].gated_out, self.blks[i].sums_out
-        dx = g
-        self.join_side()
+        self._main = torch.cuda.current_stream()
+        with _on_stream(self._main, main=True):
+            for i in range(len(self.blks) - 1, -1, -1):
+                req = self.blks[i - 1].wants_gated_gradient(self) if i > 0 else None
+                g = self.blks[i].backward(g, nt, self, g_gated=gated, gate=req, sums_done=sums)
+                gated, sums = self.blks[i].gated_out, self.blks[i].sums_out
+            dx = g
+            self.join_side()
         return dx.view(nt, h, w, c).permute(0, 3, 1, 2)
 
 
@@ -1518,9 +1528,8 @@ class TrainEngine(_ParamStore):
         if not imgs.is_cuda or imgs.dtype not in (torch.float32, torch.uint8):
             raise RuntimeError("TrainEngine.forward: float32 (or uint8 frames) GPU input required")
         self._main = torch.cuda.current_stream()
-        _MAINH[0] = self._main.cuda_stream
         self.forward_count += 1
-        with _on_stream(self._main):
+        with _on_stream(self._main, main=True):
             return self._forward(imgs, labels, stages)
 
     def set_options(self, lr=None, momentum=None, weight_decay=None, max_norm=None, dtype=None):
@@ -1611,9 +1620,8 @@ class TrainEngine(_ParamStore):
         """exchange=True (train_step): this engine also owns the data-parallel gradient exchange and may start it during
         backward; False (autograd API / external optimizer hooks): gradients are only produced."""
         self._main = torch.cuda.current_stream()
-        _MAINH[0] = self._main.cuda_stream
         self._exchange = bool(exchange)
-        with _on_stream(self._main):
+        with _on_stream(self._main, main=True):
             self._backward()
 
     def _backward(self):
@@ -1726,7 +1734,7 @@ class TrainEngine(_ParamStore):
     force_allreduce = False
 
     def step(self, lr=None):
-        with _on_stream(torch.cuda.current_stream()):
+        with _on_stream(torch.cuda.current_stream(), main=True):
             return self._step(lr)
 
     def _step(self, lr=None):

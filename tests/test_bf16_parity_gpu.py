@@ -351,6 +351,14 @@ def test_full_size_bf16_train_step_properties(cfg):
     rel = np.abs(n3 - n1) / np.maximum(n1, 1e-12)
     print("R%d T=%d x %d clips, permutation: loss %.6f vs %.6f, grad-norm rel diff median %.2e max %.2e" % (depth, T, clips, float(l1), float(l3), np.median(rel), rel.max()))
     assert abs(float(l3) - float(l1)) < 1e-3 * abs(float(l1))               # measured 3e-5
+    # [r6] per layer group: a wrong gradient in ONE layer (say 10 %) moves that group's median, which the network-wide median / max of 161-314 parameters cannot see
+    names = [n for n, _ in m.named_parameters()]
+    group = lambda n: n.split(".")[1] if n.startswith("backbone.layer") else ("stem" if n.startswith("backbone.") else "head")      # noqa: E731
+    groups = {}
+    for n, r in zip(names, rel):
+        groups.setdefault(group(n), []).append(r)
+    table = {k: (float(np.median(v)), float(np.max(v)), len(v)) for k, v in groups.items()}
+    print("  per group (median, max, parameters): " + ", ".join("%s %.1e %.1e %d" % ((k,) + v) for k, v in table.items()))
     # measured C3: median 6e-3, max 0.11 (a re-ordered sum re-diverges to the bf16 floor); the 33-block R101 amplifies that further.  [r5] with bn3's
     # statistics of the z3-free blocks from the Gram matrix of a2 (eng.gram_stats) a re-ordering moves those statistics by ONE fp32 ulp (5e-8: measured at full
     # size, profiles/r05_gram_stats.txt; they are at fp32 epsilon against fp64) where the pass they replace, which reduces its partial rows in double, did not
