@@ -41,12 +41,19 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # MI355X_MICROARCH.md: dense MFMA peaks (fp32-in / bf16)
-# fp32 convs run on the BF16 matrix cores as six bf16 partial products per fp32 product (conv_tile X3, the default; MVF_F32_X3=0 = the fp32
+# fp32 convs run on the BF16 matrix cores as six bf16 partial products per fp32 product (conv_tile X3, the default; MVF_POLICY=f32_x3=0 = the fp32
 # MFMA): their ceiling in fp32-EQUIVALENT flops is the bf16 peak / 6.  The fp32 weight gradients keep the fp32 MFMA (157.3).
-F32_X3 = os.environ.get("MVF_F32_X3", "1") != "0"
+def _policy(name, default):           # MVF_POLICY="name=value,..." (mvfnet_amd/policy.py; parsed here without importing torch)
+    for item in os.environ.get("MVF_POLICY", "").replace(";", ",").split(","):
+        if item.split("=")[0].strip().lower() == name and "=" in item:
+            return int(item.split("=", 1)[1])
+    return default
+
+
+F32_X3 = _policy("f32_x3", 1) != 0
 F32_CONV_PEAK = PEAK_TFLOPS["bf16"] / 6.0 if F32_X3 else PEAK_TFLOPS["f32"]
-# the fp32 weight gradients likewise ([r4] wgrad_x3_kernel; MVF_WGRAD_X3=0 = the fp32 MFMA kernel)
-F32_WGRAD_PEAK = PEAK_TFLOPS["bf16"] / 6.0 if (F32_X3 and os.environ.get("MVF_WGRAD_X3", "1") != "0") else PEAK_TFLOPS["f32"]
+# the fp32 weight gradients likewise ([r4] wgrad_x3_kernel; MVF_POLICY=wgrad_x3=0 = the fp32 MFMA kernel)
+F32_WGRAD_PEAK = PEAK_TFLOPS["bf16"] / 6.0 if (F32_X3 and _policy("wgrad_x3", 1) != 0) else PEAK_TFLOPS["f32"]
 VIDEO = False
 T_FRAMES, SIZE = 8, 224     # overwritten from --frames / --mode video in main()
 
@@ -451,7 +458,7 @@ def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None, kernel=None, pm
         common.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tflops / peak, 4)})
         if peak_tf and abs(peak_tf - PEAK_TFLOPS["f32"]) > 1.0:
             common["peak_note"] = ("fp32-equivalent flops on the bf16 matrix cores: six bf16 partial products per fp32 product (exact three-term split), "
-                                   "peak = 2500 / 6 TF/s; MVF_F32_X3=0 runs the fp32 MFMA (157.3)")
+                                   "peak = 2500 / 6 TF/s; MVF_POLICY=f32_x3=0 runs the fp32 MFMA (157.3)")
     return common
 
 
@@ -654,7 +661,9 @@ def other_configs(seconds):
             "C5 in bf16": ["--mode", "video", "--dtype", "bf16"]}
     out = {}
     for name, flags in runs.items():
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-eager-compare", "--no-other-configs"] + flags
+        # ([r6] 5 warm-up steps: a train engine replays its launch plan from the fifth step on -- two eager steps, two recorded ones)
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10" if "train" in flags else "5", "--warmup", "5" if "train" in flags else "2", "--no-cpu-baseline",
+               "--no-eager-compare", "--no-other-configs"] + flags
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=seconds, env=dict(os.environ, BENCH_CHILD="1"))
             line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
@@ -668,6 +677,15 @@ def other_configs(seconds):
                          "conv_mfma_frac": rf.get("mfma_frac")}
             if "videos_per_s" in d:
                 out[name]["videos_per_s"] = d["videos_per_s"]
+            # [r6] every kernel group of this configuration (not only the conv family): time, roofline fraction, algorithmic and counter bytes per step
+            keep = ("ms_per_step", "launches_per_step", "bound", "frac", "hbm_frac", "mfma_frac", "alg_bytes_per_step", "traffic_per_step", "traffic_over_algorithmic",
+                    "counter_bytes", "counter_bytes_over_fused_floor", "fused_floor_bytes", "step_hbm_frac", "counter_hbm_frac")
+            groups = {"conv_required": rf}
+            groups.update({g: rf[g] for g in ("family", "wgrad", "bn", "bn_wgrad", "mvf", "step") if isinstance(rf.get(g), dict)})
+            out[name]["roofline"] = {g: {k: v[k] for k in keep if k in v} for g, v in groups.items()}
+            src = rf.get("traffic_source") or (rf.get("step") or {}).get("counter_source")
+            if src:
+                out[name]["roofline"]["counter_source"] = src[:160]
         except subprocess.TimeoutExpired:
             out[name] = {"error": "timed out after %.0f s" % seconds}
     return out

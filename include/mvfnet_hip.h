@@ -169,14 +169,13 @@ int mvf_conv2d_nhwc_fwd_resmask(const mvf_conv_desc_t* d, const void* x, const v
 int mvf_conv2d_nhwc_fwd_resmask_gate(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                                      const void* residual, const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y,
                                      void* ws, size_t ws_bytes, void* stream);
-/* [r5] ... and the BatchNorm-backward sums of the gated output in the same epilogue: with gm = y (as stored) on channels >= d->res_c0, sums_part
- * CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] = per-128-row column sums of gm and gm * (bn_z - bn_mean) * bn_invstd, bn_z = the stored input of the
- * BatchNorm whose output gradient y is (bn3 of the block below, resnet.py:236-244) -> mvf_bn_bwd_finalize on the channel range [res_c0, cout): that block's
- * sums pass over (gm, z3) disappears.  (Channels below res_c0 get meaningless partial rows: finalize the range only.)  bn_z = NULL: the column sums of gm and
- * gm^2 instead (no read of z3 at all): mvf_bn_bwd_dzfree_sums completes them with the weight-gradient GEMM. */
-int mvf_conv2d_nhwc_fwd_resmask_gate_sums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* residual,
-                                          const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y, const void* bn_z,
-                                          const float* bn_mean, const float* bn_invstd, float* sums_part, void* ws, size_t ws_bytes, void* stream);
+/* [r5] ... and the column sums of the gated output in the same epilogue: with gm = y (as stored), sums_part CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] =
+ * per-128-row column sums of gm and gm^2.  The dz3-free block below (resnet.py:236-244 under autograd) takes bn3's dbeta from them and dgamma from its
+ * weight-gradient GEMM (mvf_bn_bwd_dzfree_sums): no pass over (gm, z3), no read of z3.  (Channels below res_c0 belong to the MVF stencil's launch.)
+ * ([r6] the form that read z3 here for the complete sums measured neutral for two rounds and was removed.) */
+int mvf_conv2d_nhwc_fwd_resmask_gate_colsums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* residual,
+                                             const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y, float* sums_part, void* ws,
+                                             size_t ws_bytes, void* stream);
 /* Stride-1 data gradient whose output da feeds the backward of a = ReLU(BN(z)): besides y = dgrad(dz) it accumulates that
  * BatchNorm's backward sums in the epilogue -- sums_part, CHANNEL-MAJOR [cout][mvf_conv2d_stats_rows(d)][2] = per-128-row column sums of gm and
  * gm * xhat with gm = y * [bn_scale*z + bn_shift > 0], xhat = (z - bn_mean) * bn_invstd (z: the forward conv output the BN
@@ -259,13 +258,10 @@ int mvf_bn_bwd_dzfree_wgrad(float* dw, const void* w_packed, const float* gram, 
                             const float* invstd, const float* dgamma, const float* dbeta, long m, int c, int k, int dtype, void* stream);
 /* _sums : dgamma / dbeta WITHOUT the pass over (gm, z3) either: sum_m gm z3 = sum_k W[c][k] Q[c][k] (Q = the weight-gradient GEMM of _wgrad, taken FIRST) and
  *         sum_m gm from the column sums the kernels that stored gm took in their epilogues -- part_lo [c_split][rows_lo][2] (the MVF stencil's slice,
- *         mvf_nhwc_stencil_gate_sums with bn_z = NULL) and part_hi [c][rows_hi][2] indexed by the absolute channel (mvf_conv2d_nhwc_fwd_resmask_gate_sums
- *         with bn_z = NULL); element [.][.][0] is read.  dgamma[c] = invstd (W[c].Q[c] - mean sum gm), dbeta[c] = sum gm.
- *         q_slabs != NULL: Q arrives as the nslabs partial results of mvf_conv2d_nhwc_wgrad_slabs ([nslabs][c][k]); they are summed here in order and q [c][k]
- *         is WRITTEN (the _wgrad correction reads it) -- the weight-gradient GEMM's own reduce launch is not needed. */
-int mvf_bn_bwd_dzfree_sums(float* q, const float* q_slabs, int nslabs, const void* w_packed, int c, int k, const float* mean, const float* invstd,
-                           const float* part_lo, int rows_lo, int c_split, const float* part_hi, int rows_hi, float* dgamma, float* dbeta, int dtype,
-                           void* stream);
+ *         mvf_nhwc_stencil_gate_colsums) and part_hi [c][rows_hi][2] indexed by the absolute channel (mvf_conv2d_nhwc_fwd_resmask_gate_colsums); element
+ *         [.][.][0] is read.  dgamma[c] = invstd (W[c].Q[c] - mean sum gm), dbeta[c] = sum gm. */
+int mvf_bn_bwd_dzfree_sums(const float* q, const void* w_packed, int c, int k, const float* mean, const float* invstd, const float* part_lo, int rows_lo,
+                           int c_split, const float* part_hi, int rows_hi, float* dgamma, float* dbeta, int dtype, void* stream);
 size_t mvf_bn_workspace_bytes(long m, int c);
 /* batch mean / biased var of z over m -> save_mean, save_invstd, scale = gamma*invstd, shift = beta - mean*scale;
  * running_mean/var updated in place (unbiased var).  Shifted single-pass sums (shift = old running_mean). */
@@ -410,8 +406,6 @@ int mvf_conv2d_nhwc_wgrad(const mvf_conv_desc_t* d, const void* dz, const void* 
  * chip); results differ from mvf_conv2d_nhwc_wgrad only by the fp32 summation order of the pixel split. */
 int mvf_conv2d_nhwc_wgrad_wgs(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real,
                               int cin_real, int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, int wgs, void* stream);
-/* [r5] ... and without the slab reduce (pointwise convs): ws holds *nslabs partial results [nslabs][cout][cin] fp32 for a consumer that sums them itself. */
-int mvf_conv2d_nhwc_wgrad_slabs(const mvf_conv_desc_t* d, const void* dz, const void* x, void* ws, size_t ws_bytes, int wgs, int* nslabs, void* stream);
 /* Every weight pack of a training step in one launch.  jobs_dev = DEVICE array of njobs records sorted by first_block;
  * job k owns workgroups [first_block, first_block + ceil(elements / 2048)), total_blocks = their sum.  kind 0 = the forward
  * pack of mvf_pack_conv_weight (no scale), kind 1 = the data-gradient pack of mvf_pack_conv_weight_dgrad.  kind 2 / 3 = the
@@ -440,13 +434,11 @@ int mvf_nhwc_stencil_gate(const mvf_desc_t* d, const void* x, int x_c, void* out
                           const float* w_h, const float* w_w, const float* scale, const float* shift, int flip,
                           const void* addend, int addend_c, const unsigned char* addend_sign_bits,
                           const unsigned char* out_gate_bits, void* stream);
-/* [r5] mvf_nhwc_stencil_gate + the BatchNorm-backward sums of the gated slice: sums_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] =
- * per-workgroup sums of gm and gm * (bn_z - bn_mean) * bn_invstd (bn_z pitch out_c) -> mvf_bn_bwd_finalize: the slice's share of
- * mvf_conv2d_nhwc_fwd_resmask_gate_sums (bn_z = NULL: sums of gm and gm^2, as there). */
-int mvf_nhwc_stencil_gate_sums(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
-                               const float* w_w, int flip, const void* addend, int addend_c, const unsigned char* addend_sign_bits,
-                               const unsigned char* out_gate_bits, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sums_part,
-                               void* stream);
+/* [r5] mvf_nhwc_stencil_gate + the column sums of the gated slice: sums_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] = per-workgroup
+ * sums of gm and gm^2 -- the slice's share of mvf_conv2d_nhwc_fwd_resmask_gate_colsums. */
+int mvf_nhwc_stencil_gate_colsums(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
+                                  const float* w_w, int flip, const void* addend, int addend_c, const unsigned char* addend_sign_bits,
+                                  const unsigned char* out_gate_bits, float* sums_part, void* stream);
 /* [r5] the plain stencil (no activation) that also accumulates the batch statistics of MVF's BatchNorm3d (MVF.py:131-134, training mode) over the
  * values it stores: stats_part CHANNEL-MAJOR [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] = per-workgroup sums of (y - K), (y - K)^2, K =
  * stats_shift (the old running mean; NULL = 0) -> mvf_bn_train_finalize.  Replaces the statistics pass over y. */
@@ -479,6 +471,24 @@ typedef struct mvf_sgd_segment {
 int mvf_sgd_step_segments(float* params, const float* grads, float* momentum_buf, long n, float grad_scale, float max_norm, float lr,
                           float momentum, float weight_decay, int first_step, int nesterov, const mvf_sgd_segment_t* segments, int nseg,
                           float* norm_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * [r6] Launch-table replay.  One training step (the reference's batch_processor + DistOptimizerHook.after_train_iter, codes/core/train.py:45-60,
+ * codes/core/dist_utils.py:61-67) is a fixed sequence of this library's entry points on two HIP streams; the host code records it once and replays it from C
+ * instead of re-issuing ~650 calls from Python (mvfnet_amd/launch_plan.py).  An op is
+ *   MVF_PLAN_CALL    fn(words[word0 .. word0 + n_int), floats[float0 .. float0 + n_flt)): fn = the address of ANY int-returning entry point of this header,
+ *                    its integer-class arguments (pointers, int, long, size_t, the stream) in prototype order as 64-bit words, its float arguments in order
+ *   MVF_PLAN_RECORD  hipEventRecord(event = words[word0], stream = words[word0 + 1])
+ *   MVF_PLAN_WAIT    hipStreamWaitEvent(stream = words[word0], event = words[word0 + 1])
+ * Events are the caller's.  The run stops at the first op that fails: its index goes to *failed_op (else -1), its status is returned and mvf_last_error()
+ * describes it.  Arguments that change between runs are patched in `words` by the caller.  x86-64 System V hosts only. */
+enum { MVF_PLAN_CALL = 0, MVF_PLAN_RECORD = 1, MVF_PLAN_WAIT = 2 };
+typedef struct mvf_plan_op {
+    int kind, n_int, n_flt, reserved;
+    void* fn;
+    long long word0, float0;
+} mvf_plan_op_t;
+int mvf_plan_run(const mvf_plan_op_t* ops, int n_ops, const unsigned long long* words, const float* floats, int* failed_op);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,11 @@ class PackJob(C.Structure):
                 ("kw_pad", C.c_int32), ("cin_pad", C.c_int32), ("kind", C.c_int32), ("first_block", C.c_int32)]
 
 
+class PlanOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_int", C.c_int32), ("n_flt", C.c_int32), ("reserved", C.c_int32), ("fn", C.c_void_p), ("word0", C.c_longlong),
+                ("float0", C.c_longlong)]
+
+
 class SgdSegment(C.Structure):
     _fields_ = [("first", C.c_int64), ("lr_mult", C.c_float), ("decay_mult", C.c_float)]
 
@@ -87,10 +92,10 @@ def _load():
     i64_ = C.c_long
     lib.mvf_conv2d_nhwc_fwd_resmask_gate.restype = i32
     lib.mvf_conv2d_nhwc_fwd_resmask_gate.argtypes = [cp, vp, vp, vp, fp, vp, vp, vp, vp, vp, sz, vp]
-    lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums.restype = i32
-    lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums.argtypes = [cp, vp, vp, vp, vp, vp, vp, vp, vp, fp, fp, fp, vp, sz, vp]
-    lib.mvf_nhwc_stencil_gate_sums.restype = i32
-    lib.mvf_nhwc_stencil_gate_sums.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, i32, vp, i32, vp, vp, vp, fp, fp, fp, vp]
+    lib.mvf_conv2d_nhwc_fwd_resmask_gate_colsums.restype = i32
+    lib.mvf_conv2d_nhwc_fwd_resmask_gate_colsums.argtypes = [cp, vp, vp, vp, vp, vp, vp, vp, fp, vp, sz, vp]
+    lib.mvf_nhwc_stencil_gate_colsums.restype = i32
+    lib.mvf_nhwc_stencil_gate_colsums.argtypes = [dp, vp, i32, vp, i32, fp, fp, fp, i32, vp, i32, vp, vp, fp, vp]
     lib.mvf_conv2d_nhwc_dgrad_bnsums_split.restype = i32
     lib.mvf_conv2d_nhwc_dgrad_bnsums_split.argtypes = [cp, vp, vp, vp, fp, vp, vp, fp, fp, fp, fp, fp, vp, sz, vp]
     lib.mvf_bn_bwd_dzfree_prep.restype = i32
@@ -98,7 +103,7 @@ def _load():
     lib.mvf_bn_bwd_dzfree_wgrad.restype = i32
     lib.mvf_bn_bwd_dzfree_wgrad.argtypes = [fp, vp, fp, fp, fp, fp, fp, fp, fp, i64_, i32, i32, i32, vp]
     lib.mvf_bn_bwd_dzfree_sums.restype = i32
-    lib.mvf_bn_bwd_dzfree_sums.argtypes = [fp, fp, i32, vp, i32, i32, fp, fp, fp, i32, i32, fp, i32, fp, fp, i32, vp]
+    lib.mvf_bn_bwd_dzfree_sums.argtypes = [fp, vp, i32, i32, fp, fp, fp, i32, i32, fp, i32, fp, fp, i32, vp]
     lib.mvf_nhwc_stencil_stats_rows.restype = i32
     lib.mvf_nhwc_stencil_stats_rows.argtypes = [dp, i32, i32]
     lib.mvf_nhwc_stencil_tile_plan.restype = i32
@@ -192,8 +197,6 @@ def _load():
     lib.mvf_conv2d_nhwc_wgrad.argtypes = [cp, vp, vp, vp, i32, i32, i32, i32, fp, vp, sz, vp]
     lib.mvf_conv2d_nhwc_wgrad_wgs.restype = i32
     lib.mvf_conv2d_nhwc_wgrad_wgs.argtypes = [cp, vp, vp, vp, i32, i32, i32, i32, fp, vp, sz, i32, vp]
-    lib.mvf_conv2d_nhwc_wgrad_slabs.restype = i32
-    lib.mvf_conv2d_nhwc_wgrad_slabs.argtypes = [cp, vp, vp, vp, sz, i32, C.POINTER(C.c_int), vp]
     lib.mvf_pack_conv_weight_dgrad.restype = i32
     lib.mvf_pack_conv_weight_dgrad.argtypes = [fp, i32, i32, i32, i32, vp, i32, vp]
     lib.mvf_nhwc_stencil.restype = i32
@@ -208,6 +211,8 @@ def _load():
     lib.mvf_sgd_nesterov_step.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, f32, i32, fp, vp, sz, vp]
     lib.mvf_sgd_step_segments.restype = i32
     lib.mvf_sgd_step_segments.argtypes = [fp, fp, fp, i64, f32, f32, f32, f32, f32, i32, i32, vp, i32, fp, vp, sz, vp]
+    lib.mvf_plan_run.restype = i32
+    lib.mvf_plan_run.argtypes = [C.POINTER(PlanOp), i32, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     # Callers pass device pointers as plain Python ints (train_engine._p): without declared argtypes ctypes would truncate them to c_int silently.  Every
     # function the header declares must therefore have its signature declared above.
     missing = [n for n in declared_symbols() if hasattr(lib, n) and getattr(lib, n).argtypes is None]

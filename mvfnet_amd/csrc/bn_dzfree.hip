@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void dzfree_wgrad_fix_kernel(float* dw, const 
 // [r5] bn's backward sums WITHOUT a pass over (gm, z): z = a_in W^T, so sum_m gm[m][c] z[m][c] = sum_k W[c][k] Q[c][k] with Q = gm^T a_in -- the weight-gradient
 // GEMM the dz-free path computes anyway (now BEFORE the data gradient, on the launch stream) -- and sum_m gm[m][c] comes from the column sums the kernels that
 // STORED gm took in their epilogues (two runs of per-workgroup partials: channels < c_split from the MVF stencil, the rest from the conv).  One wave per channel.
-__global__ __launch_bounds__(256) void dzfree_sums_kernel(float* q, const float* slabs, int nslabs, const uint16_t* w, int C, int K, const float* mean,
+__global__ __launch_bounds__(256) void dzfree_sums_kernel(const float* q, const uint16_t* w, int C, int K, const float* mean,
                                                           const float* invstd, const float* part_lo, int rows_lo, int c_split, const float* part_hi, int rows_hi,
                                                           float* dgamma, float* dbeta) {
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -209,21 +209,10 @@ __global__ __launch_bounds__(256) void dzfree_sums_kernel(float* q, const float*
     float s1 = 0.f, dot = 0.f;
     for (int r = lane; r < rows; r += 64) s1 += p[r].x;
     const uint16_t* pw = w + (long)c * K;
-    float* pq = q + (long)c * K;
-    const long slab = (long)C * K;
+    const float* pq = q + (long)c * K;
     for (int k = lane * 4; k < K; k += 256) {
         const uint2 wv = *reinterpret_cast<const uint2*>(pw + k);
-        float4 qv;
-        if (slabs) {           // Q = the weight-gradient GEMM's partial results, summed here in pixel-range order (and stored: the correction kernel reads it)
-            qv = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s_ = 0; s_ < nslabs; ++s_) {
-                const float4 t = *reinterpret_cast<const float4*>(slabs + s_ * slab + (long)c * K + k);
-                qv.x += t.x; qv.y += t.y; qv.z += t.z; qv.w += t.w;
-            }
-            *reinterpret_cast<float4*>(pq + k) = qv;
-        } else {
-            qv = *reinterpret_cast<const float4*>(pq + k);
-        }
+        const float4 qv = *reinterpret_cast<const float4*>(pq + k);
         dot += bf16lo(wv.x) * qv.x + bf16hi(wv.x) * qv.y + bf16lo(wv.y) * qv.z + bf16hi(wv.y) * qv.w;
     }
 #pragma unroll
@@ -339,15 +328,14 @@ int mvf_bn_train_stats_gram(const float* gram, const float* a_mean, const void* 
     return MVF_OK;
 }
 
-int mvf_bn_bwd_dzfree_sums(float* q, const float* q_slabs, int nslabs, const void* w_packed, int c, int k, const float* mean, const float* invstd,
+int mvf_bn_bwd_dzfree_sums(const float* q, const void* w_packed, int c, int k, const float* mean, const float* invstd,
                            const float* part_lo, int rows_lo, int c_split, const float* part_hi, int rows_hi, float* dgamma, float* dbeta, int dtype, void* stream) {
-    MVF_REQUIRE(!q_slabs || (nslabs > 0 && (uintptr_t)q_slabs % 16 == 0), MVF_EINVAL, "bn_bwd_dzfree_sums: q_slabs needs nslabs > 0 and 16-byte alignment");
     MVF_REQUIRE(q && w_packed && mean && invstd && dgamma && dbeta, MVF_EINVAL, "bn_bwd_dzfree_sums: NULL argument");
     MVF_REQUIRE(dtype == MVF_BF16, MVF_EUNSUPPORTED, "bn_bwd_dzfree_sums: bf16 storage only");
     MVF_REQUIRE(c > 0 && k > 0 && k % 4 == 0 && c_split >= 0 && c_split <= c, MVF_ESHAPE, "bn_bwd_dzfree_sums: c=%d, k=%d (a multiple of 4), 0 <= c_split=%d <= c", c, k, c_split);
     MVF_REQUIRE((c_split == 0 || (part_lo && rows_lo > 0)) && (c_split == c || (part_hi && rows_hi > 0)), MVF_EINVAL, "bn_bwd_dzfree_sums: a channel range without partial sums");
     MVF_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)w_packed % 8 == 0), MVF_EINVAL, "bn_bwd_dzfree_sums: q must be 16-byte, w_packed 8-byte aligned");
-    hipLaunchKernelGGL(dzfree_sums_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, q_slabs, nslabs, (const uint16_t*)w_packed, c, k, mean, invstd, part_lo, rows_lo,
+    hipLaunchKernelGGL(dzfree_sums_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, (const uint16_t*)w_packed, c, k, mean, invstd, part_lo, rows_lo,
                        c_split, part_hi, rows_hi, dgamma, dbeta);
     MVF_LAUNCH_CHECK();
     return MVF_OK;

@@ -305,7 +305,7 @@ int bnbwd_wgrad_plan(long m, int c, int k, int nbn, int mask_mode, int* rows_per
     if (!bnbwd_wgrad_tile(c, k, nbn, mask_mode, &ct, &kt)) return 0;
     *ctiles = c / ct;
     *ktiles = k / kt;
-    static const int wgs_env = getenv("MVF_BNWG_WGS") ? atoi(getenv("MVF_BNWG_WGS")) : 256;                 // one persistent workgroup per CU
+    static const int wgs_env = mvf_policy_int("bnwg_wgs", 256);                 // one persistent workgroup per CU
     const int want = wgs_env / (*ctiles * *ktiles) > 0 ? wgs_env / (*ctiles * *ktiles) : 1;
     long rows = (m + want - 1) / want;
     rows = (rows + CH - 1) / CH * CH;

@@ -1,6 +1,9 @@
 // Shared host/device helpers for libmvfnet_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -81,6 +84,35 @@ __device__ __forceinline__ float hswish_grad_f(float u) {
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// [r6] Policy switches: ONE environment variable, MVF_POLICY="name=value,name=value" (integers), is the only thing the library reads from the environment.
+// The defaults at the call sites are the measured policy (DESIGN.md section 4.5 lists every name with the measurement behind its default); an override is for
+// A/B runs and for the tests that drive both sides of a switch.  Call sites that want the value once wrap the call in a function-local static.
+static inline bool mvf_policy_lookup(const char* name, long* out) {
+    const char* p = getenv("MVF_POLICY");
+    if (!p) return false;
+    const size_t n = strlen(name);
+    while (*p) {
+        while (*p == ',' || *p == ';' || *p == ' ') ++p;
+        const char* e = p;
+        while (*e && *e != ',' && *e != ';') ++e;
+        const char* eq = (const char*)memchr(p, '=', (size_t)(e - p));
+        if (eq && (size_t)(eq - p) == n && strncasecmp(p, name, n) == 0) {
+            *out = strtol(eq + 1, nullptr, 10);
+            return true;
+        }
+        p = e;
+    }
+    return false;
+}
+static inline int mvf_policy_int(const char* name, int dflt) {
+    long v;
+    return mvf_policy_lookup(name, &v) ? (int)v : dflt;
+}
+static inline bool mvf_policy_has(const char* name) {
+    long v;
+    return mvf_policy_lookup(name, &v);
+}
 
 // the direct 7x7 stride-2 stem conv (stem_direct.hip), reached from conv_nhwc.hip's conv_fwd_impl when the launch is the stem's
 struct StemDirectArgs {
@@ -163,7 +195,7 @@ struct PwBwdFusedArgs {
     float* sums_part;           // [64][sums_rows][2] out: partial rows of bn_in's backward sums (2 x nsplit rows)
     float* part;                // [nsplit][256][64] fp32 out: weight-gradient slabs
     int aps, g_pitch, M, sums_rows, rows_per_split, nsplit;
-    int ablate;                 // -DMVF_PWBF_ABLATE builds only: phases to skip (timing experiments)
+    int ablate;                 // -Dpolicy pwbf_ablate builds only: phases to skip (timing experiments)
 };
 // BatchNorm-backward sums of both branches of a z3-free downsample bottleneck in one pass over g (pw_sums_pair.hip); splits as pw_bwd_fused_plan
 struct PwSumsPairArgs {

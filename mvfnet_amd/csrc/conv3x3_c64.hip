@@ -21,7 +21,7 @@
 //     sums all rows).
 // Arithmetic = the implicit-GEMM kernel's: the same bf16 products accumulated in fp32 in the same k order (tap-major), rounded once.
 // Measured (C3 shape, 256 frames of 56 x 56, in the training step): forward + statistics 109 -> 69 us (852 TF/s), data gradient + BatchNorm
-// sums 120 -> 82 us; s_memtime trace of one workgroup (-DMVF_CONV_ABLATE, MVF_CONV3X3_TRACE): a band takes ~6900 ticks for 4608 of matrix
+// sums 120 -> 82 us; s_memtime trace of one workgroup (-DMVF_CONV_ABLATE, policy conv3x3_trace): a band takes ~6900 ticks for 4608 of matrix
 // work per SIMD; what is left is the 28 DMA instructions per loader wave and band (2500-4000 ticks of issue) and epilogues that the second
 // wave of a SIMD only partly covers.  Measured without effect: two accumulation chains, staggering waves 4-7, wave priorities, z fetched a
 // block ahead (profiles/r03_conv3x3_c64_experiments.txt).
@@ -51,7 +51,7 @@ struct KArgs {
     int bands_per_frame, bands, bands_per_wg;
     unsigned fd_bpf_mul, fd_bpf_shr;
     long wK;
-    unsigned long long* trace;         // -DMVF_CONV_ABLATE + MVF_CONV3X3_TRACE=1: s_memtime stamps of workgroup 0, [wave][band][8]
+    unsigned long long* trace;         // -DMVF_CONV_ABLATE + policy conv3x3_trace=1: s_memtime stamps of workgroup 0, [wave][band][8]
     int abl;                           // -DMVF_CONV_ABLATE builds: bit 0 no window staging after the first band, bit 1 no pixel blocks, bit 2 no output stores
 };
 
@@ -325,8 +325,7 @@ namespace mvf_internal {
 
 // MVF_OK when launched, -1 when the shape is not this kernel's (the caller falls back to the implicit-GEMM path)
 int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
-    const char* sw = getenv("MVF_CONV3X3_DIRECT");        // A/B switch, read per call: 0 = the implicit-GEMM kernel
-    if (sw && atoi(sw) == 0) return -1;
+    if (mvf_policy_int("conv3x3_direct", 1) == 0) return -1;      // A/B switch, read per call: 0 = the implicit-GEMM kernel
     // instantiated (width, rows per band): layer1 at 224 / 256 (the 30-clip video test, BASELINE configs[4]) / 64 / 32-pixel inputs (the last
     // two are what the small test networks reach; a 28 x 28 map has no band of whole 32-pixel blocks that divides its height and stays on
     // the implicit-GEMM kernel)
@@ -343,9 +342,9 @@ int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
     a.bands = (int)bands;
     fd_make_local((unsigned)a.bands_per_frame, a.fd_bpf_mul, a.fd_bpf_shr);
 #ifdef MVF_CONV_ABLATE
-    a.abl = getenv("MVF_CONV3X3_ABL") ? atoi(getenv("MVF_CONV3X3_ABL")) : 0;
+    a.abl = mvf_policy_int("conv3x3_abl", 0);
     static unsigned long long* trace_buf = nullptr;
-    const bool tracing = getenv("MVF_CONV3X3_TRACE") && atoi(getenv("MVF_CONV3X3_TRACE")) == s.epi;
+    const bool tracing = mvf_policy_int("conv3x3_trace", -1) == s.epi;
     if (tracing && !trace_buf) MVF_HIP_OK(hipMalloc(&trace_buf, 8 * 14 * 8 * 8));
     if (tracing) { MVF_HIP_OK(hipMemsetAsync(trace_buf, 0, 8 * 14 * 8 * 8, st)); a.trace = trace_buf; }
 #endif
@@ -356,8 +355,7 @@ int conv3x3_c64_launch(const Conv3x3C64Args& s, hipStream_t st) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    const char* bw = getenv("MVF_CONV3X3_BPW");
-    a.bands_per_wg = bw ? atoi(bw) : (int)((bands + cus - 1) / cus);            // one workgroup per CU, contiguous bands
+    a.bands_per_wg = mvf_policy_int("conv3x3_bpw", (int)((bands + cus - 1) / cus));            // one workgroup per CU, contiguous bands
     if (a.bands_per_wg < 1) a.bands_per_wg = 1;
     const int grid = (int)((bands + a.bands_per_wg - 1) / a.bands_per_wg);
     if ((s.epi == 1 || s.epi == 6) && grid > s.stats_rows) return -1;           // one partial row per workgroup

@@ -55,13 +55,9 @@ struct ConvArgs {
     // [r5] optional [M][Cout/4] bytes in the same layout: the OUTPUT (accumulator + residual) of channels >= res_c0 is gated by them before the
     // store -- the data gradient then hands the block below gm = g * [out > 0] instead of g + sign bits (mvf_conv2d_nhwc_fwd_resmask_gate)
     const unsigned char* out_gate;
-    // [r5] EPI 11 = EPI 3 (data gradient + gated residual) + the output gate + the BatchNorm-backward sums of the bn3 the gated output belongs to: per-128-row
-    // column sums of gm (the stored, gated output) and gm * (gs_z - gs_mean) * gs_invstd into stats_part; gs_z = that BatchNorm's stored input (the output's shape)
-    const char* gs_z;
-    const float *gs_mean, *gs_invstd;
     int x_c0;      // [r5] split operand: x holds channels [split_c, Cin) of the contraction at column (channel - x_c0) of its rows (0: at their own offset)
-    int mask_lds;  // stage the gate bytes in LDS (experiment switch MVF_MASK_LDS=0)
-    int prio;      // experiment switch MVF_CONV_PRIO=1: raise the wave priority around the MFMA phase of the LDS-DMA loops; in
+    int mask_lds;  // stage the gate bytes in LDS (experiment switch policy mask_lds=0)
+    int prio;      // experiment switch policy conv_prio=1: raise the wave priority around the MFMA phase of the LDS-DMA loops; in
                    // -DMVF_CONV_ABLATE builds bits 1-5 additionally switch parts of the kernel OFF (timing ablation, wrong results)
     int dil;       // input dilation (generic fallback; the strided data-gradient is normally decomposed into parity classes)
     int pad_w;     // horizontal padding (pad = vertical)
@@ -1036,8 +1032,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
     // back row-wise, 16 B per lane -> whole 512-B (f32) / 256-B (bf16) row segments per 32 lanes for the stores and the
     // residual loads.
     const bool e_bias = EPI == 0 ? a.bias != nullptr : (EPI == 4 || EPI == 5 || (EPI == 6 && a.bias != nullptr));   // ([r5] EPI 6 + bias: mvf_conv2d_nhwc_dgrad_bnsums_split)
-    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8 || EPI == 9 || EPI == 10 || EPI == 11 || EPI == 12);
-    constexpr bool e_gs = EPI == 11;                     // [r5] gated output + the BatchNorm-backward sums of the block below
+    const bool e_res = EPI == 0 ? a.res != nullptr : (EPI == 3 || EPI == 5 || EPI == 8 || EPI == 9 || EPI == 10 || EPI == 12);
     constexpr bool e_bw = EPI == 9 || EPI == 10;         // BatchNorm backward on the recomputed conv output (g and its sign-bit gate arrive as the residual operand)
     const bool e_relu = EPI == 0 ? a.relu != 0 : (EPI == 4 || EPI == 5);
     constexpr bool e_apply = EPI == 8;                   // BatchNorm apply + residual + ReLU + sign bits on the rounded accumulators
@@ -1068,7 +1063,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         if (a.ap_rscale) { ap_rs = *reinterpret_cast<const float4*>(a.ap_rscale + col); ap_rb = *reinterpret_cast<const float4*>(a.ap_rshift + col); }
     }
     float4 b_mu = st1, b_rs = st1, b_sc = st1, b_sh = st1;
-    if (e_gs && col < a.Cout) { b_mu = *reinterpret_cast<const float4*>(a.gs_mean + col); b_rs = *reinterpret_cast<const float4*>(a.gs_invstd + col); }
     if (e_bnb && col < a.Cout) {
         b_mu = *reinterpret_cast<const float4*>(a.bn_mean + col); b_rs = *reinterpret_cast<const float4*>(a.bn_invstd + col);
         b_sc = *reinterpret_cast<const float4*>(a.bn_scale + col); b_sh = *reinterpret_cast<const float4*>(a.bn_shift + col);
@@ -1108,11 +1102,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         (void*)(a.out_gate ? a.out_gate + (long)m0 * (a.Cout / 4) : (const unsigned char*)a.y), 0,
         (unsigned)min((long)(a.M - m0) * (a.Cout / 4), 0x7ffffff0L), 0x00020000);
     const bool e_gate = e_res && !e_apply && !e_bw && a.out_gate != nullptr;
-    __amdgpu_buffer_rsrc_t rs_gz = rs_gate;
-    if constexpr (e_gs) {
-        const long base = (long)m0 * a.Cout * ESZ, left = (long)a.M * a.Cout * ESZ - base;
-        rs_gz = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gs_z + base), 0, (unsigned)(left < 0x7ffffff0L ? left : 0x7ffffff0L), 0x00020000);
-    }
     (void)y; (void)res;
     // The tile's gate bytes (BM rows x BN/4) are staged in LDS behind the C tile with ONE 16-byte load per thread (instead of a
     // byte load per thread per row, which made the gated data gradient 35 % slower than the ungated one); visible after the
@@ -1297,8 +1286,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
         typedef typename std::conditional<sizeof(ET) == 2, u32x2, u32x4>::type raw_t;
         unsigned offs[NPS];
         raw_t rraw[NPS];
-        raw_t gzraw[e_gs ? NPS : 1];
-        (void)gzraw;
         {
             const int mrow0 = m0 + hf * HR + r0;
             const bool cok2 = col < a.Cout;              // Cout % 4 == 0 (checked on the host)
@@ -1318,10 +1305,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     const unsigned roff = (e_bnb || col >= a.res_c0) ? offs[ps] : kOOB;       // skipped columns read zeros
                     if constexpr (sizeof(ET) == 2) rraw[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, roff, 0, 0);
                     else rraw[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0);
-                }
-                if constexpr (e_gs) {
-                    if constexpr (sizeof(ET) == 2) gzraw[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_gz, offs[ps], 0, 0);
-                    else gzraw[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_gz, offs[ps], 0, 0);
                 }
             }
         }
@@ -1410,13 +1393,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                     pk.x = __float_as_uint(v.x); pk.y = __float_as_uint(v.y); pk.z = __float_as_uint(v.z); pk.w = __float_as_uint(v.w);
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, off, 0, 0);
                 }
-                if constexpr (e_gs) {                // v = the stored (rounded, gated) gradient gm; z = the block below's stored z3
-                    const float4 zv = unpack(gzraw[ps]);
-                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    st1.x += v.x; st1.y += v.y; st1.z += v.z; st1.w += v.w;
-                    st2.x += v.x * ((zv.x - b_mu.x) * b_rs.x); st2.y += v.y * ((zv.y - b_mu.y) * b_rs.y);
-                    st2.z += v.z * ((zv.z - b_mu.z) * b_rs.z); st2.w += v.w * ((zv.w - b_mu.w) * b_rs.w);
-                }
                 if constexpr (e_bnb) {               // v = the stored (rounded) gradient; z was fetched in phase A
                     const float4 zv = unpack(rraw[ps]);
                     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1434,7 +1410,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, char* smem, const i
                 }
             }
         }
-        if ((e_stats || e_bnb || EPI == 10 || e_gs) && (hf + 1) % HPP == 0) {   // column sums over the RPP row-threads, fixed order, one writer per column
+        if ((e_stats || e_bnb || EPI == 10) && (hf + 1) % HPP == 0) {   // column sums over the RPP row-threads, fixed order, one writer per column
             __syncthreads();
             float4* red = reinterpret_cast<float4*>(smem);
             red[(r0 * 2 + 0) * TPR + cq] = st1;
@@ -1531,7 +1507,7 @@ __global__ __launch_bounds__(512) void conv_igemm_glds8_kernel(ConvArgs a) {
 
 // 256 x 256 outputs per workgroup of 8 waves (4 x 2, 64 x 128 each), two 64 KB LDS-DMA buffers, one workgroup per CU: per SIMD 16 DMA
 // instructions feed 2048 cycles of MFMA work per chunk -- twice the ratio of the 128 x 128 and 256 x 128 tiles, which plateau on the DMA
-// issue path.  Only for launches whose tile count suits 256 single-workgroup slots (MVF_CONV_BIG2).
+// issue path.  Only for launches whose tile count suits 256 single-workgroup slots (policy conv_big2).
 template <typename ET, int EPI, bool ILV>
 __global__ __launch_bounds__(512) void conv_igemm_big2_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1545,9 +1521,9 @@ int launch_big2(hipStream_t st, const ConvArgs& a0) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.Cout + 255) / 256;
     constexpr int lds = kGldsLds<256, 256, 2>();
-    // experiment switch MVF_CONV_ILV=1: the next chunk's DMA pieces issued one behind each MFMA of the first k-step instead of in a block
+    // experiment switch policy conv_ilv=1: the next chunk's DMA pieces issued one behind each MFMA of the first k-step instead of in a block
     // ahead of them.  Measured neutral on the K = 2304 launches and 6-8 % SLOWER on the K = 1024 ones (0.234 -> 0.25 ms): off.
-    static const int ilv = getenv("MVF_CONV_ILV") ? atoi(getenv("MVF_CONV_ILV")) : 0;
+    static const int ilv = mvf_policy_int("conv_ilv", 0);
     auto k0 = conv_igemm_big2_kernel<ET, EPI, false>;
     auto k1 = conv_igemm_big2_kernel<ET, EPI, true>;
     static bool attr = false;
@@ -1627,8 +1603,8 @@ int launch_glds(int nb, int tiles, hipStream_t st, const ConvArgs& a) {
         }
     }
     // pointwise launches (1x1 taps, no padding, no split operand) take the loader specialisation PW: no tap masks, no second-operand
-    // offsets and, at stride 1, no division in the per-tile set-up (MVF_CONV_EPI bit 1, as for the register-staged kernel)
-    static const int epi_spec = getenv("MVF_CONV_EPI") ? atoi(getenv("MVF_CONV_EPI")) : 3;
+    // offsets and, at stride 1, no division in the per-tile set-up (policy conv_epi bit 1, as for the register-staged kernel)
+    static const int epi_spec = mvf_policy_int("conv_epi", 3);
     const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
     if (nb == 1) {
         constexpr int lds = kGldsLds<BM, BN, 1>();
@@ -1662,10 +1638,10 @@ __global__ __launch_bounds__(512) void conv_igemm_x3w_kernel(ConvArgs a) {
     SkArgs sk = {};
     conv_tile<float, 4, 2, 2, 2, true, false, false, EPI, PW, 0, false, false, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
-int g_x3_wide = 0;               // MVF_X3_WIDE=n: the 8-wave 256 x 128 X3 tile for launches with >= n tiles of that size (0 = off)
+int g_x3_wide = 0;               // policy x3_wide=n: the 8-wave 256 x 128 X3 tile for launches with >= n tiles of that size (0 = off)
 
-int g_f32_x3 = 1;                // fp32 storage: products on the bf16 matrix cores as 3-term bf16 splits (MVF_F32_X3=0: the fp32 MFMA)
-int g_x3_db_min = 1 << 30;       // X3: double-buffered planes (one workgroup per CU, one barrier per chunk) from this many K chunks on (MVF_X3_DB)
+int g_f32_x3 = 1;                // fp32 storage: products on the bf16 matrix cores as 3-term bf16 splits (policy f32_x3=0: the fp32 MFMA)
+int g_x3_db_min = 1 << 30;       // X3: double-buffered planes (one workgroup per CU, one barrier per chunk) from this many K chunks on (policy x3_db)
 
 // X3 with two LDS buffers: chunk k + 1 is split and written to the other buffer behind the MFMAs of chunk k, one barrier per chunk
 template <int WM, int WN, int TM, int TN, int EPI = 0, bool PW = false>
@@ -1675,7 +1651,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_x3db_kernel(ConvArgs a) {
     conv_tile<float, WM, WN, TM, TN, false, false, false, EPI, PW, 0, false, false, false, true>(a, smem, xcd_swizzle(blockIdx.x, gridDim.x), 0, a.nchunks, SEG_FULL, sk, 0, 0);
 }
 
-// MVF_F32_X3: 0 never, 1 always; diagnostics: 2 only launches with a forward epilogue (statistics / bias / BatchNorm apply), 3 only the others
+// policy f32_x3: 0 never, 1 always; diagnostics: 2 only launches with a forward epilogue (statistics / bias / BatchNorm apply), 3 only the others
 // (data gradients, plain forwards), 4 only 3x3 taps, 5 only pointwise, 6 only the stem's 7 x 1 view, 7 everything but the stem
 inline bool x3_on(const ConvArgs& a) {
     const bool fwd_like = a.stats_part || a.bias || a.ap_scale || a.bw_mode;
@@ -1812,48 +1788,35 @@ struct SkHost {
     size_t ws_bytes;
 };
 
-// Launches with at most this many K chunks use the single-LDS-buffer variant (MVF_CONV_LOWK=n; 0 disables).  Measured on the
+// Launches with at most this many K chunks use the single-LDS-buffer variant (policy conv_lowk=n; 0 disables).  Measured on the
 // R50 train step: the 36 KB variant (3-4 workgroups per CU) beats the double-buffered 72 KB one (2 per CU) at EVERY K, bf16 and
 // fp32 -- occupancy hides more latency than the second buffer does (bf16 27.97 -> 26.96 ms, fp32 83.0 -> 79.6 ms per step).
 int g_lowk_max_chunks = 1 << 30;
-int g_pf2_mode = 1;              // two-chunk register prefetch: 0 off, 1 bf16 only, 2 both dtypes (MVF_CONV_PF2)
-int g_glds1_f32_infer = 1;       // fp32: only the inference epilogues (bias + ReLU [+ residual]) take it by default (MVF_CONV_GLDS1_F32=0/1)
+int g_pf2_mode = 1;              // two-chunk register prefetch: 0 off, 1 bf16 only, 2 both dtypes (policy conv_pf2)
+int g_glds1_f32_infer = 1;       // fp32: only the inference epilogues (bias + ReLU [+ residual]) take it by default (policy conv_glds1_f32=0/1)
 int g_glds1_max = -1;            // single-buffer LDS-DMA kernel (4 workgroups per CU) up to this many K chunks: -1 = default policy
-                                 // (bf16: 8), 0 = off (MVF_CONV_GLDS1)
-int g_big_min = 0;               // 256 x 128 LDS-DMA tile from this many K chunks on (MVF_CONV_BIG; 0 = off)
-int g_big2_min = 16;             // 256 x 256 LDS-DMA tile (bf16) from this many K chunks on, when the tile count suits it (MVF_CONV_BIG2; 0 = off).
+                                 // (bf16: 8), 0 = off (policy conv_glds1)
+int g_big_min = 0;               // 256 x 128 LDS-DMA tile from this many K chunks on (policy conv_big; 0 = off)
+int g_big2_min = 16;             // 256 x 256 LDS-DMA tile (bf16) from this many K chunks on, when the tile count suits it (policy conv_big2; 0 = off).
                                  // Measured on the R50 bf16 train step: layer3's K = 1024 pointwise launches -16...-19 %, its 3x3 convs -5...-7 %
                                  // (conv family 9.59 -> 9.42 ms per step); from 8 chunks on the K = 512 launches lose (9.49)
 int g_glds_min = -1, g_glds_nb = 2;  // LDS-DMA variant: -1 = the measured default policy (see launch_conv), 0 = off, n = from n K chunks on;
-                                     // with 1 or 2 LDS buffers (MVF_CONV_GLDS=min[,nb])
+                                     // with 1 or 2 LDS buffers (policy conv_glds=min[,nb])
 
 int sk_slots() {
     static int slots = 0;
     if (!slots) {
-        const char* e = getenv("MVF_CONV_LOWK");
-        if (e && e[0] >= '0' && e[0] <= '9') g_lowk_max_chunks = atoi(e);
-        e = getenv("MVF_CONV_PF2");
-        if (e && e[0] >= '0' && e[0] <= '2') g_pf2_mode = e[0] - '0';
-        e = getenv("MVF_CONV_GLDS1_F32");
-        if (e && (e[0] == '0' || e[0] == '1')) g_glds1_f32_infer = e[0] - '0';
-        e = getenv("MVF_CONV_GLDS1");
-        if (e && e[0] >= '0' && e[0] <= '9') g_glds1_max = atoi(e);
-        e = getenv("MVF_F32_X3");
-        if (e && e[0] >= '0' && e[0] <= '7') g_f32_x3 = e[0] - '0';
-        e = getenv("MVF_X3_WIDE");
-        if (e && e[0] >= '0' && e[0] <= '9') g_x3_wide = atoi(e);
-        e = getenv("MVF_X3_DB");
-        if (e && e[0] >= '0' && e[0] <= '9') g_x3_db_min = atoi(e);
-        e = getenv("MVF_CONV_BIG");
-        if (e && e[0] >= '0' && e[0] <= '9') g_big_min = atoi(e);
-        e = getenv("MVF_CONV_BIG2");
-        if (e && e[0] >= '0' && e[0] <= '9') g_big2_min = atoi(e);
-        e = getenv("MVF_CONV_GLDS");
-        if (e && ((e[0] >= '0' && e[0] <= '9') || e[0] == '-')) {
-            g_glds_min = atoi(e);
-            const char* c = strchr(e, ',');
-            if (c && (c[1] >= '1' && c[1] <= '3')) g_glds_nb = c[1] - '0';      // 3 = two buffers, 8 waves (128 x 128 tile only)
-        }
+        g_lowk_max_chunks = mvf_policy_int("conv_lowk", g_lowk_max_chunks);
+        g_pf2_mode = mvf_policy_int("conv_pf2", g_pf2_mode);
+        g_glds1_f32_infer = mvf_policy_int("conv_glds1_f32", g_glds1_f32_infer);
+        g_glds1_max = mvf_policy_int("conv_glds1", g_glds1_max);
+        g_f32_x3 = mvf_policy_int("f32_x3", g_f32_x3);
+        g_x3_wide = mvf_policy_int("x3_wide", g_x3_wide);
+        g_x3_db_min = mvf_policy_int("x3_db", g_x3_db_min);
+        g_big_min = mvf_policy_int("conv_big", g_big_min);
+        g_big2_min = mvf_policy_int("conv_big2", g_big2_min);
+        g_glds_min = mvf_policy_int("conv_glds", g_glds_min);
+        g_glds_nb = mvf_policy_int("conv_glds_nb", g_glds_nb);      // 3 = two buffers, 8 waves (128 x 128 tile only)
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) {
             hipDeviceProp_t p;
@@ -1864,8 +1827,8 @@ int sk_slots() {
     return slots;
 }
 
-float sk_min_us() {          // stream-K when cutting the partial tile wave saves more than this (MVF_SK_MIN_US; the fix-up costs ~60 us)
-    static const float v = getenv("MVF_SK_MIN_US") ? (float)atof(getenv("MVF_SK_MIN_US")) : 60.0f;
+float sk_min_us() {          // stream-K when cutting the partial tile wave saves more than this (policy sk_min_us; the fix-up costs ~60 us)
+    static const float v = (float)mvf_policy_int("sk_min_us", 60);
     return v;
 }
 
@@ -1928,9 +1891,9 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
                         !a.res && !a.stats_part && !a.bn_z, MVF_EINVAL, "conv2d_mvf: needs a plain 1x1 stride-1 conv with bias + ReLU");
         MVF_REQUIRE(img_bytes * (span_imgs + 1) < 0x7ffffff0L, MVF_EUNSUPPORTED, "conv2d_mvf: image too large for tile-relative 32-bit addressing");
         fd_make((unsigned)a.mvf_T, a.fd_t_mul, a.fd_t_shr);
-        // which kernel carries the fused loader: MVF_FUSE_KERNEL = 0 register-staged single buffer, 1 / 2 LDS-DMA with 1 / 2 buffers,
+        // which kernel carries the fused loader: policy fuse_kernel = 0 register-staged single buffer, 1 / 2 LDS-DMA with 1 / 2 buffers,
         // -1 (default) = by K: one DMA buffer up to 16 chunks, two beyond (the policy of the unfused inference launches)
-        static const int fk_env = getenv("MVF_FUSE_KERNEL") ? atoi(getenv("MVF_FUSE_KERNEL")) : -1;
+        static const int fk_env = mvf_policy_int("fuse_kernel", -1);
         const int fk = fk_env >= 0 ? fk_env : (a.nchunks <= 16 ? 1 : 2);
         if (fk == 0) {
             auto k = conv_igemm_lowk_kernel<ET, WM, WN, TM, TN, 4, true, true>;
@@ -1953,44 +1916,28 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
         MVF_LAUNCH_CHECK();
         return MVF_OK;
     }
-    if (a.bn_z || a.ap_scale || a.bw_mode || a.gs_z) sk_wins = false;   // the BatchNorm-backward / BatchNorm-apply epilogues live in the single-buffer kernels only
+    if (a.bn_z || a.ap_scale || a.bw_mode) sk_wins = false;   // the BatchNorm-backward / BatchNorm-apply epilogues live in the single-buffer kernels only
     // fp32 on the bf16 matrix cores: the single-buffer register-staged kernel carries it (x3_on)
     const bool x3 = sizeof(ET) == 4 && x3_on(a);
     if (x3) sk_wins = false;
-    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale || a.bw_mode || a.gs_z || x3) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
+    if ((a.nchunks <= g_lowk_max_chunks && !sk_wins) || a.bn_z || a.ap_scale || a.bw_mode || x3) {      // single LDS buffer: half the LDS, 3-4 workgroups per CU
         constexpr size_t lds_lk = (size_t)kLowkLds<BM, BN>();
-        static const int epi_spec = getenv("MVF_CONV_EPI") ? atoi(getenv("MVF_CONV_EPI")) : 3;     // A/B switch: bit 0 epilogues, bit 1 pointwise loader
+        static const int epi_spec = mvf_policy_int("conv_epi", 3);     // A/B switch: bit 0 epilogues, bit 1 pointwise loader
         const bool pw = (epi_spec & 2) && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.pad_w == 0 && a.split_c == 0 && a.dil <= 1;
         const bool contiguous = (epi_spec & 1) && a.o_s <= 0;
         const bool train_like = contiguous && !a.bias && !a.relu;
         const bool infer_like = contiguous && a.bias && a.relu && !a.stats_part;
         const bool bnsum_epi = (epi_spec & 1) && a.bn_z && !a.relu && !a.res;      // contiguous or a scattered parity class ([r5] + an optional bias)
-        if (a.gs_z) {        // [r5] EPI 11: on the register-staged single-buffer kernel (3 workgroups per CU: the sums' registers spill under the 4-per-CU bound)
-            MVF_REQUIRE(contiguous_ok(a) && a.res && a.out_gate && a.stats_part && !a.bias && !a.relu && !a.bn_z && !a.ap_scale && !a.bw_mode, MVF_EINVAL,
-                        "conv2d gated output + sums: needs a residual, the gate bits, a partial buffer and a contiguous bf16 / fp32 output");
-            static const int gs_glds = getenv("MVF_GSUM_GLDS") ? atoi(getenv("MVF_GSUM_GLDS")) : 0;     // A/B: 1 = the single-buffer LDS-DMA kernel (4 workgroups per CU) up to 8 chunks
-            if constexpr (sizeof(ET) == 2) {
-                if (gs_glds && a.nchunks <= 8) {
-                    const int rc = launch_glds<ET, WM, WN, TM, TN, 11>(1, tiles, st, a);
-                    if (rc != MVF_OK) return rc;
-                    MVF_LAUNCH_CHECK();
-                    return MVF_OK;
-                }
-            }
-            launch_lowk<ET, WM, WN, TM, TN, 11>(pw, tiles, lds_lk, st, a);
-            MVF_LAUNCH_CHECK();
-            return MVF_OK;
-        }
-        // long K, wide output: the 256 x 128 LDS-DMA tile (MVF_CONV_BIG = <min chunks>, 0 = off)
+        // long K, wide output: the 256 x 128 LDS-DMA tile (policy conv_big = <min chunks>, 0 = off)
         if (BN == 128 && sizeof(ET) == 2 && g_big2_min > 0 && a.nchunks >= g_big2_min && a.Cout % 256 == 0 && a.o_s <= 0 && !a.ap_scale && !a.bw_mode) {
             const long t2 = (long)((a.M + 255) / 256) * (a.Cout / 256);
             const int cus = slots / 2;
             const long rounds = (t2 + cus - 1) / cus;
-            static const bool force2 = getenv("MVF_CONV_BIG2_FORCE") != nullptr;      // tests: every eligible shape, whatever its tile count
+            static const bool force2 = mvf_policy_has("conv_big2_force");      // tests: every eligible shape, whatever its tile count
             if (force2 || (t2 >= cus / 2 && (double)t2 / (double)(rounds * cus) >= 0.75)) {       // the last round at least 3/4 full
                 int rc;
-                // the four-phase ping-pong loop carries the same tile (MVF_CONV_P4=0 -> the two-barrier loop); whole K chunks only
-                static const int p4_on = getenv("MVF_CONV_P4") ? atoi(getenv("MVF_CONV_P4")) : 1;
+                // the four-phase ping-pong loop carries the same tile (policy conv_p4=0 -> the two-barrier loop); whole K chunks only
+                static const int p4_on = mvf_policy_int("conv_p4", 1);
                 if (p4_on && a.Cin % 64 == 0 && (a.split_c % 64) == 0) {
                     if (train_like && a.stats_part && !a.res && !a.bn_z) rc = launch_p4<ET, 1>(st, a);
                     else if (bnsum_epi) rc = launch_p4<ET, 6>(st, a);
@@ -2028,7 +1975,7 @@ int launch_conv(const ConvArgs& a0, const SkHost& skh, hipStream_t st) {
             MVF_LAUNCH_CHECK();
             return MVF_OK;
         }
-        // long K: LDS-DMA staging (MVF_CONV_GLDS = "<min chunks>[,<buffers 1|2>]", 0 = off)
+        // long K: LDS-DMA staging (policy conv_glds = "<min chunks>[,<buffers 1|2>]", 0 = off)
         // default policy (measured per layer on the R50 train step, bf16): the DMA variant wins 10-15 % from 32 chunks on
         // (K >= 2048: the 3x3 layers of layer3/4) and, for the 128 x 64 tile, from 9 chunks (layer1's 3x3); it loses 10-20 % on
         // the 8-18 chunk pointwise layers, where three register-staged workgroups per CU hide more latency than two DMA ones
@@ -2143,10 +2090,6 @@ struct BnBwdRecompute {       // optional: BatchNorm backward on the recomputed 
     int mode;                 // 9 apply (y = dz), 10 sums (stats_part)
     const float *mean, *invstd, *gamma, *dgamma, *dbeta;
 };
-struct GatedSums {            // optional ([r5], with out_gate): the BatchNorm-backward sums of the gated output (see ConvArgs::gs_z)
-    const void* z;
-    const float *mean, *invstd;
-};
 struct BnApply {              // optional: the epilogue applies a BatchNorm + residual + ReLU and writes the sign bits (see ConvArgs::ap_scale)
     const float *scale, *shift, *rscale, *rshift;
     unsigned char* bits;
@@ -2154,7 +2097,7 @@ struct BnApply {              // optional: the epilogue applies a BatchNorm + re
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
                          void* stream, const unsigned char* res_mask = nullptr, const BnBwdSums* bnb = nullptr, const MvfFuse* mf = nullptr,
-                         const BnApply* ap = nullptr, const BnBwdRecompute* bw = nullptr, const unsigned char* out_gate = nullptr, const GatedSums* gs = nullptr);
+                         const BnApply* ap = nullptr, const BnBwdRecompute* bw = nullptr, const unsigned char* out_gate = nullptr);
 
 int mvf_conv2d_nhwc_fwd_mvf(const mvf_conv_desc_t* d, const void* x, const void* w_packed, const float* bias, const float* mvf_coef,
                             int cs, int n_segment, int act, void* y, void* ws, size_t ws_bytes, void* stream) {
@@ -2224,19 +2167,15 @@ int mvf_conv2d_nhwc_fwd_resmask_gate(const mvf_conv_desc_t* d, const void* x, co
     return conv_fwd_impl(d, x, x2, w_packed, bias, residual, y, nullptr, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits);
 }
 
-int mvf_conv2d_nhwc_fwd_resmask_gate_sums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* residual,
-                                          const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y, const void* bn_z,
-                                          const float* bn_mean, const float* bn_invstd, float* sums_part, void* ws, size_t ws_bytes, void* stream) {
+int mvf_conv2d_nhwc_fwd_resmask_gate_colsums(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const void* residual,
+                                             const unsigned char* res_sign_bits, const unsigned char* out_gate_bits, void* y, float* sums_part, void* ws, size_t ws_bytes,
+                                             void* stream) {
     MVF_REQUIRE(d && residual && out_gate_bits && sums_part && d->in_dil <= 1 && !d->relu, MVF_EINVAL,
-                "conv2d_resmask_gate_sums: needs a residual, the gate bits, a partial buffer and a stride-1 launch without ReLU");
+                "conv2d_resmask_gate_colsums: needs a residual, the gate bits, a partial buffer and a stride-1 launch without ReLU");
     MVF_REQUIRE(((uintptr_t)out_gate_bits | (uintptr_t)(res_sign_bits ? res_sign_bits : out_gate_bits)) % 16 == 0 || d->cout % 64 != 0, MVF_EINVAL,
-                "conv2d_resmask_gate_sums: gate byte rows must be 16-byte aligned");      // (the epilogue stages both byte planes with 16-byte buffer loads, as _gate does)
-    if (!bn_z)       // column sums only: [.][.][0] = sum gm, [.][.][1] = sum gm^2 (the dz3-free backward takes dgamma from its weight-gradient GEMM: mvf_bn_bwd_dzfree_sums)
-        return conv_fwd_impl(d, x, x2, w_packed, nullptr, residual, y, sums_part, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits);
-    MVF_REQUIRE(bn_mean && bn_invstd, MVF_EINVAL, "conv2d_resmask_gate_sums: bn_z needs bn_mean / bn_invstd");
-    MVF_REQUIRE(((uintptr_t)bn_mean | (uintptr_t)bn_invstd | (uintptr_t)bn_z) % 16 == 0, MVF_EINVAL, "conv2d_resmask_gate_sums: bn_z / bn_mean / bn_invstd must be 16-byte aligned");
-    const GatedSums gs = {bn_z, bn_mean, bn_invstd};
-    return conv_fwd_impl(d, x, x2, w_packed, nullptr, residual, y, sums_part, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits, &gs);
+                "conv2d_resmask_gate_colsums: gate byte rows must be 16-byte aligned");      // (the epilogue stages both byte planes with 16-byte buffer loads, as _gate does)
+    // [.][.][0] = sum gm, [.][.][1] = sum gm^2 of the stored values (the dz3-free backward takes dgamma from its weight-gradient GEMM: mvf_bn_bwd_dzfree_sums)
+    return conv_fwd_impl(d, x, x2, w_packed, nullptr, residual, y, sums_part, nullptr, ws, ws_bytes, stream, res_sign_bits, nullptr, nullptr, nullptr, nullptr, out_gate_bits);
 }
 
 int mvf_conv2d_nhwc_dgrad_bnsums_split(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias, void* y,
@@ -2277,7 +2216,7 @@ int mvf_conv2d_nhwc_fwd_stats(const mvf_conv_desc_t* d, const void* x, const voi
 static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2, const void* w_packed, const float* bias,
                          const void* residual, void* y, float* stats_part, const float* stats_shift, void* ws, size_t ws_bytes,
                          void* stream, const unsigned char* res_mask, const BnBwdSums* bnb, const MvfFuse* mf, const BnApply* ap, const BnBwdRecompute* bw,
-                         const unsigned char* out_gate, const GatedSums* gs) {
+                         const unsigned char* out_gate) {
     MVF_REQUIRE(d && x && w_packed && (y || (stats_part && !bnb)), MVF_EINVAL, "conv2d: NULL argument");      // (y may be NULL for a statistics-only pass)
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "conv2d: bad dtype %d", d->dtype);
     MVF_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -2312,13 +2251,11 @@ static int conv_fwd_impl(const mvf_conv_desc_t* d, const void* x, const void* x2
     a.res_c0 = d->res_c0 > 0 ? d->res_c0 : 0;
     a.res_mask = res_mask;
     a.out_gate = out_gate;
-    if (gs) { a.gs_z = (const char*)gs->z; a.gs_mean = gs->mean; a.gs_invstd = gs->invstd; }
     MVF_REQUIRE(d->x_c0 == 0 || (d->split_c > 0 && d->x_c0 > 0 && d->x_c0 <= d->split_c && d->x_c0 % ue == 0 && d->x_pix_stride >= d->cin - d->x_c0), MVF_EINVAL,
                 "conv2d: x_c0=%d needs a split operand (split_c=%d), 0 < x_c0 <= split_c, a multiple of %d, and x rows of >= cin - x_c0 channels", d->x_c0, d->split_c, ue);
     a.x_c0 = d->x_c0;
-    static const int mask_lds_on = getenv("MVF_MASK_LDS") ? atoi(getenv("MVF_MASK_LDS")) : 1;
-    a.mask_lds = mask_lds_on;
-    static const int prio_on = getenv("MVF_CONV_PRIO") ? atoi(getenv("MVF_CONV_PRIO")) : 0;
+    a.mask_lds = 1;
+    static const int prio_on = mvf_policy_int("conv_prio", 0);
 #ifdef MVF_CONV_ABLATE
     a.prio = prio_on;                 // ablation builds: bit 0 priority, bits 1-5 remove loads / MFMAs / epilogue parts (wrong results)
 #else

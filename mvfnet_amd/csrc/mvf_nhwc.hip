@@ -40,13 +40,10 @@ struct NhwcArgs {
     int add_c;
     const unsigned char* add_mask;   // optional gate bits of the addend: [pixels][add_c/4] bytes, bit j of byte k = channel 4k+j
     float* stats_part;               // [r5] optional (chunked kernel): CHANNEL-MAJOR [cs][gridDim.x][2] column sums of (y - K), (y - K)^2 over the workgroup's outputs AS STORED
-    const void* gs_z;                // [r5] with stats_part and out_gate: the sums become the BatchNorm-backward sums of the gated output -- sum gm, sum gm (gs_z - gs_mean) gs_invstd,
-    const float *gs_mean, *gs_invstd;     //      gs_z = that BatchNorm's stored input (pitch out_c), as mvf_conv2d_nhwc_fwd_resmask_gate_sums does for the channels >= cs
-    const float* stats_shift;        //      K per channel (the BatchNorm's old running mean; NULL = 0): the statistics pass of MVF's BatchNorm3d without a pass over y
-    const unsigned char* out_gate;   // [r5] optional gate bits of the OUTPUT (after the addend): [pixels][out_c/4] bytes, same layout (VEC = 4 kernels only)
-    int tsplit;    // 1: one frame per workgroup (grid.z = T) instead of sliding along t -- 7 loads, one round trip, T x the threads
     int rb, cw, lbands;   // [r5] LDS-tiled kernel (mvf_nhwc_apply_lds): rows per band, channels per workgroup, bands per clip
     unsigned fdw_mul, fdw_shr, fdrw_mul, fdrw_shr;      // host-made magic for n / w and n / ((rb + 2) w)
+    const float* stats_shift;        // K per channel for the statistics sums (the BatchNorm's old running mean; NULL = 0): MVF's BatchNorm3d statistics without a pass over y
+    const unsigned char* out_gate;   // [r5] optional gate bits of the OUTPUT (after the addend): [pixels][out_c/4] bytes, same layout (VEC = 4 kernels only)
 };
 
 // one 3-tap view with the contraction spelled out: every stencil kernel of this file rounds the same way whatever the compiler would fuse on its own
@@ -100,13 +97,11 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply(NhwcArgs a) {
         const long e0 = ((long)n * T * HW + pix) * C + c0;     // (n, t=0, pix, c0)
         const long o0 = ((long)n * T * HW + pix) * a.out_c + c0;
         float prev[VEC], cur[VEC], next[VEC], up[VEC], dn[VEC], lf[VEC], rt[VEC], y[VEC];
-        // sliding: t runs 0..T-1 with (prev, cur, next) carried in registers.  tsplit: this workgroup owns frame blockIdx.z only; its
-        // previous frame is loaded like the other neighbours (unconditionally, from the frame itself when t == 0, then zeroed)
-        const int t_begin = a.tsplit ? (int)blockIdx.z : 0, t_end = a.tsplit ? t_begin + 1 : T;
-        Vec<ET, VEC>::load(x + e0 + (long)(t_begin > 0 ? t_begin - 1 : 0) * fstride, prev);
-        Vec<ET, VEC>::load(x + e0 + (long)t_begin * fstride, cur);
+        // sliding: t runs 0..T-1 with (prev, cur, next) carried in registers
+        const int t_begin = 0, t_end = T;
+        Vec<ET, VEC>::load(x + e0, cur);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) prev[i] = t_begin > 0 ? prev[i] : 0.f;
+        for (int i = 0; i < VEC; ++i) prev[i] = 0.f;
         // neighbour validity is per thread, constant over t: out-of-range neighbours re-read the centre pixel (always valid)
         // and are zeroed afterwards, so the five loads of a t-step are unconditional and go out back to back (a conditional
         // load each cost its own memory round trip: the compiler waits at every join)
@@ -180,13 +175,11 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
     const bool vh = a.mode & MVF_VIEW_H, vw = a.mode & MVF_VIEW_W;
     const bool hs = a.scale != nullptr;
     float wt[VEC][3], wh[VEC][3], ww[VEC][3], sc[VEC], sh[VEC];
-    float st1[VEC], st2[VEC], kk[VEC], gmu[VEC], grs[VEC];
+    float st1[VEC], st2[VEC], kk[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         st1[i] = st2[i] = 0.f;
         kk[i] = (a.stats_part && a.stats_shift) ? a.stats_shift[c0 + i] : 0.f;
-        gmu[i] = a.gs_z ? a.gs_mean[c0 + i] : 0.f;
-        grs[i] = a.gs_z ? a.gs_invstd[c0 + i] : 0.f;
     }
     {
         auto load12 = [&](const float* p, bool on, float (&dst)[VEC][3]) {
@@ -228,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
         const bool ok_up = vh && hh > 0, ok_dn = vh && hh < H - 1, ok_lf = vw && wv > 0, ok_rt = vw && wv < W - 1;
         const long d_up = ok_up ? -(long)W * C : 0, d_dn = ok_dn ? (long)W * C : 0, d_lf = ok_lf ? -(long)C : 0, d_rt = ok_rt ? (long)C : 0;
         for (int t0 = 0; t0 < T; t0 += TB) {
-            float cen[TB + 2][VEC], up[TB][VEC], dn[TB][VEC], lf[TB][VEC], rt[TB][VEC], ad[TB][VEC], zz[TB][VEC];
+            float cen[TB + 2][VEC], up[TB][VEC], dn[TB][VEC], lf[TB][VEC], rt[TB][VEC], ad[TB][VEC];
             unsigned mb[TB], gb[TB];
 #pragma unroll
             for (int k = 0; k < TB + 2; ++k) {                 // frames t0 - 1 .. t0 + TB (clamped into the clip; zeroed below where outside)
@@ -247,7 +240,6 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
                 mb[k] = 0xfu;
                 gb[k] = 0xfu;
                 if (a.out_gate) gb[k] = a.out_gate[(((long)n * T + t) * HW + pix) * (a.out_c / 4) + c0 / 4] >> (c0 & 3);
-                if (a.gs_z) Vec<ET, VEC>::load(reinterpret_cast<const ET*>(a.gs_z) + (((long)n * T + t) * HW + pix) * a.out_c + c0, zz[k]);
                 if (a.add) {
                     const long apix = ((long)n * T + t) * HW + pix;
                     Vec<ET, VEC>::load(reinterpret_cast<const ET*>(a.add) + apix * a.add_c + c0, ad[k]);
@@ -281,14 +273,9 @@ __global__ __launch_bounds__(kThreads) void mvf_nhwc_apply_chunked(NhwcArgs a) {
                     for (int i = 0; i < VEC; ++i) {
                         float v = y[i];
                         if constexpr (sizeof(ET) == 2) v = bf16_to_f32(f32_to_bf16(v));
-                        if (a.gs_z) {                          // BatchNorm-backward sums of the gated output
-                            st1[i] += v;
-                            st2[i] += v * ((zz[k][i] - gmu[i]) * grs[i]);
-                        } else {
-                            const float dlt = v - kk[i];
-                            st1[i] += dlt;
-                            st2[i] += dlt * dlt;
-                        }
+                        const float dlt = v - kk[i];
+                        st1[i] += dlt;
+                        st2[i] += dlt * dlt;
                     }
                 }
             }
@@ -369,7 +356,7 @@ __global__ __launch_bounds__(kThreads, 2) void mvf_nhwc_apply_lds(NhwcArgs a) {
     const int g = tid % NG, c0 = cbase + g * VEC;
     const bool vh = a.mode & MVF_VIEW_H, vw = a.mode & MVF_VIEW_W;
     const bool hs = a.scale != nullptr;
-    float wt[VEC][3], wh[VEC][3], ww[VEC][3], sc[VEC], sh[VEC], st1[VEC], st2[VEC], kk[VEC], gmu[VEC], grs[VEC];
+    float wt[VEC][3], wh[VEC][3], ww[VEC][3], sc[VEC], sh[VEC], st1[VEC], st2[VEC], kk[VEC];
     {
         auto load12 = [&](const float* p, bool on, float (&dst)[VEC][3]) {
             float f[12];
@@ -398,8 +385,6 @@ __global__ __launch_bounds__(kThreads, 2) void mvf_nhwc_apply_lds(NhwcArgs a) {
             sh[i] = hs ? a.shift[c0 + i] : 0.f;
             st1[i] = st2[i] = 0.f;
             kk[i] = (a.stats_part && a.stats_shift) ? a.stats_shift[c0 + i] : 0.f;
-            gmu[i] = a.gs_z ? a.gs_mean[c0 + i] : 0.f;
-            grs[i] = a.gs_z ? a.gs_invstd[c0 + i] : 0.f;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -414,7 +399,7 @@ __global__ __launch_bounds__(kThreads, 2) void mvf_nhwc_apply_lds(NhwcArgs a) {
         if (h >= H) break;                                         // (items are ordered by row: the rest of this thread's items are below the image too)
         const long pix0 = (long)n * TT * HW + h * W + w;           // (n, t = 0, h, w)
         constexpr int TC = 4;                                      // frames per batch of streamed operands (addend, gate bytes, bn_z): one batch ahead
-        struct Side { uint2 ad[TC], zz[TC]; unsigned mb[TC], gb[TC]; };
+        struct Side { uint2 ad[TC]; unsigned mb[TC], gb[TC]; };
         auto load_side = [&](int tc, Side& sd) {
 #pragma unroll
             for (int k = 0; k < TC; ++k) {
@@ -422,8 +407,6 @@ __global__ __launch_bounds__(kThreads, 2) void mvf_nhwc_apply_lds(NhwcArgs a) {
                 sd.mb[k] = 0xfu;
                 sd.gb[k] = 0xfu;
                 sd.ad[k] = make_uint2(0u, 0u);
-                sd.zz[k] = make_uint2(0u, 0u);
-                if (a.gs_z) sd.zz[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.gs_z) + apix * a.out_c + c0);
                 if (a.add) {
                     sd.ad[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.add) + apix * a.add_c + c0);
                     if (a.add_mask) sd.mb[k] = a.add_mask[apix * (a.add_c / 4) + c0 / 4];
@@ -469,19 +452,12 @@ __global__ __launch_bounds__(kThreads, 2) void mvf_nhwc_apply_lds(NhwcArgs a) {
                 }
                 st4(out + (pix0 + (long)t * HW) * a.out_c + c0, make_float4(y[0], y[1], y[2], y[3]));
                 if (a.stats_part) {                                // statistics of what is STORED
-                    const float zv[VEC] = {__uint_as_float(sd.zz[k].x << 16), __uint_as_float(sd.zz[k].x & 0xffff0000u), __uint_as_float(sd.zz[k].y << 16),
-                                           __uint_as_float(sd.zz[k].y & 0xffff0000u)};
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
                         const float v = bf16_to_f32(f32_to_bf16(y[i]));
-                        if (a.gs_z) {                              // BatchNorm-backward sums of the gated output
-                            st1[i] += v;
-                            st2[i] += v * ((zv[i] - gmu[i]) * grs[i]);
-                        } else {
-                            const float dlt = v - kk[i];
-                            st1[i] += dlt;
-                            st2[i] += dlt * dlt;
-                        }
+                        const float dlt = v - kk[i];
+                        st1[i] += dlt;
+                        st2[i] += dlt * dlt;
                     }
                 }
                 prev = cur;
@@ -516,14 +492,14 @@ __global__ __launch_bounds__(kThreads, 2) void mvf_nhwc_apply_lds(NhwcArgs a) {
 
 struct LdsPlan { int rb, cw, bands; size_t lds; };
 // the LDS-tiled kernel's plan: the widest channel chunk (64 / 32 / 16) whose band of >= 2 rows (or the whole image) + halo fits 64 KB over all T frames, taken when
-// it makes >= MVF_STENCIL_LDS_MINWG (150) workgroups; a stage whose whole planes fit (7 x 7: 128 workgroups) may halve the budget once if the chunk stays 64 wide.
+// it makes >= policy stencil_lds_minwg (150) workgroups; a stage whose whole planes fit (7 x 7: 128 workgroups) may halve the budget once if the chunk stays 64 wide.
 // Everything smaller stays on the chunked kernel: with few workgroups the two-phase tile (load all, then compute) has nothing to overlap with.  Measured in the
 // step (ms, chunked / tiled): C3 18.52 / 18.24-18.29, C4 31.30 / 31.03-31.05.  The threshold (400 / 150; three alternations): 12 clips per GPU (168 workgroups on
 // layer3) 9.11-9.13 / 9.06-9.09, C5 video 4.97-5.00 / 4.94-4.95, C4 30.84-30.89 / 30.76-30.86, the 16-clip inference chains (224) 4.00-4.03 / 4.02-4.05;
 // narrower 32-channel tiles forced on those small launches (budget halving without the 64-wide rule) measured 9.38 -> 9.42 and 4.04 -> 4.15.
 static bool lds_plan(int T, int H, int W, int cs, int n_clips, LdsPlan& best) {
-    static const int on = getenv("MVF_STENCIL_LDS") ? atoi(getenv("MVF_STENCIL_LDS")) : 1;
-    static const int min_wg = getenv("MVF_STENCIL_LDS_MINWG") ? atoi(getenv("MVF_STENCIL_LDS_MINWG")) : 150;
+    static const int on = mvf_policy_int("stencil_lds", 1);
+    static const int min_wg = mvf_policy_int("stencil_lds_minwg", 150);
     if (!on || (T != 4 && T != 8 && T != 16)) return false;
     auto bytes = [&](int rb, int cw) { return (((size_t)T * (rb + 2) * W * cw * 2 / 16 + 63) / 64) * 1024; };      // whole 64-piece DMA instructions
     for (size_t budget = 65536; budget >= 32768; budget >>= 1) {
@@ -578,8 +554,7 @@ __global__ void copy_tail_nhwc(const ET* src, ET* dst, long npix, int c, int cs)
 
 }  // namespace
 
-struct NhwcFlip { int flip; const void* add; int add_c; const unsigned char* add_mask; const unsigned char* out_gate; float* stats_part; const float* stats_shift; int rows_only;
-                  const void* gs_z; const float* gs_mean; const float* gs_invstd; };
+struct NhwcFlip { int flip; const void* add; int add_c; const unsigned char* add_mask; const unsigned char* out_gate; float* stats_part; const float* stats_shift; int rows_only; };
 int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
                              const float* ww, const float* scale, const float* shift, NhwcFlip fl, hipStream_t st) {
     // In-place hazard: a workgroup re-reads neighbour pixels that another workgroup may already have overwritten.
@@ -598,7 +573,6 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     a.out_gate = fl.out_gate;
     a.stats_part = fl.stats_part;
     a.stats_shift = fl.stats_shift;
-    a.gs_z = fl.gs_z; a.gs_mean = fl.gs_mean; a.gs_invstd = fl.gs_invstd;
     const int esz = d->dtype == MVF_F32 ? 4 : 2;
     const bool vec = (d->cs % 4 == 0) && (d->c % 4 == 0) && (out_c % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % (4 * esz) == 0) &&
                      (!fl.add || (fl.add_c % 4 == 0 && (uintptr_t)fl.add % (4 * esz) == 0));
@@ -611,26 +585,19 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
     const int nplanes = kThreads / cgp;
     // enough workgroups to fill 256 CUs several times over: 4 pixels per thread-plane (amortises the tap registers) only when that
     // still leaves >= 1024 workgroups -- the 14x14 / 7x7 stages of a 16-32 clip batch got 112-224 workgroups and ran latency-bound
-    static const int pix_env = getenv("MVF_STENCIL_PIX") ? atoi(getenv("MVF_STENCIL_PIX")) : 0;
-    int per = pix_env > 0 ? pix_env : 4;
-    if (pix_env <= 0)
-        while (per > 1 && (long)a.n_clips * ((HW + nplanes * per - 1) / (nplanes * per)) * ((a.cg + cgp - 1) / cgp) < 1024) per >>= 1;
+    int per = 4;
+    while (per > 1 && (long)a.n_clips * ((HW + nplanes * per - 1) / (nplanes * per)) * ((a.cg + cgp - 1) / cgp) < 1024) per >>= 1;
     int pixw = std::max(nplanes * per, 1);
     while ((long)a.n_clips * ((HW + pixw - 1) / pixw) > 8192 && pixw < HW) pixw *= 2;
     a.pixw = std::min(pixw, HW);
     a.bands = (HW + a.pixw - 1) / a.pixw;
-    // experiment switch (MVF_STENCIL_TSPLIT=1): one frame per workgroup instead of the serial walk over t.  Measured neutral in
-    // the train step (24.19 vs 24.17 ms) and 1 % slower in bf16 inference (4.58 vs 4.63 ms): the walk is not what bounds it. Off.
-    static const int tsplit_env = getenv("MVF_STENCIL_TSPLIT") ? atoi(getenv("MVF_STENCIL_TSPLIT")) : 0;
-    a.tsplit = tsplit_env != 0 && a.T > 1;
-    dim3 grid(a.n_clips * a.bands, (a.cg + cgp - 1) / cgp, a.tsplit ? a.T : 1);
+    dim3 grid(a.n_clips * a.bands, (a.cg + cgp - 1) / cgp, 1);
     // [r5] bf16: the LDS-tiled kernel wherever its plan exists
     LdsPlan lp = {};
     // (the plan depends on the shape only -- mvf_nhwc_stencil_stats_rows must name the same partial rows as the launch; operands that break its alignment
     // rules fall back to the chunked kernel, which is an error when partial rows were asked for)
-    const bool lds_shape = (!fl.add || fl.add_c % 4 == 0) && !a.tsplit && lds_shape_plan(d, out_c, lp);
-    const bool use_lds = lds_shape && vec && (uintptr_t)x % 16 == 0 && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0 &&
-                         (!fl.gs_z || (uintptr_t)fl.gs_z % 8 == 0);
+    const bool lds_shape = (!fl.add || fl.add_c % 4 == 0) && lds_shape_plan(d, out_c, lp);
+    const bool use_lds = lds_shape && vec && (uintptr_t)x % 16 == 0 && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0;
     MVF_REQUIRE(use_lds || !lds_shape || !fl.stats_part, MVF_EINVAL, "nhwc_stencil: operands of a statistics launch must be 16-byte aligned (x, taps) / 8-byte (out, addend, bn_z)");
     if (use_lds) {
         if (fl.rows_only) return a.n_clips * lp.bands;
@@ -643,10 +610,10 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
         MVF_LAUNCH_CHECK();
     }
     if (fl.rows_only) return (int)grid.x;                  // mvf_nhwc_stencil_stats_rows: the partial-row count of this plan, nothing is launched
-    // [r3] all of a chunk's loads in flight at once instead of the serial walk over t (MVF_STENCIL_CHUNKED=0: the walk)
-    static const int chunked_env = getenv("MVF_STENCIL_CHUNKED") ? atoi(getenv("MVF_STENCIL_CHUNKED")) : 1;
-    const bool chunked = chunked_env != 0 && vec && !a.tsplit && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0;
-    MVF_REQUIRE(!fl.stats_part || chunked, MVF_EUNSUPPORTED, "nhwc_stencil_stats: needs the chunked 4-channel kernel (cs, pitches %% 4 == 0, 16-byte aligned taps, MVF_STENCIL_CHUNKED != 0)");
+    // [r3] all of a chunk's loads in flight at once instead of the serial walk over t (policy stencil_chunked=0: the walk)
+    static const int chunked_env = mvf_policy_int("stencil_chunked", 1);
+    const bool chunked = chunked_env != 0 && vec && ((uintptr_t)wt | (uintptr_t)(wh ? wh : wt) | (uintptr_t)(ww ? ww : wt)) % 16 == 0;
+    MVF_REQUIRE(!fl.stats_part || chunked, MVF_EUNSUPPORTED, "nhwc_stencil_stats: needs the chunked 4-channel kernel (cs, pitches %% 4 == 0, 16-byte aligned taps, policy stencil_chunked != 0)");
     if (use_lds) {
         // launched above
     } else if (d->dtype == MVF_F32) {
@@ -673,7 +640,7 @@ int mvf_nhwc_fwd_infer_impl2(const mvf_desc_t* d, const void* x, void* out, int 
 
 int mvf_nhwc_fwd_infer_impl(const mvf_desc_t* d, const void* x, void* out, int out_c, const float* wt, const float* wh,
                             const float* ww, const float* scale, const float* shift, hipStream_t st) {
-    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
     return mvf_nhwc_fwd_infer_impl2(d, x, out, out_c, wt, wh, ww, scale, shift, f, st);
 }
 
@@ -958,11 +925,10 @@ TapRows tap_rows_plan(long rows, int cs) {
     p.nblk = (int)((rows + rpb - 1) / rpb);
     return p;
 }
-int g_tap_rows = -1;      // MVF_TAPGRAD_ROWS=0 keeps the (clip, band) kernel (A/B switch)
+int g_tap_rows = -1;      // policy tapgrad_rows=0 keeps the (clip, band) kernel (A/B switch)
 bool tap_rows_on() {
     if (g_tap_rows < 0) {
-        const char* e = getenv("MVF_TAPGRAD_ROWS");
-        g_tap_rows = (e && e[0] == '0') ? 0 : 1;
+        g_tap_rows = mvf_policy_int("tapgrad_rows", 1) != 0 ? 1 : 0;
     }
     return g_tap_rows != 0;
 }
@@ -998,7 +964,7 @@ int mvf_nhwc_stencil(const mvf_desc_t* d, const void* x, int x_c, void* out, int
     MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil: gate bits need an addend with pitch % 4 == 0");
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, nullptr, nullptr, nullptr, 0};
     return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, scale, shift, f, (hipStream_t)stream);
 }
 
@@ -1013,23 +979,22 @@ int mvf_nhwc_stencil_gate(const mvf_desc_t* d, const void* x, int x_c, void* out
     MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil_gate: gate bits need an addend with pitch % 4 == 0");
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, out_gate_bits, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, out_gate_bits, nullptr, nullptr, 0};
     return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, scale, shift, f, (hipStream_t)stream);
 }
 
-// [r5] mvf_nhwc_stencil_gate that ALSO accumulates the BatchNorm-backward sums of the gated slice it stores: sums_part CHANNEL-MAJOR
-// [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] = per-workgroup sums of gm and gm * (bn_z - bn_mean) * bn_invstd (bn_z: the stored input of the
-// BatchNorm the gated gradient belongs to, pitch out_c) -> mvf_bn_bwd_finalize.  The slice's share of mvf_conv2d_nhwc_fwd_resmask_gate_sums.
-int mvf_nhwc_stencil_gate_sums(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
-                               const float* w_w, int flip, const void* addend, int addend_c, const unsigned char* addend_sign_bits,
-                               const unsigned char* out_gate_bits, const void* bn_z, const float* bn_mean, const float* bn_invstd, float* sums_part, void* stream) {
-    MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs && out_gate_bits && sums_part && (!bn_z || (bn_mean && bn_invstd)), MVF_EINVAL,
-                "nhwc_stencil_gate_sums: bad argument");      // (bn_z = NULL: the column sums of gm and gm^2 only -- mvf_bn_bwd_dzfree_sums takes dgamma from the weight-gradient GEMM)
-    MVF_REQUIRE(!addend || addend_c >= d->cs, MVF_EINVAL, "nhwc_stencil_gate_sums: addend pitch < cs");
-    MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil_gate_sums: gate bits need an addend with pitch % 4 == 0");
+// [r5] mvf_nhwc_stencil_gate that ALSO accumulates the column sums of the gated slice it stores: sums_part CHANNEL-MAJOR
+// [cs][mvf_nhwc_stencil_stats_rows(d, x_c, out_c)][2] = per-workgroup sums of gm and gm^2 -- the slice's share of mvf_conv2d_nhwc_fwd_resmask_gate_colsums
+// (the dz3-free block below takes bn3's dbeta from them and dgamma from its weight-gradient GEMM: mvf_bn_bwd_dzfree_sums)
+int mvf_nhwc_stencil_gate_colsums(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
+                                  const float* w_w, int flip, const void* addend, int addend_c, const unsigned char* addend_sign_bits,
+                                  const unsigned char* out_gate_bits, float* sums_part, void* stream) {
+    MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs && out_gate_bits && sums_part, MVF_EINVAL, "nhwc_stencil_gate_colsums: bad argument");
+    MVF_REQUIRE(!addend || addend_c >= d->cs, MVF_EINVAL, "nhwc_stencil_gate_colsums: addend pitch < cs");
+    MVF_REQUIRE(!addend_sign_bits || (addend && addend_c % 4 == 0), MVF_EINVAL, "nhwc_stencil_gate_colsums: gate bits need an addend with pitch % 4 == 0");
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, out_gate_bits, sums_part, nullptr, 0, bn_z, bn_mean, bn_invstd};
+    NhwcFlip f = {flip, addend, addend_c, addend_sign_bits, out_gate_bits, sums_part, nullptr, 0};
     return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, nullptr, nullptr, f, (hipStream_t)stream);
 }
 
@@ -1054,7 +1019,7 @@ int mvf_nhwc_stencil_stats_rows(const mvf_desc_t* d, int x_c, int out_c) {
     if (!d || d->cs <= 0 || d->nt <= 0) return 0;
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr};
+    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 1};
     return mvf_nhwc_fwd_infer_impl2(&dd, (const void*)16, (void*)32, out_c, (const float*)16, (const float*)16, (const float*)16, nullptr, nullptr, f, nullptr);
 }
 int mvf_nhwc_stencil_stats(const mvf_desc_t* d, const void* x, int x_c, void* out, int out_c, const float* w_t, const float* w_h,
@@ -1062,7 +1027,7 @@ int mvf_nhwc_stencil_stats(const mvf_desc_t* d, const void* x, int x_c, void* ou
     MVF_REQUIRE(d && x && out && w_t && x != out && x_c >= d->cs && out_c >= d->cs && stats_part, MVF_EINVAL, "nhwc_stencil_stats: bad argument");
     mvf_desc_t dd = *d;
     dd.c = x_c;
-    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, stats_part, stats_shift, 0, nullptr, nullptr, nullptr};
+    NhwcFlip f = {0, nullptr, 0, nullptr, nullptr, stats_part, stats_shift, 0};
     return mvf_nhwc_fwd_infer_impl2(&dd, x, out, out_c, w_t, w_h, w_w, nullptr, nullptr, f, (hipStream_t)stream);
 }
 

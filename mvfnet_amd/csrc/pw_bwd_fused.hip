@@ -84,7 +84,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ void full_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void g_ahead_barrier() { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#ifdef MVF_PWBF_ABLATE
+#ifdef policy pwbf_ablate
 #define PWBF_ON(bit) if (!(a.ablate & (bit)))
 #else
 #define PWBF_ON(bit)
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kT) void pw_bwd_fused_kernel(const mvf_internal::Pw
             PWBF_ON(16) if (g2) dma_g(cc + 2);
             PWBF_ON(8) gemm3();
             PWBF_ON(4) gemm2(cc & 1);
-#ifdef MVF_PWBF_ABLATE
+#ifdef policy pwbf_ablate
             full_barrier();
 #else
             if (g2) g_ahead_barrier(); else full_barrier();          // da2 tile complete; every read of the dz3 / a2 tiles done; chunk c + 1 landed
@@ -419,7 +419,7 @@ namespace mvf_internal {
 // workgroups (= weight-gradient slabs; bn2's sums take 2 x this many partial rows) for an [m][256] gradient over a 64-channel conv input; 0 = not built
 int pw_bwd_fused_plan(long m, int c, int k, int* rows_per_split) {
     if (c != NC || k != NK || m <= 0 || m * (long)NC * 2 >= 0x7ffffff0L) return 0;
-    static const int wgs_env = getenv("MVF_PWBF_WGS") ? std::max(1, atoi(getenv("MVF_PWBF_WGS"))) : 256;      // one persistent workgroup per CU
+    static const int wgs_env = std::max(1, mvf_policy_int("pwbf_wgs", 256));      // one persistent workgroup per CU
     long rows = (m + wgs_env - 1) / wgs_env;
     rows = (rows + CH - 1) / CH * CH;
     if (rows < 2 * CH) rows = 2 * CH;
@@ -435,8 +435,8 @@ int pw_bwd_fused_launch(const PwBwdFusedArgs& a0, hipStream_t st) {
         attr = true;
     }
     PwBwdFusedArgs a = a0;
-#ifdef MVF_PWBF_ABLATE
-    a.ablate = getenv("MVF_PWBF_ABLATE") ? atoi(getenv("MVF_PWBF_ABLATE")) : 0;
+#ifdef policy pwbf_ablate
+    a.ablate = mvf_policy_int("pwbf_ablate", 0);
 #endif
     hipLaunchKernelGGL(k, dim3(a.nsplit), dim3(kT), kLds, st, a);
     MVF_LAUNCH_CHECK();

@@ -205,8 +205,7 @@ namespace mvf_internal {
 
 // MVF_OK when launched, -1 when the shape is not this kernel's (the caller falls back to the implicit-GEMM epilogues)
 int pw_sums_launch(const PwSumsArgs& s, hipStream_t st) {
-    const char* sw = getenv("MVF_PW_SUMS");               // A/B switch, read per call: 0 = the implicit-GEMM epilogues
-    if (sw && atoi(sw) == 0) return -1;
+    if (mvf_policy_int("pw_sums", 1) == 0) return -1;      // A/B switch, read per call: 0 = the implicit-GEMM epilogues
     if (s.K != 64 || (s.N != 256 && s.N != 128) || s.xps < 64 || s.xps % 8 || s.M <= 0) return -1;
     const long nblocks = ((long)s.M + 31) / 32;
     if (nblocks >= (1L << 31)) return -1;
@@ -218,8 +217,7 @@ int pw_sums_launch(const PwSumsArgs& s, hipStream_t st) {
         if (cus <= 0) cus = 256;
     }
     const int nhalf = s.N / 128;
-    const char* wpc = getenv("MVF_PW_SUMS_WGS");
-    const long per_cu = wpc ? atoi(wpc) : 3;
+    const long per_cu = mvf_policy_int("pw_sums_wgs", 3);
     int nwg = (int)std::min<long>((nblocks + 3) / 4, per_cu * cus / nhalf);      // resident workgroups per CU, every wave walks its blocks
     if (nwg > s.rows / 2) nwg = s.rows / 2;                         // two partial rows per workgroup (and channel half)
     if (nwg < 1) return -1;

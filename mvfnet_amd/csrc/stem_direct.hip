@@ -208,8 +208,7 @@ namespace mvf_internal {
 
 // MVF_OK when launched, -1 when the shape is not this kernel's (the caller falls back to the implicit-GEMM path)
 int stem_direct_launch(const StemDirectArgs& s, hipStream_t st) {
-    const char* sw = getenv("MVF_STEM_DIRECT");          // A/B switch, read per call (one stem launch per pass): 0 = the implicit-GEMM kernel
-    if (sw && atoi(sw) == 0) return -1;
+    if (mvf_policy_int("stem_direct", 1) == 0) return -1;      // A/B switch, read per call (one stem launch per pass): 0 = the implicit-GEMM kernel
     if (s.epi != 1 && s.epi != 4) return -1;
     if (s.W % 2 || s.Ho <= 0 || s.Wo <= 0 || s.wK != 224) return -1;
     if (2 * (s.Ho - 1) + 7 > s.H || 2 * (s.Wo - 1) + 8 > s.W) return -1;          // every fragment read stays inside the image row
@@ -235,8 +234,7 @@ int stem_direct_launch(const StemDirectArgs& s, hipStream_t st) {
     const long tiles = (long)s.N * a.tiles_per_frame;
     if (tiles >= (1L << 31)) return -1;
     a.tiles = (int)tiles;
-    const char* tw = getenv("MVF_STEM_TPW");
-    a.tiles_per_wg = tw ? atoi(tw) : (int)((tiles + 511) / 512);           // ~2 workgroups per CU, each reusing its weight registers
+    a.tiles_per_wg = mvf_policy_int("stem_tpw", (int)((tiles + 511) / 512));           // ~2 workgroups per CU, each reusing its weight registers
     if (a.tiles_per_wg < 1) a.tiles_per_wg = 1;
     const long grid = (tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
     if (s.epi == 1) {

@@ -1515,7 +1515,7 @@ int mvf_bn_bwd_reduce(const void* g, int g_pitch, const void* z, const void* yma
     float* part = (float*)ws;
     const bool wide = false;                 // measured: the 8-byte-lane variant is ~7% faster for this kernel (more rows in flight per wave)
     const int gy = col_plan(m, c, (dtype != MVF_F32 && wide) ? 8 : 4).gy;
-    static const bool bn_spec = !(getenv("MVF_BN_SPEC") && getenv("MVF_BN_SPEC")[0] == '0');      // A/B switch
+    static const bool bn_spec = (mvf_policy_int("bn_spec", 1) != 0);      // A/B switch
     if (bn_spec)
         MVF_BN_DISPATCH_MM(bn_bwd_reduce_kernel, mask_mode, wide, 2048, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, mean, invstd, scale, shift, mask_mode, (ET*)gm_out, p.cqb, p.rows, part);
     else
@@ -1546,7 +1546,7 @@ int mvf_bn_bwd_apply_masked(const void* g, int g_pitch, const void* z, const voi
     hipStream_t st = (hipStream_t)stream;
     const bool wide = c % 8 == 0 && g_pitch % 8 == 0 && al16(g) && al16(z) && al16(dz) && (mask_mode != 1 || al16(ymask)) &&
                       (mask_mode != 4 || ((uintptr_t)ymask & 1) == 0);
-    static const bool bn_spec = !(getenv("MVF_BN_SPEC") && getenv("MVF_BN_SPEC")[0] == '0');      // A/B switch
+    static const bool bn_spec = (mvf_policy_int("bn_spec", 1) != 0);      // A/B switch
     if (bn_spec)
         MVF_BN_DISPATCH_MM(bn_bwd_apply_kernel, mask_mode, wide, 4096, (const ET*)g, g_pitch, (const ET*)z, (const ET*)ymask, m, c, gamma, mean, invstd, scale, shift,
                     dgamma, dbeta, mask_mode, (ET*)dz, p.cqb, p.rows);
@@ -1721,8 +1721,8 @@ int mvf_maxpool_bn_relu_fwd(const void* z, int n, int h, int w, int c, const flo
     MVF_REQUIRE(z && y && scale && shift && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, MVF_EINVAL, "maxpool_bn_relu_fwd: bad argument");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
     const long total = (long)n * ho * wo * (c / 4);
-    {   // [r3] 2 x 2 pooled outputs per thread, 16-byte channel groups (MVF_POOL_FWD_BLOCK=0: the element form)
-        static const int blk_on = getenv("MVF_POOL_FWD_BLOCK") ? atoi(getenv("MVF_POOL_FWD_BLOCK")) : 1;
+    {   // [r3] 2 x 2 pooled outputs per thread, 16-byte channel groups (policy pool_fwd_block=0: the element form)
+        static const int blk_on = mvf_policy_int("pool_fwd_block", 1);
         const int vc = dtype == MVF_F32 ? 4 : 8;
         if (blk_on && h % 4 == 0 && w % 4 == 0 && c % vc == 0 && ((uintptr_t)z | (uintptr_t)y) % 16 == 0 && (uintptr_t)argmax % 8 == 0) {
             const long tb = (long)n * (ho / 2) * (wo / 2) * (c / vc);
@@ -1764,7 +1764,7 @@ int mvf_maxpool_bn_relu_bwd(const unsigned char* argmax, const void* g, int n, i
 
 // the block form (maxpool_bn_bwd_blk_kernel): even image sides, 16-byte channel groups that divide 256 threads, 16-byte aligned tensors
 static bool pool_blk_ok(const void* amax, const void* g, const void* ga, const void* z, const void* dz, int h, int w, int c, int dtype) {
-    static const int on = getenv("MVF_POOL_BWD_BLOCK") ? atoi(getenv("MVF_POOL_BWD_BLOCK")) : 1;
+    static const int on = mvf_policy_int("pool_bwd_block", 1);
     const int vc = dtype == MVF_F32 ? 4 : 8;
     return on && h % 2 == 0 && w % 2 == 0 && c % vc == 0 && 256 % (c / vc) == 0 && c <= 256 && (uintptr_t)amax % 8 == 0 &&
            ((uintptr_t)g | (uintptr_t)(ga ? ga : g) | (uintptr_t)z | (uintptr_t)(dz ? dz : z)) % 16 == 0;

@@ -20,7 +20,7 @@
 // Arithmetic: the same bf16 products as the implicit GEMM, accumulated in fp32 in a different (band-major) order.
 // Measured (C3 shape, 256 frames of 56 x 56; kernel + slab reduce, tools/kbench.py wgrad16 l1.c2): 146 -> 90-94 us; in the training step the
 // weight-gradient group alone 3.42 -> 3.25 ms and the step 19.84 -> 19.81 ms (four alternations, every pair the same sign: it runs on the side
-// stream).  Ablations (-DMVF_WGRAD_ABLATE, MVF_WGRAD_ABL bits): matrix loop 27 us (= the matrix rate: 2.2 PF/s while it runs), staging 21,
+// stream).  Ablations (-DMVF_WGRAD_ABLATE, policy wgrad_abl bits): matrix loop 27 us (= the matrix rate: 2.2 PF/s while it runs), staging 21,
 // slab stores 8, the reduce of 512 slabs + two launches 21; they overlap little.  Measured without effect: a second fragment set (spills at 256
 // registers), the head of the next k-step fetched ahead, starting the second half of the grid late, 16-byte loads in the reduce; 256 workgroups
 // (one per CU, half the slabs) lose the second wave per SIMD: 110 us.
@@ -166,20 +166,20 @@ namespace mvf_internal {
 
 // output rows per band: 3 -> 61 KB of LDS per workgroup at W = 56 (two workgroups per CU: one stages while the other contracts); 4 -> 78 KB
 static int band_rows() {
-    static const int r = getenv("MVF_WGRAD3X3_R") ? atoi(getenv("MVF_WGRAD3X3_R")) : 3;
+    static const int r = mvf_policy_int("wgrad3x3_r", 3);
     return r == 4 ? 4 : 3;
 }
 
-// workgroups (= partial slabs) of a launch: two per CU (MVF_WGRAD3X3_WGS overrides), never more than bands
+// workgroups (= partial slabs) of a launch: two per CU (policy wgrad3x3_wgs overrides), never more than bands
 int wgrad3x3_c64_wgs(int n, int h) {
-    static const int env = getenv("MVF_WGRAD3X3_WGS") ? std::max(1, atoi(getenv("MVF_WGRAD3X3_WGS"))) : 512;
+    static const int env = std::max(1, mvf_policy_int("wgrad3x3_wgs", 512));
     const int kR = band_rows();
     const long bands = (long)n * ((h + kR - 1) / kR);
     return (int)std::min<long>(env, bands);
 }
 
 bool wgrad3x3_c64_ok(int n, int h, int w, int xps) {
-    static const bool on = !(getenv("MVF_WGRAD3X3_DIRECT") && getenv("MVF_WGRAD3X3_DIRECT")[0] == '0');
+    static const bool on = (mvf_policy_int("wgrad3x3_direct", 1) != 0);
     return on && w >= 4 && w <= 56 && h >= 1 && xps >= 64 && xps % 8 == 0 && (long)n * h * w * xps * 2 < 0x7ffffff0L;
 }
 
@@ -196,7 +196,7 @@ int wgrad3x3_c64_launch(const Wgrad3x3C64Args& w, hipStream_t st) {
     fd_make((unsigned)a.bands_per_frame, a.fd_bpf_mul, a.fd_bpf_shr);
     fd_make((unsigned)a.WP, a.fd_wp_mul, a.fd_wp_shr);
 #ifdef MVF_WGRAD_ABLATE
-    a.abl = getenv("MVF_WGRAD_ABL") ? atoi(getenv("MVF_WGRAD_ABL")) : 0;
+    a.abl = mvf_policy_int("wgrad_abl", 0);
 #endif
     const int lds = (a.xpix + a.dpix) * 128;
     static bool attr = false;

@@ -1058,12 +1058,12 @@ int launch_wgrad_bf16(const WgArgs& a, int tiles, int nsplit, hipStream_t st) {
     const size_t lds = (size_t)2 * BMR16 * (BCO * 2 + BK * 2);
     // LDS-DMA loaders by default where they measured faster (R50 bf16 train step, per layer): +6-15 % on the 3x3 and the wide
     // pointwise layers, -3-7 % on layer1's K = 64 pointwise convs and the stem (kept on the register-staged kernel); the MVF
-    // split operand cannot use them.  MVF_WGRAD_DMA=0 / 2 = never / wherever possible.  Weight gradients alone 5.23 -> 4.78 ms.
-    static const int dma_env = getenv("MVF_WGRAD_DMA") ? atoi(getenv("MVF_WGRAD_DMA")) : 1;
+    // split operand cannot use them.  policy wgrad_dma=0 / 2 = never / wherever possible.  Weight gradients alone 5.23 -> 4.78 ms.
+    static const int dma_env = mvf_policy_int("wgrad_dma", 1);
     const bool dma = dma_env && (a.split_c == 0 || (dma_env != 3 && a.split_c % BK == 0 && a.Cin % BK == 0)) &&
                      (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 2 < 0x7ffffff0L && (dma_env == 2 || (a.K >= 128 && a.Cin >= 32));
-    // [r6] MVF_WGRAD_STAGES: LDS-DMA ring depth of the four-wave tile (2 = the two-buffer kernel; default 3 = two chunks in flight; 4 measured the same)
-    static const int stages_env = getenv("MVF_WGRAD_STAGES") ? atoi(getenv("MVF_WGRAD_STAGES")) : 3;
+    // [r6] policy wgrad_stages: LDS-DMA ring depth of the four-wave tile (2 = the two-buffer kernel; default 3 = two chunks in flight; 4 measured the same)
+    static const int stages_env = mvf_policy_int("wgrad_stages", 3);
     if (dma && stages_env >= 3) {
         const size_t lds_p = (size_t)(stages_env >= 4 ? 4 : 3) * BMR16 * (BCO * 2 + BK * 2);
         auto k3 = wgrad_bf16_pipe_kernel<TM, TN, 3>;
@@ -1111,8 +1111,8 @@ int launch_wgrad_bf16_big(const WgArgs& a, int tiles, int nsplit, hipStream_t st
         MVF_HIP_OK(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_d = true;
     }
-    // the four-phase ping-pong loop carries the tile when a 64-column block lies inside one tap (MVF_WGRAD_P4=0: the two-barrier loop)
-    static const int p4_on = getenv("MVF_WGRAD_P4") ? atoi(getenv("MVF_WGRAD_P4")) : 1;
+    // the four-phase ping-pong loop carries the tile when a 64-column block lies inside one tap (policy wgrad_p4=0: the two-barrier loop)
+    static const int p4_on = mvf_policy_int("wgrad_p4", 1);
     if (p4_on && a.Cin % 64 == 0) {
         hipLaunchKernelGGL(kp, dim3(nsplit * tiles), dim3(512), lds, st, a);
         MVF_LAUNCH_CHECK();
@@ -1123,80 +1123,16 @@ int launch_wgrad_bf16_big(const WgArgs& a, int tiles, int nsplit, hipStream_t st
     return MVF_OK;
 }
 
-// dW_oihw[co][ci][kh][kw] = sum_s part[s][co][(kh*KWP + kw)*CINP + ci]   (KWP/CINP = packed extents; stem: 8 / 4)
-// [r4] EXPERIMENT, off (MVF_WGRAD_REDUCE4=1 turns it on, n > 1 forces n split-lanes).  In the profile of the overlapped bf16 step the reduce is the largest
-// single kernel (53 launches x 37.7 us = 2.0 ms: 1.7 TB/s over 3.4 GB of slabs), which reads like a slow kernel: 4-byte loads, four per
-// thread in flight.  This form gives a thread FOUR consecutive packed elements (16-byte loads, 1 KB of a slab row per wave instruction), four
-// independent accumulators over its share of the splits, and SL split-lanes per workgroup combined by a fixed LDS tree (host-chosen so that
-// a launch has >= 1024 workgroups even for layer1's 16 K-element gradients with 512 splits; deterministic, no atomics).  Measured: alone the
-// two forms take the same time (the slabs were written a moment ago and come from L2 / MALL: wgrad + reduce over the twelve C3 shapes 964.8 vs
-// 963.5 us) -- the 37.7 us are contention with the launch stream, not the access pattern -- and IN the step the wider loads take more from
-// the launch stream's kernels than they give back: 19.93 vs 20.02 ms (three alternations, every pair the same sign); fp32 52.75 vs 52.78.
-template <int SL>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
-                                                           float* dw) {
-    constexpr int Q = 256 / SL;                       // quads (4 elements) per workgroup
-    __shared__ float4 red[SL > 1 ? 256 : 1];
-    const long K = (long)kh * kwp * cinp;
-    const long total = (long)cout * K;
-    const int q = threadIdx.x % Q, sl = threadIdx.x / Q;
-    const long i = ((long)blockIdx.x * Q + q) * 4;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-    if (i < total) {
-        const float* p = part + i;
-        int k = sl;
-        for (; k + 3 * SL < nsplit; k += 4 * SL) {
-            const float4 v0 = *reinterpret_cast<const float4*>(p + (long)k * total);
-            const float4 v1 = *reinterpret_cast<const float4*>(p + (long)(k + SL) * total);
-            const float4 v2 = *reinterpret_cast<const float4*>(p + (long)(k + 2 * SL) * total);
-            const float4 v3 = *reinterpret_cast<const float4*>(p + (long)(k + 3 * SL) * total);
-            add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
-        }
-        for (; k < nsplit; k += SL) add(s0, *reinterpret_cast<const float4*>(p + (long)k * total));
-    }
-    add(s0, s1); add(s2, s3); add(s0, s2);
-    if constexpr (SL > 1) {
-        red[threadIdx.x] = s0;
-        __syncthreads();
-#pragma unroll
-        for (int w = SL / 2; w >= 1; w >>= 1) {
-            if (sl < w) {
-                float4 a = red[threadIdx.x];
-                add(a, red[threadIdx.x + w * Q]);
-                red[threadIdx.x] = a;
-            }
-            __syncthreads();
-        }
-        s0 = red[q];
-    }
-    if (sl != 0 || i >= total) return;
-    if (kh * kwp == 1 && cin == cinp) {               // pointwise: the packed layout IS the parameter's
-        *reinterpret_cast<float4*>(dw + i) = s0;
-        return;
-    }
-    const float v[4] = {s0.x, s0.y, s0.z, s0.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        long t = i + e;
-        const int ci = (int)(t % cinp); t /= cinp;
-        const int x = (int)(t % kwp); t /= kwp;
-        const int y = (int)(t % kh);
-        const int co = (int)(t / kh);
-        if (ci < cin && x < kw) dw[(((long)co * cin + ci) * kh + y) * kw + x] = v[e];
-    }
-}
-// the default form (one element per thread, four split-lanes)
+// dW_oihw[co][ci][kh][kw] = sum_s part[s][co][(kh*KWP + kw)*CINP + ci]   (KWP/CINP = packed extents; stem: 8 / 4): one element per thread, four split-lanes
+// combined by a fixed LDS tree (deterministic, no atomics).  ([r4] a 16-byte-load form measured the same alone -- the slabs come from L2 / MALL -- and
+// slower in the step, where its wider loads took more from the launch stream's kernels than they gave back: removed in round 6.)
 __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp,
                                     float* dw) {
     __shared__ float red[4][64];
     const long K = (long)kh * kwp * cinp;
     const long total = (long)cout * K;
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long nblk = (total + 63) / 64;
-    for (long bid = blockIdx.x; bid < nblk; bid += gridDim.x) {        // ([r5] a capped grid walks the blocks: MVF_WGRAD_REDUCE_WGS)
-    if (bid != (long)blockIdx.x) __syncthreads();
-    const long i = bid * 64 + e;
+    const long i = (long)blockIdx.x * 64 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < total) {
         int k = sl;
@@ -1218,33 +1154,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* part, i
         const int co = (int)(t / kh);
         if (ci < cin && x < kw) dw[(((long)co * cin + ci) * kh + y) * kw + x] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
-    }
 }
 int launch_wgrad_reduce(const float* part, int nsplit, int cout, int cin, int kh, int kw, int kwp, int cinp, float* dw, hipStream_t st) {
-    static const int r4 = getenv("MVF_WGRAD_REDUCE4") ? atoi(getenv("MVF_WGRAD_REDUCE4")) : 0;
     const long total = (long)cout * kh * kwp * cinp;
-    if (!r4 || total % 4 || ((uintptr_t)part | (uintptr_t)dw) % 16) {
-        static const int cap = getenv("MVF_WGRAD_REDUCE_WGS") ? atoi(getenv("MVF_WGRAD_REDUCE_WGS")) : 0;      // [r5] A/B: at most this many workgroups (0 = one per 64 elements)
-        const long nblk = (total + 63) / 64;
-        hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((int)(cap > 0 ? std::min<long>(nblk, cap) : nblk)), dim3(256), 0, st, part, nsplit, cout, cin, kh, kw, kwp, cinp, dw);
-        MVF_LAUNCH_CHECK();
-        return MVF_OK;
-    }
-    const long quads = total / 4;
-    int sl = 1;                                        // split-lanes: >= 1024 workgroups, at least two splits per lane
-    while (sl < 32 && quads * sl / 256 < 1024 && 4 * sl <= nsplit) sl *= 2;
-    if (r4 > 1) sl = std::min(32, r4);                 // (A/B: MVF_WGRAD_REDUCE4=2 / 4 / ... forces the lane count)
-    const int blocks = (int)((quads * sl + 255) / 256);
-#define MVF_RED(SLV) hipLaunchKernelGGL(wgrad_reduce_kernel<SLV>, dim3(blocks), dim3(256), 0, st, part, nsplit, cout, cin, kh, kw, kwp, cinp, dw)
-    switch (sl) {
-        case 1: MVF_RED(1); break;
-        case 2: MVF_RED(2); break;
-        case 4: MVF_RED(4); break;
-        case 8: MVF_RED(8); break;
-        case 16: MVF_RED(16); break;
-        default: MVF_RED(32); break;
-    }
-#undef MVF_RED
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((int)((total + 63) / 64)), dim3(256), 0, st, part, nsplit, cout, cin, kh, kw, kwp, cinp, dw);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -1334,7 +1247,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const mvf_pack_job_t*
 }
 
 int plan_split(int M, int tiles, int target_override = 0) {
-    static const int target_env = getenv("MVF_WGRAD_WGS") ? std::max(64, atoi(getenv("MVF_WGRAD_WGS"))) : 1024;     // workgroups aimed at per launch (A/B switch)
+    static const int target_env = std::max(64, mvf_policy_int("wgrad_wgs", 1024));     // workgroups aimed at per launch (A/B switch)
     const int target = target_override > 0 ? target_override : target_env;
     int want = std::max(1, target / std::max(tiles, 1));
     int rows = std::max((M + want - 1) / want, 256);
@@ -1364,12 +1277,12 @@ extern "C" {
 // the 256 x 256 eight-wave tile (bf16, LDS-DMA): shape eligibility (pointer alignment is checked at launch) and its pixel split --
 // ~256 workgroups (one per CU), i.e. the same number of splits as the 128 x 128 plan's ~1024
 static bool wg_big_shape(const mvf_conv_desc_t* d) {
-    // MVF_WGRAD_BIG: 0 never, 1 (default) every eligible shape, 2 pointwise convs only, 3 pointwise convs with cout >= 512.
+    // policy wgrad_big: 0 never, 1 (default) every eligible shape, 2 pointwise convs only, 3 pointwise convs with cout >= 512.
     // Measured on the R50 bf16 train step, two alternations: weight gradients ALONE 5.23 (0) / 5.17 (1) / 5.13 (2) / 5.13 (3) ms -- the
     // tile wins -10...-18 % on the wide pointwise layers and loses 5-10 % on the 3x3 ones --, but the STEP is 22.24 / 22.16 / 22.37 /
     // 22.39 ms: one 8-wave workgroup per CU (252 of them for a 3x3 layer) leaves the launch stream's kernels more of the chip than
     // 1008 four-wave workgroups do.
-    static const int big_env = getenv("MVF_WGRAD_BIG") ? atoi(getenv("MVF_WGRAD_BIG")) : 1;
+    static const int big_env = mvf_policy_int("wgrad_big", 1);
     const long K = (long)d->kh * d->kw * d->cin;
     if (big_env >= 2 && (d->kh != 1 || d->kw != 1)) return false;
     if (big_env >= 3 && d->cout < 512) return false;
@@ -1382,17 +1295,17 @@ static int wg_big_rows(const mvf_conv_desc_t* d, int wgs_override = 0) {
     // work-conservingly -- what the weight gradients cost the step is their FOOTPRINT (a 256 x 256 workgroup owns its CU's whole register file), not their own
     // length.  Measured in the step (alternating runs; ms, C3 / C4): 256 workgroups 19.20 / 33.08, 192: 18.95 / 32.72, 128: 18.88 / 32.36 on one box; 128: 18.34 / 31.45,
     // 96: 18.35 / 31.91, 64: 18.50 / 32.38 on another.  (Round 2 measured 128 = 256 on a step whose launch stream still carried 7 ms of BatchNorm passes.)
-    static const int big_wgs = getenv("MVF_WGRAD_BIG_WGS") ? std::max(32, atoi(getenv("MVF_WGRAD_BIG_WGS"))) : 128;      // A/B switch
+    static const int big_wgs = std::max(32, mvf_policy_int("wgrad_big_wgs", 128));      // A/B switch
     return plan_split(M, (d->cout / 256) * (K / 256), wgs_override > 0 ? wgs_override : big_wgs);
 }
 
-// [r4] layer1's 3x3 (64 -> 64 channels, stride 1, pad 1, bf16) on the direct kernel of wgrad3x3_c64.hip (MVF_WGRAD3X3_DIRECT=0: the implicit GEMM)
+// [r4] layer1's 3x3 (64 -> 64 channels, stride 1, pad 1, bf16) on the direct kernel of wgrad3x3_c64.hip (policy wgrad3x3_direct=0: the implicit GEMM)
 static bool wg_direct3x3(const mvf_conv_desc_t* d) {
     return d->dtype == MVF_BF16 && d->cin == 64 && d->cout == 64 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->split_c == 0 &&
            d->ho == d->h && d->wo == d->w && mvf_internal::wgrad3x3_c64_ok(d->n, d->h, d->w, d->x_pix_stride);
 }
 
-// [r4] the stem (7 x 1 taps over the 32-"channel" view of the padded NHWC4 operand, stride 2, bf16) on the direct kernel of wgrad_stem.hip (MVF_WGRAD_STEM_DIRECT=0: the implicit GEMM)
+// [r4] the stem (7 x 1 taps over the 32-"channel" view of the padded NHWC4 operand, stride 2, bf16) on the direct kernel of wgrad_stem.hip (policy wgrad_stem_direct=0: the implicit GEMM)
 static bool wg_direct_stem(const mvf_conv_desc_t* d) {
     return d->dtype == MVF_BF16 && d->cin == 32 && d->cout == 64 && d->kh == 7 && d->kw == 1 && d->stride == 2 && d->pad == 0 && d->split_c == 0 &&
            d->x_pix_stride == 4 && mvf_internal::wgrad_stem_ok(d->n, d->h, d->w, d->ho, d->wo);
@@ -1415,15 +1328,14 @@ size_t mvf_conv2d_wgrad_workspace_bytes(const mvf_conv_desc_t* d) {
 // kw_real/cin_real < packed extents only for the stem view (kh x 1 x 32 over the padded NHWC4 input = 7 x 8 x 4).
 }  // extern "C"
 static int wgrad_impl(const mvf_conv_desc_t* d, const void* dz, const void* x, const void* x2, int kw_real, int cin_real,
-                      int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, void* stream, int wgs_target, int* nslabs_out = nullptr) {
-    MVF_REQUIRE(d && dz && x && (dw_oihw || nslabs_out), MVF_EINVAL, "wgrad: NULL argument");
+                      int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, void* stream, int wgs_target) {
+    MVF_REQUIRE(d && dz && x && dw_oihw, MVF_EINVAL, "wgrad: NULL argument");
     MVF_REQUIRE(d->dtype == MVF_F32 || d->dtype == MVF_BF16, MVF_EINVAL, "wgrad: bad dtype");
     MVF_REQUIRE(d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride > 0, MVF_ESHAPE, "wgrad: cin/cout must be multiples of 4");
     MVF_REQUIRE(kw_packed * cin_packed == d->kw * d->cin && kw_real <= kw_packed && cin_real <= cin_packed, MVF_EINVAL, "wgrad: packed extents inconsistent");
     MVF_REQUIRE(ws && ws_bytes >= mvf_conv2d_wgrad_workspace_bytes(d), MVF_EWS, "wgrad: workspace too small");
     if (d->split_c) MVF_REQUIRE(x2 && d->kh == 1 && d->kw == 1 && d->split_c % 4 == 0, MVF_EINVAL, "wgrad: bad split_c");
     hipStream_t st0 = (hipStream_t)stream;
-    if (nslabs_out) MVF_REQUIRE(d->kh == 1 && d->kw == 1 && kw_real == kw_packed && cin_real == cin_packed, MVF_EINVAL, "wgrad_slabs: pointwise convs with unpadded packs only");
     if (wg_direct3x3(d) && kw_real == 3 && cin_real == 64 && kw_packed == 3 && cin_packed == 64 && ((uintptr_t)dz | (uintptr_t)x) % 16 == 0) {
         Wgrad3x3C64Args w = {dz, x, (float*)ws, d->n, d->h, d->w, d->x_pix_stride, mvf_internal::wgrad3x3_c64_wgs(d->n, d->h)};
         const int rc = mvf_internal::wgrad3x3_c64_launch(w, st0);
@@ -1445,15 +1357,15 @@ static int wgrad_impl(const mvf_conv_desc_t* d, const void* dz, const void* x, c
     WgTile t = pick_tile(d->cout, a.K);
     // [r5] a Gram matrix (dz == x: a^T a of ONE tensor, the dz3-free BatchNorm backward's A2, bn_dzfree.hip): its output is a single small tile, so the usual
     // plan -- one workgroup per CU -- spends 256 x 256 KB of fp32 slabs (written, then read by the reduce) on a 256 KB result: 128 MB of traffic per call, 2.4 GB per
-    // C3 step.  It runs on the side stream with slack, so it takes MVF_GRAM_WGS (default 32) workgroups instead: an eighth of the slabs and of the CUs.  Measured in the
+    // C3 step.  It runs on the side stream with slack, so it takes policy gram_wgs (default 32) workgroups instead: an eighth of the slabs and of the CUs.  Measured in the
     // step (alternating runs; ms, C3 / C4): 256 workgroups 18.64 / 32.2, 128: 18.68 / 32.45, 64: 18.75 / 32.6, 32: 18.59 / 31.8 on one box; 32: 19.10 / 33.08, 24: 19.08 /
     // 33.1, 16: 19.16 / 33.3, 8: 19.30 / 33.6 on another.
-    static const int gram_env = getenv("MVF_GRAM_WGS") ? std::max(8, atoi(getenv("MVF_GRAM_WGS"))) : 32;
+    static const int gram_env = std::max(8, mvf_policy_int("gram_wgs", 32));
     // (wgs_target > 0, mvf_conv2d_nhwc_wgrad_wgs: the caller names the workgroup count to aim at -- a GEMM the LAUNCH stream waits for wants the whole chip)
     const int gram_wgs = wgs_target > 0 ? wgs_target : (dz == x && !x2 && d->kh == 1 && d->kw == 1 && d->cin == d->cout) ? gram_env : 0;
     // 256 x 256 tile: the shapes of wg_big_shape() when the LDS-DMA address ranges and alignments hold and every split has >= 4 chunks
-    static const int tgt_big = getenv("MVF_WGRAD_WGS_BIG") ? atoi(getenv("MVF_WGRAD_WGS_BIG")) : 0;      // A/B: 0 = a caller-named workgroup count takes the 128 x 128 plans
-    bool big = wg_big_shape(d) && (wgs_target <= 0 || tgt_big) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
+    // (a caller-named workgroup count takes the 128 x 128 plans)
+    bool big = wg_big_shape(d) && wgs_target <= 0 && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
                (long)a.N * a.H * a.W * std::max(a.xps, a.x2ps) * 2 < 0x7ffffff0L;
     if (big) {
         const int rows = wg_big_rows(d, gram_wgs);
@@ -1462,13 +1374,13 @@ static int wgrad_impl(const mvf_conv_desc_t* d, const void* dz, const void* x, c
     }
     a.tiles_k = (a.K + t.bk - 1) / t.bk;
     const int tiles = ((d->cout + t.bco - 1) / t.bco) * a.tiles_k;
-    // [r4] fp32 storage on the bf16 matrix cores (wgrad_x3_kernel): on with the conv kernels' switch (MVF_F32_X3 != 0) unless MVF_WGRAD_X3=0.
+    // [r4] fp32 storage on the bf16 matrix cores (wgrad_x3_kernel): on with the conv kernels' switch (policy f32_x3 != 0) unless policy wgrad_x3=0.
     // Three workgroups per CU = 768 slots: the pixel split aims at one full round of them (1024 / 1536 / 2304: 3185 / 3218 / 3308 us over the
-    // twelve C3 shapes against 3115), unless MVF_WGRAD_WGS says otherwise
-    static const int x3_env = (getenv("MVF_F32_X3") ? atoi(getenv("MVF_F32_X3")) != 0 : 1) && (getenv("MVF_WGRAD_X3") ? atoi(getenv("MVF_WGRAD_X3")) != 0 : 1);
+    // twelve C3 shapes against 3115), unless policy wgrad_wgs says otherwise
+    static const int x3_env = (mvf_policy_int("f32_x3", 1) != 0) && (mvf_policy_int("wgrad_x3", 1) != 0);
     bool x3 = d->dtype == MVF_F32 && x3_env && d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride % 4 == 0 && d->split_c % 4 == 0 &&
               (d->x2_pix_stride % 4 == 0 || !d->split_c) && ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0;
-    static const bool wgs_forced = getenv("MVF_WGRAD_WGS") != nullptr;
+    static const bool wgs_forced = mvf_policy_has("wgrad_wgs");
     // [r5] bf16 128 x 128 plans aim at 256 workgroups instead of 1024 for the same reason (with the big tile at 128; ms, C3 / C4: 1024: 18.34 / 31.45, 512: 18.20 / 31.29,
     // 384: 18.21 / 31.23, 256: 18.15 / 31.30)
     const int bf16_wgs = (d->dtype == MVF_BF16 && !wgs_forced) ? 256 : 0;
@@ -1479,17 +1391,16 @@ static int wgrad_impl(const mvf_conv_desc_t* d, const void* dz, const void* x, c
     MVF_REQUIRE(ws_bytes >= (size_t)nsplit * d->cout * a.K * sizeof(float), MVF_EWS, "wgrad: workspace too small for %d slabs", nsplit);
     a.tiles = tiles;
     a.nsplit = nsplit;
-    static const int map_env = getenv("MVF_WGRAD_MAP") ? atoi(getenv("MVF_WGRAD_MAP")) : -1;      // A/B: 0 balanced ranges everywhere, 1 round-robin wherever legal
-    a.xcd_rr = (nsplit % 8 == 0) && map_env != 0;
+    a.xcd_rr = nsplit % 8 == 0;
 #ifdef MVF_WGRAD_ABLATE
-    a.abl = getenv("MVF_WGRAD_ABL") ? atoi(getenv("MVF_WGRAD_ABL")) : 0;
+    a.abl = mvf_policy_int("wgrad_abl", 0);
 #endif
     wg_fd_make((unsigned)(a.Ho * a.Wo), a.fd_hw_mul, a.fd_hw_shr);
     wg_fd_make((unsigned)a.Wo, a.fd_w_mul, a.fd_w_shr);
     hipStream_t st = (hipStream_t)stream;
     // fp32 storage: LDS-DMA loaders by default (weight gradients 25.3 -> 21.8 ms per R50 step = 82 -> 96 TF/s, fp32 step 75.9 ->
-    // 73.8 ms); MVF_WGRAD_DMA_F32=0 restores the register-staged loaders
-    static const int dma32_env = getenv("MVF_WGRAD_DMA_F32") ? atoi(getenv("MVF_WGRAD_DMA_F32")) : 1;
+    // 73.8 ms); policy wgrad_dma_f32=0 restores the register-staged loaders
+    static const int dma32_env = mvf_policy_int("wgrad_dma_f32", 1);
     const bool dma32 = d->dtype == MVF_F32 && dma32_env && d->cin % 4 == 0 && d->cout % 4 == 0 && d->x_pix_stride % 4 == 0 &&
                        (a.split_c == 0 || (a.split_c % t.bk == 0 && a.Cin % t.bk == 0)) &&
                        ((uintptr_t)dz | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) % 16 == 0 &&
@@ -1521,10 +1432,6 @@ static int wgrad_impl(const mvf_conv_desc_t* d, const void* dz, const void* x, c
         else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 2>), dim3(nsplit * tiles), dim3(kThreads), 0, st, a);
     }
     MVF_LAUNCH_CHECK();
-    if (nslabs_out) {          // the caller sums the slabs itself (ws: [nsplit][cout][cin] fp32)
-        *nslabs_out = nsplit;
-        return MVF_OK;
-    }
     const int kh_p = d->kh * d->kw * d->cin / (kw_packed * cin_packed);
     return launch_wgrad_reduce(a.part, nsplit, d->cout, cin_real, kh_p, kw_real, kw_packed, cin_packed, dw_oihw, st);
 }
@@ -1541,14 +1448,6 @@ int mvf_conv2d_nhwc_wgrad_wgs(const mvf_conv_desc_t* d, const void* dz, const vo
                               int kw_packed, int cin_packed, float* dw_oihw, void* ws, size_t ws_bytes, int wgs, void* stream) {
     MVF_REQUIRE(wgs >= 8 && wgs <= 4096, MVF_EINVAL, "wgrad_wgs: wgs=%d outside 8 .. 4096", wgs);
     return wgrad_impl(d, dz, x, x2, kw_real, cin_real, kw_packed, cin_packed, dw_oihw, ws, ws_bytes, stream, wgs);
-}
-
-// [r5] ... without the slab reduce: ws holds nslabs partial results [nslabs][cout][cin] (fp32, in pixel-range order) for a consumer that sums them itself
-// (mvf_bn_bwd_dzfree_sums: one launch less on the launch stream).  Pointwise convs only.
-int mvf_conv2d_nhwc_wgrad_slabs(const mvf_conv_desc_t* d, const void* dz, const void* x, void* ws, size_t ws_bytes, int wgs, int* nslabs, void* stream) {
-    MVF_REQUIRE(nslabs && wgs >= 8 && wgs <= 4096, MVF_EINVAL, "wgrad_slabs: nslabs is NULL or wgs=%d outside 8 .. 4096", wgs);
-    MVF_REQUIRE(d && d->split_c == 0, MVF_EINVAL, "wgrad_slabs: no split operand");
-    return wgrad_impl(d, dz, x, nullptr, 1, d->cin, 1, d->cin, nullptr, ws, ws_bytes, stream, wgs, nslabs);
 }
 
 int mvf_pack_conv_weights_batched(const mvf_pack_job_t* jobs_dev, int njobs, int total_blocks, int dtype, void* stream) {

@@ -142,7 +142,7 @@ inline void fd_make(unsigned d, unsigned& mul, unsigned& shr) {
 
 // output rows per band: 2 -> 46 KB of LDS per workgroup at the 224^2 shape (three workgroups per CU: two stage while one contracts); 1 -> 27 KB
 static int band_rows() {
-    static const int r = getenv("MVF_WGRAD_STEM_R") ? atoi(getenv("MVF_WGRAD_STEM_R")) : 2;
+    static const int r = mvf_policy_int("wgrad_stem_r", 2);
     return r == 1 ? 1 : 2;
 }
 
@@ -152,15 +152,15 @@ namespace mvf_internal {
 
 // the stem view (7 x 1 taps over 32 "channels" of the padded NHWC4 operand, stride 2) at sizes the band walk covers
 bool wgrad_stem_ok(int n, int h, int w, int ho, int wo) {
-    static const bool on = !(getenv("MVF_WGRAD_STEM_DIRECT") && getenv("MVF_WGRAD_STEM_DIRECT")[0] == '0');
+    static const bool on = (mvf_policy_int("wgrad_stem_direct", 1) != 0);
     return on && n > 0 && wo >= 16 && wo % 16 == 0 && ho % 2 == 0 && (w * 8) % 16 == 0 && 2 * (ho - 1) + 6 < h && 2 * (wo - 1) + 7 < w &&
            (long)n * h * w * 8 < 0x7ffffff0L && (long)n * ho * wo * 128 < 0x7ffffff0L &&
            (2 * 2 + 5) * w * 8 + 1024 + 2 * wo * 128 <= 72 * 1024;
 }
 
-// workgroups (= partial slabs) of a launch: three per CU (MVF_WGRAD_STEM_WGS overrides), never more than bands
+// workgroups (= partial slabs) of a launch: three per CU (policy wgrad_stem_wgs overrides), never more than bands
 int wgrad_stem_wgs(int n, int ho) {
-    static const int env = getenv("MVF_WGRAD_STEM_WGS") ? std::max(1, atoi(getenv("MVF_WGRAD_STEM_WGS"))) : 768;      // measured at the C3 shape: 256 / 512 / 768 / 1024 workgroups 235 / 163 / 143 / 175 us
+    static const int env = std::max(1, mvf_policy_int("wgrad_stem_wgs", 768));      // measured at the C3 shape: 256 / 512 / 768 / 1024 workgroups 235 / 163 / 143 / 175 us
     return (int)std::min<long>(env, (long)n * (ho / band_rows()));
 }
 

@@ -35,8 +35,9 @@ _SK_WS = {}
 # MVF computed INSIDE conv1's A-operand loader (mvf_conv2d_nhwc_fwd_mvf: one launch, no slice buffer) instead of the stencil kernel +
 # split-A conv.  Parity-tested (tests/test_conv_gpu.py, tests/test_net_gpu.py), but measured 3-5 % SLOWER end to end on MI355X (bf16
 # inference 7090-7270 vs 7480 clips/s, fp32 1622-1656 vs 1672): every n-tile of the conv recomputes the stencil of its rows (2-4x
-# redundant VALU + loads) and the loader's extra registers cost a workgroup per CU -- so it is opt-in (MVF_FUSE_LOADER=1).
-FUSE_MVF_LOADER = __import__("os").environ.get("MVF_FUSE_LOADER", "0") == "1"
+# redundant VALU + loads) and the loader's extra registers cost a workgroup per CU -- so it is opt-in (MVF_POLICY=fuse_loader=1).
+from .policy import policy as _policy      # noqa: E402
+FUSE_MVF_LOADER = _policy("fuse_loader", 0) == 1
 
 
 def _sk_workspace(device):

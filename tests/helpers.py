@@ -15,6 +15,44 @@ def golden(name):
     return _cache[name]
 
 
+def policy_str(base=None, **kv):
+    """MVF_POLICY value: `base` (default: the current environment's) with the given switches overriding -- for child processes and for the
+    library's per-call switches (csrc/common.h mvf_policy_int re-reads the variable where a test flips a switch inside one process)."""
+    import os
+    cur = {}
+    for item in (os.environ.get("MVF_POLICY", "") if base is None else base).replace(";", ",").split(","):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            cur[k.strip().lower()] = v.strip()
+    cur.update({k: str(v) for k, v in kv.items()})
+    return ",".join("%s=%s" % kv_ for kv_ in cur.items())
+
+
+def policy_env(**kv):
+    """os.environ + MVF_POLICY with the given switches (child processes)."""
+    import os
+    return dict(os.environ, MVF_POLICY=policy_str(**kv))
+
+
+class policy_set(object):
+    """with policy_set(conv3x3_direct=0): ... -- the library's per-call switches inside this process."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("MVF_POLICY")
+        os.environ["MVF_POLICY"] = policy_str(**self.kv)
+
+    def __exit__(self, *a):
+        import os
+        if self.old is None:
+            os.environ.pop("MVF_POLICY", None)
+        else:
+            os.environ["MVF_POLICY"] = self.old
+
+
 def rel_err(a, ref):
     """max|a-ref| / max|ref| -- tolerances are relative to each tensor's scale."""
     a = np.asarray(a, dtype=np.float64)

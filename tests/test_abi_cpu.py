@@ -43,7 +43,7 @@ def test_stencil_partial_row_plan_follows_the_kernel_choice():
     """[r5] mvf_nhwc_stencil_stats_rows names the partial rows of the launch that WILL run (no launch, no GPU): the LDS-tiled bf16 kernel
     (clips x bands of rows) where its plan exists and makes >= 150 workgroups, the register-chunked kernel's (clips x pixel bands) otherwise."""
     import os
-    if os.environ.get("MVF_STENCIL_LDS", "1") == "0" or os.environ.get("MVF_STENCIL_LDS_MINWG"):
+    if "stencil_lds" in os.environ.get("MVF_POLICY", ""):
         pytest.skip("the plan switches are set in the environment")
     from mvfnet_amd import _lib
     L = _lib

@@ -363,7 +363,11 @@ def test_full_size_bf16_train_step_properties(cfg):
     # statistics of the z3-free blocks from the Gram matrix of a2 (eng.gram_stats) a re-ordering moves those statistics by ONE fp32 ulp (5e-8: measured at full
     # size, profiles/r05_gram_stats.txt; they are at fp32 epsilon against fp64) where the pass they replace, which reduces its partial rows in double, did not
     # move at all -- and the network amplifies that ulp like any other perturbation: median 1.8e-2, max 0.29 on C3 (5.9e-3 / 0.086 with MVF_GRAM_STATS=0)
-    assert np.median(rel) < (4e-2 if depth == 50 else 6e-2) and rel.max() < 0.5
+    # [r6] bounds per layer group, 2-3 x what two boxes measured (R50: medians 8e-3 ... 2.1e-2 per stage, head 1e-5, max 0.32; R101: 1.4e-2 ... 3.0e-2, stem's three
+    # parameters 7e-2, head 9e-5, max 0.27): one layer's gradients off by 10 % now move its group's median out of bounds
+    assert np.median(rel) < (3e-2 if depth == 50 else 5e-2) and rel.max() < 0.45
+    for k, (med, mx, cnt) in table.items():
+        assert med < (1e-3 if k == "head" else (0.2 if k == "stem" else 6e-2)), (k, med, mx, cnt)
     eng.step()
     l4 = eng.forward(imgs[perm].contiguous(), labels[perm].contiguous())
     assert float(l4) < float(l3)

@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import rel_err
+from helpers import policy_env, policy_set, policy_str, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -145,7 +145,7 @@ def test_stem_maxpool_head_ops_vs_oracle():
 @pytest.mark.parametrize("shape", [(3, 56, 56, 64), (5, 56, 56, 128), (2, 64, 64, 64), (3, 16, 16, 64), (4, 8, 8, 64)], ids=lambda s: "n%d_%dx%d_pitch%d" % s)
 def test_conv3x3_c64_direct_vs_oracle_and_the_implicit_gemm(shape):
     """[r3] layer1's 3x3 (resnet.py:213-224 conv2 at planes = 64) and its data gradient run on a direct kernel (csrc/conv3x3_c64.hip: padded
-    window staged once per row band, the wave's weights in registers); MVF_CONV3X3_DIRECT=0 sends the same calls to the implicit-GEMM kernel.
+    window staged once per row band, the wave's weights in registers); MVF_POLICY=conv3x3_direct=0 sends the same calls to the implicit-GEMM kernel.
     Every epilogue (statistics, plain, bias + ReLU, data gradient + BatchNorm-backward sums) against torch on the bf16-rounded operands and
     against the other kernel; a pixel pitch wider than the 64 channels read (the input as a slice of a wider tensor)."""
     import os
@@ -172,9 +172,8 @@ def test_conv3x3_c64_direct_vs_oracle_and_the_implicit_gemm(shape):
     sc, sh = (torch.randn(64, generator=g)).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()
     m = n * h * w
 
-    def run(direct):
-        os.environ["MVF_CONV3X3_DIRECT"] = "1" if direct else "0"
-        try:
+    def run(direct, **more):
+        with policy_set(conv3x3_direct=1 if direct else 0, **more):
             d = _lib.ConvDesc(n, h, w, 64, 64, 3, 3, 1, 1, h, w, pitch, 1, 0, 0, 0, 0, 0)
             rows = lib.mvf_conv2d_stats_rows(C.byref(d))
             new = lambda: torch.full((m, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
@@ -188,16 +187,10 @@ def test_conv3x3_c64_direct_vs_oracle_and_the_implicit_gemm(shape):
             check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(xw), None, P(wpk), P(bias), None, P(y4), None, 0, None))
             torch.cuda.synchronize()
             return z, part.double().sum(1), y2, y4, dx, sums.double().sum(1)
-        finally:
-            os.environ.pop("MVF_CONV3X3_DIRECT", None)
 
     r1, r0 = run(True), run(False)
     # workgroups whose band ranges straddle frames (5 bands each; a frame has h / 4 or h / 8): same outputs bit for bit, sums to summation order
-    os.environ["MVF_CONV3X3_BPW"] = "5"
-    try:
-        r5 = run(True)
-    finally:
-        os.environ.pop("MVF_CONV3X3_BPW", None)
+    r5 = run(True, conv3x3_bpw=5)
     for a_, b_ in zip((r5[0], r5[2], r5[3], r5[4]), (r1[0], r1[2], r1[3], r1[4])):
         assert torch.equal(a_, b_)
     assert rel_err(r5[1].cpu().numpy(), r1[1].cpu().numpy()) < 1e-5 and rel_err(r5[5].cpu().numpy(), r1[5].cpu().numpy()) < 1e-5
@@ -266,7 +259,7 @@ def test_conv3x3_c64_direct_full_c3_size_oracle_rows():
 @pytest.mark.parametrize("shape", [(3, 64, 64), (2, 32, 32), (1, 48, 80), (2, 224, 224)], ids=lambda s: "n%d_%dx%d" % s)
 def test_stem_direct_conv_vs_oracle_and_the_implicit_gemm(shape):
     """[r3] The bf16 stem (resnet.py:420-431 conv1) runs on its own direct kernel (csrc/stem_direct.hip: input patch staged once, weights in
-    registers); MVF_STEM_DIRECT=0 sends the same call to the implicit-GEMM kernel.  Both against F.conv2d on the bf16-rounded operands; the
+    registers); MVF_POLICY=stem_direct=0 sends the same call to the implicit-GEMM kernel.  Both against F.conv2d on the bf16-rounded operands; the
     two kernels against each other (same products, same k order: outputs within one bf16 rounding of the fp32 sum, statistics of the stored
     values to summation order).  (1, 48, 80) has no whole statistic rows per row band: the training epilogue falls back, the inference one does not."""
     import os
@@ -289,9 +282,8 @@ def test_stem_direct_conv_vs_oracle_and_the_implicit_gemm(shape):
     ref = F.conv2d(x.bfloat16().float(), wt.bfloat16().float(), stride=2, padding=3)          # fp32 sums of the bf16 products
     m = n * ho * wo
 
-    def run(direct):
-        os.environ["MVF_STEM_DIRECT"] = "1" if direct else "0"
-        try:
+    def run(direct, **more):
+        with policy_set(stem_direct=1 if direct else 0, **more):
             d = _lib.ConvDesc(n, hp, wp, 32, 64, 7, 1, 2, 0, ho, wo, 4, 1, 0, 0, 0, 0, 0)
             rows = lib.mvf_conv2d_stats_rows(C.byref(d))
             z = torch.full((m, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
@@ -302,16 +294,10 @@ def test_stem_direct_conv_vs_oracle_and_the_implicit_gemm(shape):
             check(lib.mvf_conv2d_nhwc_fwd_ws(C.byref(d), P(xp), None, P(wpk), P(bias), None, P(y), None, 0, None))
             torch.cuda.synchronize()
             return z, part.double().sum(1), y
-        finally:
-            os.environ.pop("MVF_STEM_DIRECT", None)
 
     z1, st1, y1 = run(True)
     z0, st0, y0 = run(False)
-    os.environ["MVF_STEM_TPW"] = "3"                  # workgroups that walk 3 tiles (ranges straddle frames): same outputs, sums to summation order
-    try:
-        z3, st3, y3 = run(True)
-    finally:
-        os.environ.pop("MVF_STEM_TPW", None)
+    z3, st3, y3 = run(True, stem_tpw=3)          # workgroups that walk 3 tiles (ranges straddle frames): same outputs, sums to summation order
     assert torch.equal(z3, z1) and torch.equal(y3, y1) and rel_err(st3.cpu().numpy(), st1.cpu().numpy()) < 1e-5
     nchw = lambda t: t.float().cpu().reshape(n, ho, wo, 64).permute(0, 3, 1, 2).numpy()
     for z, st, y in ((z1, st1, y1), (z0, st0, y0)):
@@ -367,8 +353,8 @@ def test_conv_streamk_tail_matches_plain_launch_and_oracle(case, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["MVF_CONV_GLDS=0", "MVF_CONV_GLDS=1,1", "MVF_CONV_GLDS=1,2", "MVF_CONV_BIG=1", "MVF_CONV_BIG2=1,MVF_CONV_BIG2_FORCE=1",
-                                 "MVF_CONV_BIG2=1,MVF_CONV_BIG2_FORCE=1,MVF_CONV_P4=0", "MVF_STEM_DIRECT=0,MVF_CONV3X3_DIRECT=0"],
+@pytest.mark.parametrize("env", ["conv_glds=0", "conv_glds=1,conv_glds_nb=1", "conv_glds=1,conv_glds_nb=2", "conv_big=1", "conv_big2=1,conv_big2_force=1",
+                                 "conv_big2=1,conv_big2_force=1,conv_p4=0", "stem_direct=0,conv3x3_direct=0"],
                          ids=["register_staged_only", "lds_dma_1buf_everywhere", "lds_dma_2buf_everywhere", "tile_256x128_everywhere",
                               "tile_256x256_four_phase_everywhere", "tile_256x256_two_barrier_everywhere", "no_direct_stem_or_layer1_3x3"])
 def test_conv_kernel_variants_forced_by_env(env):
@@ -380,7 +366,7 @@ def test_conv_kernel_variants_forced_by_env(env):
     import os
     import subprocess
     import sys
-    child_env = dict(os.environ, **dict(kv.split("=") for kv in env.split(",MVF")[:1] + ["MVF" + x for x in env.split(",MVF")[1:]]))
+    child_env = dict(os.environ, MVF_POLICY=policy_str(**dict(kv.split("=") for kv in env.split(","))))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not forced_by_env",
                         "-p", "no:cacheprovider"], env=child_env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -514,7 +500,7 @@ def test_four_phase_loops_are_run_to_run_bit_identical_under_a_perturbing_stream
     import sys
     code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_conv_gpu as t; t._race_child()" % (
         os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVF_CONV_BIG2="1", MVF_CONV_BIG2_FORCE="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=policy_env(conv_big2=1, conv_big2_force=1), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "race screen ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -545,7 +531,7 @@ _X3_SHAPES = [(4, 14, 64, 256, 1), (2, 14, 1024, 256, 1), (2, 14, 256, 256, 3), 
 def test_fp32_conv_on_the_bf16_matrix_cores_is_as_accurate_as_the_fp32_mfma(tmp_path):
     """conv_tile X3 (the default fp32 path): every fp32 operand is split exactly into three bf16 terms and a product is the six partial
     products of order <= 2^-16 on v_mfma_f32_32x32x16_bf16.  Against an fp64 convolution of the same operands the error must be the fp32
-    ACCUMULATION error, i.e. no larger than what the exact-fp32 MFMA path (MVF_F32_X3=0, run in a child process: the switch is read once
+    ACCUMULATION error, i.e. no larger than what the exact-fp32 MFMA path (MVF_POLICY=f32_x3=0, run in a child process: the switch is read once
     per process) leaves -- K = 64 ... 4608, a ragged channel tail included -- and both far inside the 1e-5 every fp32 test allows."""
     import os
     import subprocess
@@ -554,8 +540,8 @@ def test_fp32_conv_on_the_bf16_matrix_cores_is_as_accurate_as_the_fp32_mfma(tmp_
     res = {}
     for tag, val in (("x3", "1"), ("mfma", "0")):
         f = str(tmp_path / (tag + ".npz"))
-        env = {k: v for k, v in os.environ.items() if not k.startswith("MVF_CONV_")}       # (a forced tile / loader policy of a parent test run would send both legs to one kernel)
-        env.update(MVF_F32_X3=val, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env = dict(os.environ, MVF_POLICY="f32_x3=%s" % val)       # (ONLY this switch: a forced tile / loader policy of a parent test run would send both legs to one kernel)
+        env.update(PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         r = subprocess.run([sys.executable, "-c", src, f], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = np.load(f)

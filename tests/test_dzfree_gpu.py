@@ -235,75 +235,9 @@ def test_stencil_with_fused_statistics_equals_stencil_plus_statistics_pass(case)
         assert torch.isfinite(a).all() and rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
 
 
-@pytest.mark.parametrize("case", [(2, 14, 14, 256, 1024, 128), (3, 7, 9, 128, 512, 0), (1, 28, 28, 64, 256, 64)], ids=str)
-def test_gated_data_gradient_with_fused_sums_equals_gate_then_sums_pass(case):
-    """[r5] mvf_conv2d_nhwc_fwd_resmask_gate_sums: the output bit for bit mvf_conv2d_nhwc_fwd_resmask_gate's, and the finalised sums of the channels
-    >= res_c0 equal to mvf_bn_bwd_reduce (mask mode 0) over that stored output and the BatchNorm's input (fp32 summation order)."""
-    lib, check, ConvDesc, _ = _lib()
-    n, h, w, cin, cout, c0 = case
-    m = n * h * w
-    gen = torch.Generator().manual_seed(m + cout + 1)
-    x = torch.randn(m, cin, generator=gen).cuda().to(BF)
-    wp = (torch.randn(cout, cin, generator=gen) * 0.05).cuda().to(BF)
-    res = torch.randn(m, cout, generator=gen).cuda().to(BF)
-    rbits = torch.randint(0, 16, (m, cout // 4), generator=gen, dtype=torch.uint8).cuda()
-    gate = torch.randint(0, 16, (m, cout // 4), generator=gen, dtype=torch.uint8).cuda()
-    z = (torch.randn(m, cout, generator=gen) * 1.2 + 0.3).cuda().to(BF)
-    mean, invstd = (torch.randn(cout, generator=gen) * 0.3).cuda(), (torch.rand(cout, generator=gen) + 0.4).cuda()
-    ws = torch.empty(lib.mvf_conv2d_workspace_bytes(None), dtype=torch.uint8, device="cuda")
-    d = ConvDesc(n, h, w, cin, cout, 1, 1, 1, 0, h, w, cin, 1, 0, 0, 0, 0, c0)
-    y0, y1 = torch.empty(m, cout, device="cuda", dtype=BF), torch.empty(m, cout, device="cuda", dtype=BF)
-    check(lib.mvf_conv2d_nhwc_fwd_resmask_gate(C.byref(d), P(x), None, P(wp), None, P(res), P(rbits), P(gate), P(y0), P(ws), ws.numel(), None))
-    rows = lib.mvf_conv2d_stats_rows(C.byref(d))
-    part = torch.full((cout, rows, 2), float("nan"), device="cuda")
-    check(lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums(C.byref(d), P(x), None, P(wp), P(res), P(rbits), P(gate), P(y1), P(z), P(mean), P(invstd), P(part), P(ws),
-                                                    ws.numel(), None))
-    dg, db = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda")
-    check(lib.mvf_bn_bwd_finalize(P(part[c0:]), rows, cout - c0, P(dg[c0:]), P(db[c0:]), None))
-    ws_bn = torch.empty(lib.mvf_bn_workspace_bytes(m, cout), dtype=torch.uint8, device="cuda")
-    dg0, db0 = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
-    check(lib.mvf_bn_bwd_reduce(P(y0), cout, P(z), None, m, cout, P(mean), P(invstd), None, None, 0, None, P(dg0), P(db0), P(ws_bn), ws_bn.numel(), 1, None))
-    torch.cuda.synchronize()
-    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
-    assert rel_l2(dg[c0:].cpu().numpy(), dg0[c0:].cpu().numpy()) < 1e-5 and rel_l2(db[c0:].cpu().numpy(), db0[c0:].cpu().numpy()) < 1e-5
-
-
-@pytest.mark.parametrize("case", [(2, 4, 14, 14, 1024, 128), (1, 8, 7, 7, 512, 64)], ids=str)
-def test_gated_stencil_with_fused_sums_equals_gate_then_sums_pass(case):
-    """[r5] mvf_nhwc_stencil_gate_sums: the slice bit for bit mvf_nhwc_stencil_gate's, its finalised sums equal to mvf_bn_bwd_reduce (mask mode 0) over
-    the stored slice and the BatchNorm's input (a pitch-c tensor)."""
-    lib, check, _, MvfDesc = _lib()
-    from mvfnet_amd import _lib as L
-    nc, t, h, w, c, cs = case
-    nt, m = nc * t, nc * t * h * w
-    gen = torch.Generator().manual_seed(m + 7)
-    dy = torch.randn(m, cs, generator=gen).cuda().to(BF)
-    add = torch.randn(m, c, generator=gen).cuda().to(BF)
-    abits = torch.randint(0, 16, (m, c // 4), generator=gen, dtype=torch.uint8).cuda()
-    gate = torch.randint(0, 16, (m, c // 4), generator=gen, dtype=torch.uint8).cuda()
-    z = (torch.randn(m, c, generator=gen) * 1.2 + 0.3).cuda().to(BF)
-    mean, invstd = (torch.randn(c, generator=gen) * 0.3).cuda(), (torch.rand(c, generator=gen) + 0.4).cuda()
-    wt, wh, ww = (torch.randn(cs, 3, generator=gen).cuda() for _ in range(3))
-    d = MvfDesc(nt, c, h, w, t, cs, L.MODE_BITS["THW"], L.MVF_NHWC, L.MVF_BF16)
-    o0, o1 = torch.zeros(m, c, device="cuda", dtype=BF), torch.zeros(m, c, device="cuda", dtype=BF)
-    check(lib.mvf_nhwc_stencil_gate(C.byref(d), P(dy), cs, P(o0), c, P(wt), P(wh), P(ww), None, None, 1, P(add), c, P(abits), P(gate), None))
-    rows = lib.mvf_nhwc_stencil_stats_rows(C.byref(d), cs, c)
-    part = torch.full((cs, rows, 2), float("nan"), device="cuda")
-    check(lib.mvf_nhwc_stencil_gate_sums(C.byref(d), P(dy), cs, P(o1), c, P(wt), P(wh), P(ww), 1, P(add), c, P(abits), P(gate), P(z), P(mean), P(invstd), P(part), None))
-    dg, db = torch.empty(cs, device="cuda"), torch.empty(cs, device="cuda")
-    check(lib.mvf_bn_bwd_finalize(P(part), rows, cs, P(dg), P(db), None))
-    ws_bn = torch.empty(lib.mvf_bn_workspace_bytes(m, cs), dtype=torch.uint8, device="cuda")
-    dg0, db0 = torch.empty(cs, device="cuda"), torch.empty(cs, device="cuda")
-    o0s, zs = o0[:, :cs].contiguous(), z[:, :cs].contiguous()
-    check(lib.mvf_bn_bwd_reduce(P(o0s), cs, P(zs), None, m, cs, P(mean), P(invstd), None, None, 0, None, P(dg0), P(db0), P(ws_bn), ws_bn.numel(), 1, None))
-    torch.cuda.synchronize()
-    assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
-    assert rel_l2(dg.cpu().numpy(), dg0.cpu().numpy()) < 1e-5 and rel_l2(db.cpu().numpy(), db0.cpu().numpy()) < 1e-5
-
-
 @pytest.mark.parametrize("case", [(2, 4, 14, 14, 256, 1024, 128), (1, 4, 7, 9, 128, 512, 0), (1, 4, 28, 28, 64, 256, 64), (2, 4, 7, 7, 512, 2048, 256)], ids=str)
 def test_sums_from_the_weight_gradient_gemm_equal_the_sums_pass(case):
-    """[r5] bn3's backward sums with no pass over (gm, z3) (eng.dzfree_q): the producers' bn_z = NULL form (output bit for bit the gated one, partial rows =
+    """[r5] bn3's backward sums with no pass over (gm, z3) (eng.dzfree_q): the producers' column-sum form (output bit for bit the gated one, partial rows =
     the column sums of what is stored) + Q = gm^T a2 on a caller-named workgroup count (mvf_conv2d_nhwc_wgrad_wgs == mvf_conv2d_nhwc_wgrad up to the
     summation order) + mvf_bn_bwd_dzfree_sums, against mvf_bn_bwd_reduce over gm and the STORED z3 = bf16(a2 W^T) and against fp64 on the unrounded z3."""
     lib, check, ConvDesc, MvfDesc = _lib()
@@ -325,8 +259,7 @@ def test_sums_from_the_weight_gradient_gemm_equal_the_sums_pass(case):
     check(lib.mvf_conv2d_nhwc_fwd_resmask_gate(C.byref(d1), P(dz1), None, P(wd1), None, P(res), P(rbits), P(gate), P(g0), P(ws), ws.numel(), None))
     rows_hi = lib.mvf_conv2d_stats_rows(C.byref(d1))
     part_hi = torch.full((c, rows_hi, 2), float("nan"), device="cuda")
-    check(lib.mvf_conv2d_nhwc_fwd_resmask_gate_sums(C.byref(d1), P(dz1), None, P(wd1), P(res), P(rbits), P(gate), P(gm), None, None, None, P(part_hi), P(ws),
-                                                    ws.numel(), None))
+    check(lib.mvf_conv2d_nhwc_fwd_resmask_gate_colsums(C.byref(d1), P(dz1), None, P(wd1), P(res), P(rbits), P(gate), P(gm), P(part_hi), P(ws), ws.numel(), None))
     part_lo, rows_lo = None, 0
     if cs:
         dy = torch.randn(m, cs, generator=gen).cuda().to(BF)
@@ -335,7 +268,7 @@ def test_sums_from_the_weight_gradient_gemm_equal_the_sums_pass(case):
         check(lib.mvf_nhwc_stencil_gate(C.byref(dm), P(dy), cs, P(g0), c, P(wt), P(wh), P(ww), None, None, 1, P(res), c, P(rbits), P(gate), None))
         rows_lo = lib.mvf_nhwc_stencil_stats_rows(C.byref(dm), cs, c)
         part_lo = torch.full((cs, rows_lo, 2), float("nan"), device="cuda")
-        check(lib.mvf_nhwc_stencil_gate_sums(C.byref(dm), P(dy), cs, P(gm), c, P(wt), P(wh), P(ww), 1, P(res), c, P(rbits), P(gate), None, None, None, P(part_lo), None))
+        check(lib.mvf_nhwc_stencil_gate_colsums(C.byref(dm), P(dy), cs, P(gm), c, P(wt), P(wh), P(ww), 1, P(res), c, P(rbits), P(gate), P(part_lo), None))
     torch.cuda.synchronize()
     assert torch.equal(g0.view(torch.int16), gm.view(torch.int16))
     colsum = gm.double().sum(0)
@@ -353,19 +286,13 @@ def test_sums_from_the_weight_gradient_gemm_equal_the_sums_pass(case):
     check(lib.mvf_conv2d_nhwc_wgrad(C.byref(d3), P(gm), P(a2), None, 1, k, 1, k, P(q0), P(wsw), wsw.numel(), None))
     check(lib.mvf_conv2d_nhwc_wgrad_wgs(C.byref(d3), P(gm), P(a2), None, 1, k, 1, k, P(q), P(wsw), wsw.numel(), 256, None))
     dg, db = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-    check(lib.mvf_bn_bwd_dzfree_sums(P(q), None, 0, P(w3), c, k, P(mean), P(invstd), P(part_lo), rows_lo, cs, P(part_hi), rows_hi, P(dg), P(db), L.MVF_BF16, None))
-    # ... and with Q handed over as the GEMM's partial results (mvf_conv2d_nhwc_wgrad_slabs): the same sums, Q written by the sums kernel
-    ns = C.c_int(0)
-    check(lib.mvf_conv2d_nhwc_wgrad_slabs(C.byref(d3), P(gm), P(a2), P(wsw), wsw.numel(), 256, C.byref(ns), None))
-    q2, dg2, db2 = torch.full((c, k), float("nan"), device="cuda"), torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-    check(lib.mvf_bn_bwd_dzfree_sums(P(q2), P(wsw), ns.value, P(w3), c, k, P(mean), P(invstd), P(part_lo), rows_lo, cs, P(part_hi), rows_hi, P(dg2), P(db2), L.MVF_BF16, None))
+    check(lib.mvf_bn_bwd_dzfree_sums(P(q), P(w3), c, k, P(mean), P(invstd), P(part_lo), rows_lo, cs, P(part_hi), rows_hi, P(dg), P(db), L.MVF_BF16, None))
     ws_bn = torch.empty(lib.mvf_bn_workspace_bytes(m, c), dtype=torch.uint8, device="cuda")
     dg0, db0 = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
     check(lib.mvf_bn_bwd_reduce(P(gm), c, P(z3), None, m, c, P(mean), P(invstd), None, None, 0, None, P(dg0), P(db0), P(ws_bn), ws_bn.numel(), 1, None))
     torch.cuda.synchronize()
     ref_q = gm.double().t() @ a2.double()
     assert rel_l2(q.cpu().numpy(), ref_q.cpu().numpy()) < 1e-5 and rel_l2(q.cpu().numpy(), q0.cpu().numpy()) < 1e-5
-    assert ns.value > 0 and rel_l2(q2.cpu().numpy(), ref_q.cpu().numpy()) < 1e-5 and rel_l2(dg2.cpu().numpy(), dg.cpu().numpy()) < 1e-5 and torch.equal(db2, db)
     ref_dg = (gm.double() * (z3x - mean.double()) * invstd.double()).sum(0)
     e_pass, e_q = rel_l2(dg0.cpu().numpy(), ref_dg.cpu().numpy()), rel_l2(dg.cpu().numpy(), ref_dg.cpu().numpy())
     print("case %s: dgamma vs fp64 on the unrounded z3: sums pass (bf16 z3) %.2e, from Q %.2e; dbeta %.2e" %
@@ -398,13 +325,12 @@ def test_two_block_backward_with_sums_from_the_weight_gradient_gemm(shape):
         seq = torch.nn.Sequential(*blks).cuda().train()
         tr = BlockTrainer(seq, dtype=torch.bfloat16)
         tr.dzfree_q = mode
-        tr.dzfree_q_z3free = True          # (off by default: measured neutral)
         tr.gram_stats = False              # (the forward stays the same in both modes; the Gram statistics have their own test below)
         x = torch.relu(torch.randn(8, cin, hw, hw, device="cuda"))
         dy = torch.randn(8, cin, hw, hw, device="cuda")
         y = tr.forward(x).float().clone()
-        # the lower block stores no z3 where bn3's apply is a second conv3 pass (planes <= 128) and its backward sums come from Q (q_z3_free)
-        assert (tr.blks[0].saved["z3"] is None) == (mode == 2 and planes <= 128) and tr.blks[1].saved["z3"] is not None
+        # (without the Gram statistics every block stores its z3: the z3-free form of a dz3-free block is the Gram form, tested below)
+        assert tr.blks[0].saved["z3"] is not None and tr.blks[1].saved["z3"] is not None
         dx = tr.backward(dy).float().clone()
         torch.cuda.synchronize()
         assert tr.blks[1].sums_out == ("s1" if mode else False) and tr.blks[1].gated_out

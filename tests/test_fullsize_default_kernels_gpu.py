@@ -118,7 +118,7 @@ def test_lds_tiled_stencil_full_size_vs_oracle(shape):
     rows2 = lib.mvf_nhwc_stencil_stats_rows(C.byref(d), cs, c)
     part2 = torch.full((cs, rows2, 2), float("nan"), device="cuda")
     o.zero_()
-    check(lib.mvf_nhwc_stencil_gate_sums(C.byref(d), P(dy), cs, P(o), c, P(wt), P(wh), P(ww), 1, P(add), c, P(abits), P(gate), None, None, None, P(part2), None))
+    check(lib.mvf_nhwc_stencil_gate_colsums(C.byref(d), P(dy), cs, P(o), c, P(wt), P(wh), P(ww), 1, P(add), c, P(abits), P(gate), P(part2), None))
     torch.cuda.synchronize()
     assert torch.equal(o[:, :cs].contiguous().view(torch.int16), og.view(torch.int16))
     assert torch.count_nonzero(o[:, cs:]) == 0                    # channels >= cs are conv1's data gradient's, not this kernel's

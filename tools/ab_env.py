@@ -2,7 +2,10 @@
 """A/B of one environment switch on the timed training step: runs bench.py (headline config unless extra flags are given, no comparators)
 once per value and repetition, ALTERNATING the values so that box drift hits all of them alike, and prints ms/step per run and the medians.
 
-    python tools/ab_env.py MVF_FUSE_BNWG 0 7 15 [--reps 2] [-- --depth 101 --frames 16 --clips 16]"""
+    python tools/ab_env.py fuse_bnwg 0 7 15 [--reps 2] [-- --depth 101 --frames 16 --clips 16]
+
+The switch is a name of the MVF_POLICY table (mvfnet_amd/policy.py, csrc/common.h): each run gets MVF_POLICY="<name>=<value>" (appended to
+an MVF_POLICY already in the environment)."""
 import json
 import os
 import subprocess
@@ -27,7 +30,8 @@ def main():
     groups = {v: None for v in values}
     for r in range(reps):
         for v in values:
-            env = dict(os.environ, **{var: v})
+            base = os.environ.get("MVF_POLICY", "")
+            env = dict(os.environ, MVF_POLICY=(base + "," if base else "") + "%s=%s" % (var.lower(), v))
             cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs", "--no-eager-compare"] + extra
             p = subprocess.run(cmd, capture_output=True, text=True, env=env)
             line = [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -1,5 +1,5 @@
 """layer1's 3x3 conv alone at the C3 shape (256 frames, 56 x 56 x 64): forward + statistics, data gradient + BatchNorm sums.
-usage: python tools/c3_bench.py [iters]   (MVF_CONV3X3_DIRECT=0 -> the implicit-GEMM kernel)"""
+usage: python tools/c3_bench.py [iters]   (MVF_POLICY=conv3x3_direct=0 -> the implicit-GEMM kernel)"""
 import ctypes as C
 import sys
 

@@ -241,7 +241,7 @@ def bench_c3bwd():
 
 def bench_wgrad(dt=0, only=None):
     """Single weight-gradient launches (kernel + slab reduce) at the C3 shapes, fp32 by default (`wgrad` / `wgrad16`); A/B the fp32 kernels
-    with MVF_WGRAD_X3=0 (the exact-fp32 MFMA kernel) against the default (three-term bf16 splits on the bf16 matrix cores)."""
+    with MVF_POLICY=wgrad_x3=0 (the exact-fp32 MFMA kernel) against the default (three-term bf16 splits on the bf16 matrix cores)."""
     from mvfnet_amd._lib import ConvDesc
     tdt = torch.bfloat16 if dt else torch.float32
     dev = "cuda"

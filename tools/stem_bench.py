@@ -1,5 +1,5 @@
 """The stem conv alone at the C3 shape (256 frames, 224 x 224): times mvf_conv2d_nhwc_fwd_stats / _fwd_ws (bias + ReLU) with HIP events.
-usage: python tools/stem_bench.py [iters]   (MVF_STEM_DIRECT=0 -> the implicit-GEMM kernel)"""
+usage: python tools/stem_bench.py [iters]   (MVF_POLICY=stem_direct=0 -> the implicit-GEMM kernel)"""
 import ctypes as C
 import sys
 
@@ -42,7 +42,7 @@ for name in ("train", "infer"):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     print("stem %s: %.1f us  (%.2f TB/s of output bytes)" % (name, us, n * ho * wo * 128 / us / 1e6))
-# [r4] the stem's weight gradient (kernel + slab reduce): MVF_WGRAD_STEM_DIRECT=0 -> the implicit GEMM
+# [r4] the stem's weight gradient (kernel + slab reduce): MVF_POLICY=wgrad_stem_direct=0 -> the implicit GEMM
 dz = torch.randn(n * ho * wo, 64, device="cuda").bfloat16()
 wsz = lib.mvf_conv2d_wgrad_workspace_bytes(C.byref(d))
 wws = torch.empty(wsz, dtype=torch.uint8, device="cuda")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Digest of the bf16 NHWC stencil launches over a set of shapes and variants (plain, + statistics, transposed + gated addend + output gate [+ sums]): printed as
-JSON.  tests/test_mvf_gpu.py runs it with MVF_STENCIL_LDS=0 / 1 (the switch is read once per process) and compares: the LDS-tiled kernel must reproduce the chunked
+JSON.  tests/test_mvf_gpu.py runs it with MVF_POLICY=stencil_lds=0 / 1 (the switch is read once per process) and compares: the LDS-tiled kernel must reproduce the chunked
 kernel bit for bit (outputs) and to fp32 summation order (statistics)."""
 import ctypes as C
 import hashlib
@@ -52,17 +52,13 @@ def main():
         check(lib.mvf_nhwc_stencil_gate(C.byref(d), P(dy), cs, P(o), c, P(wt), P(wh), P(ww), None, None, 1, P(add), c, P(abits), P(gate), None))
         outs["transposed_gated"] = o[:, :cs].clone()
         rows2 = lib.mvf_nhwc_stencil_stats_rows(C.byref(d), cs, c)
-        part2 = torch.zeros(cs, rows2, 2, device="cuda")
-        check(lib.mvf_nhwc_stencil_gate_sums(C.byref(d), P(dy), cs, P(o), c, P(wt), P(wh), P(ww), 1, P(add), c, P(abits), P(gate), P(z), P(mean), P(invstd), P(part2), None))
-        outs["transposed_gated_sums"] = o[:, :cs].clone()
-        sums = part2.double().sum(1)
         part3 = torch.zeros(cs, rows2, 2, device="cuda")
-        check(lib.mvf_nhwc_stencil_gate_sums(C.byref(d), P(dy), cs, P(o), c, P(wt), P(wh), P(ww), 1, P(add), c, P(abits), P(gate), None, None, None, P(part3), None))
+        check(lib.mvf_nhwc_stencil_gate_colsums(C.byref(d), P(dy), cs, P(o), c, P(wt), P(wh), P(ww), 1, P(add), c, P(abits), P(gate), P(part3), None))
         outs["transposed_gated_colsums"] = o[:, :cs].clone()
         colsums = part3.double().sum(1)
         torch.cuda.synchronize()
         res[str(case)] = dict(digest={k: hashlib.sha256(v.contiguous().view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16] for k, v in outs.items()},
-                              stats=stats.cpu().flatten().tolist(), sums=sums.cpu().flatten().tolist(), colsums=colsums.cpu().flatten().tolist(), rows=[rows, rows2])
+                              stats=stats.cpu().flatten().tolist(), colsums=colsums.cpu().flatten().tolist(), rows=[rows, rows2])
     print(json.dumps(res))
 
 
