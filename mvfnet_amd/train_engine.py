@@ -1725,7 +1725,7 @@ class TrainEngine(_ParamStore):
             sw = self._switch_names = sorted(k for c_ in type(self).__mro__ for k, v in vars(c_).items()
                                              if not k.startswith("_") and isinstance(v, (bool, int, float, str)) and k not in ("lr", "momentum", "weight_decay", "max_norm"))
         return (tuple(imgs.shape), tuple(labels.shape), labels.dtype, str(imgs.device), torch.cuda.current_stream().cuda_stream, self._ddp_active(),
-                tuple(p.requires_grad for p in self.model.parameters()), tuple(getattr(self, k) for k in sw))
+                self.dropout > 0.0, tuple(p.requires_grad for p in self.model.parameters()), tuple(getattr(self, k) for k in sw))
 
     def _record_step(self, imgs, labels, prepared):
         """One eager step with every library call and stream ordering recorded; returns (loss, Plan | None)."""

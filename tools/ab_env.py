@@ -31,7 +31,10 @@ def main():
     for r in range(reps):
         for v in values:
             base = os.environ.get("MVF_POLICY", "")
-            env = dict(os.environ, MVF_POLICY=(base + "," if base else "") + "%s=%s" % (var.lower(), v))
+            if var.startswith("env:"):         # a plain environment variable instead (env:MVF_LIB_PATH <lib A> <lib B>: two builds of the library)
+                env = dict(os.environ, **{var[4:]: v})
+            else:
+                env = dict(os.environ, MVF_POLICY=(base + "," if base else "") + "%s=%s" % (var.lower(), v))
             cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs", "--no-eager-compare"] + extra
             p = subprocess.run(cmd, capture_output=True, text=True, env=env)
             line = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -43,7 +46,7 @@ def main():
             rf = d.get("roofline", {})
             groups[v] = {k: rf.get(k, {}).get("ms_per_step") for k in ("wgrad", "bn", "bn_wgrad", "mvf")}
             groups[v]["conv"] = rf.get("ms_per_step")
-            print("%s=%s run %d: %.3f ms/step  %.1f clips/s" % (var, v, r, d["ms_per_step"], d["value"]), flush=True)
+            print("%s=%s run %d: %.3f ms/step  %.1f clips/s" % (var, os.path.basename(v), r, d["ms_per_step"], d["value"]), flush=True)
     for v in values:
         xs = sorted(res[v])
         if xs:

@@ -12,7 +12,7 @@ import json
 import sys
 
 GROUPS = (
-    ("conv", ("conv_igemm", "conv_streamk", "conv3x3_c64", "conv3x3_c128", "stem_direct", "pw_sums", "pw_bwd_fused")),
+    ("conv", ("conv_igemm", "conv_streamk", "conv3x3_c64", "stem_direct", "pw_sums", "pw_bwd_fused")),
     ("bn_wgrad", ("bnbwd_wgrad",)),                             # [r4] BatchNorm backward apply + pointwise weight gradient in one pass
     ("wgrad", ("wgrad_", "wgrad3x3")),                                   # GEMMs + wgrad_reduce (the fp32 partial slabs are real traffic)
     ("bn", ("bn_apply", "bn_bwd_apply", "bn_bwd_reduce", "bn_stats_kernel")),
