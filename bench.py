@@ -565,7 +565,7 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=None):
     all_threads = {"threads": cores, "value": None, "unit": "clips/s", "note": None}
     if cores not in cands:
         import subprocess
-        bound = max(20.0, min(60.0, seconds))
+        bound = max(20.0, min(60.0, 1.5 * seconds))
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", str(cores), "--depth", str(depth), "--mode", "train" if train else "infer"],
                                capture_output=True, text=True, timeout=bound, env=dict(os.environ, BENCH_CHILD="1"))
@@ -575,7 +575,9 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=None):
             all_threads["note"] = "stopped after %.0f s" % bound
         lines = [l for l in out.splitlines() if l.startswith("{")]
         if lines:
-            all_threads.update(json.loads(lines[-1]))
+            got = json.loads(lines[-1])
+            got["note"] = "; ".join(n_ for n_ in (got.get("note"), all_threads["note"]) if n_) or None
+            all_threads.update(got)
         elif all_threads["note"] is None:
             all_threads["note"] = "no result"
     else:
@@ -746,13 +748,16 @@ def cpu_child(depth, threads, train):
             for k, v in nb.items():
                 sd[k] = v
         return loss
+    t0 = time.perf_counter()
     step()
+    # (the parent takes the last line it got: if the timed runs do not fit its bound, the warm-up run -- first-touch and oneDNN primitive creation included -- is the figure)
+    print(json.dumps({"threads": threads, "value": round(2.0 / (time.perf_counter() - t0), 3), "timed_runs": 0, "note": "warm-up run only"}), flush=True)
     ts = []
     for _ in range(3):
         t0 = time.perf_counter()
         step()
         ts.append(time.perf_counter() - t0)
-        print(json.dumps({"threads": threads, "value": round(2.0 / sorted(ts)[len(ts) // 2], 2), "timed_runs": len(ts)}), flush=True)      # (the parent takes the last line it got)
+        print(json.dumps({"threads": threads, "value": round(2.0 / sorted(ts)[len(ts) // 2], 3), "timed_runs": len(ts), "note": None}), flush=True)
 
 
 def main():

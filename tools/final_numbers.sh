@@ -9,5 +9,6 @@ run --mode infer --dtype f32 --steps 20 --warmup 5
 run --mode infer --dtype bf16 --steps 30 --warmup 5
 run --mode video --dtype bf16 --steps 30 --warmup 5
 run --mode video --dtype f32 --steps 20 --warmup 5
+run --clips 12
 run --depth 101 --frames 16 --clips 16
 run --depth 101 --frames 16 --clips 32 --steps 5
