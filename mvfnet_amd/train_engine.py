@@ -1099,6 +1099,7 @@ class _ParamStore(object):
             if flat is None or flat.numel() < n:
                 if flat is not None:                   # a larger batch arrived: side-stream kernels may still read the old storage
                     self._side_keep.append(flat)
+                    self._storage_epoch += 1           # launch plans recorded so far hold pointers into the old storage
                     for kk in [kk for kk in self._bufs if kk[0] == key and kk[2] == dt]:
                         del self._bufs[kk]
                 flat = torch.empty(max(n, 1), device=self.device, dtype=dt)
@@ -1111,9 +1112,13 @@ class _ParamStore(object):
         key = "_ws_side" if side else "_ws"
         ws = getattr(self, key, None)
         if ws is None or ws.numel() < nbytes:
+            if ws is not None:
+                self._storage_epoch += 1               # (as in buf(): recorded launch plans point at the old workspace)
             ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.device)
             setattr(self, key, ws)
         return ws
+
+    _storage_epoch = 0         # bumped whenever a persistent buffer or workspace is REPLACED by a larger one: a launch plan is valid for the epoch it was recorded in
 
     # ---- policy.  The defaults below ARE the measured policy of the bf16 / fp32 train step (DESIGN.md section 4.5 has the table with the measurement behind
     # every line); MVF_POLICY="name=value,name=value" (read once, _policy below) overrides them for A/B runs, tests set the attributes on an engine.
@@ -1747,7 +1752,9 @@ class TrainEngine(_ParamStore):
         if rec.unsupported:
             return loss, None
         lab, mask, _ = prepared
-        return loss, launch_plan.Plan(rec, dict(imgs=imgs.data_ptr(), labels=lab.data_ptr(), mask=mask.data_ptr() if mask is not None else 0, loss=loss.data_ptr()))
+        plan = launch_plan.Plan(rec, dict(imgs=imgs.data_ptr(), labels=lab.data_ptr(), mask=mask.data_ptr() if mask is not None else 0, loss=loss.data_ptr()))
+        plan.storage_epoch = self._storage_epoch
+        return loss, plan
 
     def train_step(self, imgs, labels, lr=None):
         key = self._plan_key(imgs, labels) if imgs.is_cuda else None
@@ -1759,6 +1766,10 @@ class TrainEngine(_ParamStore):
         st = self.__dict__.setdefault("_plans", {}).setdefault(key, dict(eager=0, tries=0, cand=None, plan=None))
         prepared = self._step_tensors(imgs, labels)
         plan = st["plan"]
+        if plan is not None and plan.storage_epoch != self._storage_epoch:
+            # a larger batch (or workspace) replaced storage this plan points into since it was recorded: drop it and record this shape again
+            plan = st["plan"] = st["cand"] = None
+            st["tries"] = 0
         if plan is not None:
             lab, mask, loss = prepared
             self._main = torch.cuda.current_stream()
@@ -1773,7 +1784,7 @@ class TrainEngine(_ParamStore):
         else:
             st["tries"] += 1
             loss, cand = self._record_step(imgs, labels, prepared)
-            if cand is not None and st["cand"] is not None and cand.signature == st["cand"].signature:
+            if cand is not None and st["cand"] is not None and cand.signature == st["cand"].signature and cand.storage_epoch == self._storage_epoch:
                 st["plan"], st["cand"] = cand, None          # two consecutive steps made the same calls with the same arguments
             else:
                 st["cand"] = cand

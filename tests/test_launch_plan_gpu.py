@@ -73,6 +73,37 @@ def test_a_new_batch_shape_gets_its_own_plan_and_frozen_statistics_stay_eager():
     assert len(eng._plans) == n and torch.isfinite(eng.flat_params).all()
 
 
+def test_a_larger_batch_replaces_storage_and_the_smaller_batchs_plan_is_recorded_again():
+    """A plan holds raw pointers into the engine's persistent buffers.  When a LARGER batch arrives, TrainEngine.buf() / workspace() replace those allocations
+    (one allocation per call site, sized for the largest shape seen): the plan recorded for the smaller batch must not be replayed on the freed storage.  The
+    sequence small x 6 (plan accepted) -> large x 6 -> small x 6 must equal the same sequence without plans bit for bit, and the small shape must have been
+    recorded a second time (reference: drop_last=False loaders and a val pass between epochs hand the runner batches of different sizes, codes/core/train.py:45-60)."""
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    small = (torch.randn(1, 4, 3, 64, 64, device="cuda", generator=gen), torch.randint(0, 400, (1, 1), device="cuda", generator=gen))
+    large = (torch.randn(3, 4, 3, 64, 64, device="cuda", generator=gen), torch.randint(0, 400, (3, 1), device="cuda", generator=gen))
+    seq = [small] * 6 + [large] * 6 + [small] * 6
+    out = {}
+    for use_plan in (True, False):
+        torch.manual_seed(9)
+        m, eng = _engine(torch.bfloat16, use_plan)
+        losses, epochs, replays = [], [], 0
+        for imgs, labels in seq:
+            mine = lambda: [v["plan"] for k, v in getattr(eng, "_plans", {}).items() if k[0] == tuple(imgs.shape)]  # noqa: E731
+            before = mine()
+            losses.append(eng.train_step(imgs.clone(), labels.clone()).clone())
+            epochs.append(eng._storage_epoch)
+            replays += bool(before) and before[0] is not None and mine()[0] is before[0]          # this shape's plan existed and survived the step: it was replayed
+        torch.cuda.synchronize()
+        out[use_plan] = (torch.cat(losses), eng.flat_params.clone(), epochs, eng, replays)
+    loss_p, par_p, epochs, eng_p, replays = out[True]
+    assert epochs[5] == epochs[0] and epochs[6] > epochs[5] and epochs[-1] == epochs[11], epochs      # only the first large step replaced storage
+    st = list(eng_p._plans.values())
+    assert len(st) == 2 and all(s_["plan"] is not None and s_["plan"].storage_epoch == eng_p._storage_epoch for s_ in st), [(s_["eager"], s_["tries"]) for s_ in st]
+    assert replays == 8, replays                             # steps 5-6, 11-12 and 15-18 ran from plans; step 13 dropped the stale one
+    assert torch.equal(loss_p, out[False][0]), (loss_p, out[False][0])
+    assert torch.equal(par_p, out[False][1])
+
+
 def test_plan_with_the_gradient_exchange_cut_in_two_segments(tmp_path):
     """With a process group the tail bucket's all-reduce is issued in the middle of backward: the plan has two segments around that torch call."""
     import torch.distributed as dist
