@@ -46,7 +46,11 @@ def _uses_tile(L, d, x_c, out_c):
     return bool(L.lib.mvf_nhwc_stencil_tile_plan(C.byref(d), x_c, out_c, C.byref(rb), C.byref(cw))), rb.value, cw.value
 
 
-@pytest.mark.parametrize("shape", FULL_SHAPES, ids=lambda s: "x".join(map(str, s)))
+# the other MVF shapes the bench's configurations launch: C4's layer2 / layer4 (R101 16x4, 16 clips per GPU) and the reference's own 12 clips per GPU (layer3)
+OTHER_SHAPES = [(16, 16, 512, 28, 28), (16, 16, 2048, 7, 7), (12, 8, 1024, 14, 14)]
+
+
+@pytest.mark.parametrize("shape", FULL_SHAPES + OTHER_SHAPES, ids=lambda s: "x".join(map(str, s)))
 def test_lds_tiled_stencil_full_size_vs_oracle(shape):
     from oracle import mvf_numpy
     L = _L()
@@ -67,7 +71,7 @@ def test_lds_tiled_stencil_full_size_vs_oracle(shape):
     d = L.MvfDesc(nt, c, h, w, T, cs, L.MODE_BITS["THW"], L.MVF_NHWC, L.MVF_BF16)
     # the product's own rule puts both directions of this shape on the LDS tile
     fwd_tile, bwd_tile = _uses_tile(L, d, c, cs), _uses_tile(L, d, cs, c)
-    assert fwd_tile[0] and bwd_tile[0], (fwd_tile, bwd_tile)
+    assert (fwd_tile[0] and bwd_tile[0]) or shape in OTHER_SHAPES, (fwd_tile, bwd_tile)      # (OTHER_SHAPES: whichever kernel the rule picks meets the oracle)
     chans = np.array(sorted({0, 1, cs // 2 - 1, cs // 2, cs - 2, cs - 1}))
     tsel = lambda t_: t_[chans].double().cpu().numpy()      # noqa: E731
     taps = dict(wt=tsel(wt), wh=tsel(wh), ww=tsel(ww))
