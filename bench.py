@@ -463,6 +463,36 @@ def _roof(tot, reps, dtype, event_overhead_ms=0.0, pmc_key=None, kernel=None, pm
     return common
 
 
+def usable_cpus():
+    """(CPUs this process may actually use, why): os.cpu_count() capped by the affinity mask and by the container's CFS quota (cgroup v2 cpu.max / v1
+    cpu.cfs_quota_us).  On the gpurun boxes os.cpu_count() = 256 while cpu.max = "1600000 100000": 16 CPUs' worth of time -- 256 runnable oneDNN threads on that
+    quota are throttled into minutes per step, which is what `all_hw_threads` used to time out on."""
+    n = os.cpu_count() or 1
+    why = "os.cpu_count()"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, "affinity mask"
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, why = max(1, int(quota)), "cgroup CPU quota (%.4g CPUs)" % quota
+    return n, why
+
+
 def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=None):
     """The CPU restatement of the same step (oracle/net_torch.py) on the host cores, bounded sample; `eager_compare` = the results
     of eager_comparators() (the same restatement executed by PyTorch-ROCm eager on this GPU), attached to the object."""
@@ -533,7 +563,8 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=None):
                "C3 shape at N=2: R50 8x8, 2 clips, 224^2, fp32 train step (fwd+bwd+clip+SGD)": dict(t=8, clips=2, train=True)}
     if mode != "train":
         entries.pop("C3 shape at N=2: R50 8x8, 2 clips, 224^2, fp32 train step (fwd+bwd+clip+SGD)")
-    cands = sorted(set(t for t in (8, 16, 32) if t <= cores) or {cores})
+    usable, usable_why = usable_cpus()
+    cands = sorted(set(t for t in (8, 16, 32) if t <= cores) | ({usable} if usable <= 64 else set()) or {cores})
     results = {k: None for k in entries}
     per_entry_budget = seconds / max(len(entries) * len(cands), 1)
     global T_FRAMES
@@ -553,9 +584,12 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=None):
                         with torch.no_grad():
                             return net_torch.forward_test(imgs, sd, depth, e["t"], None)
                 rate, n = median_rate(fn, e["clips"], per_entry_budget)
+                by = dict((results[name] or {}).get("by_threads", {}))
+                by[str(thr)] = round(rate, 2)
                 if results[name] is None or rate > results[name]["value"]:
                     results[name] = {"value": round(rate, 2), "unit": "clips/s", "threads": thr, "timed_runs": n,
                                      "ms_per_clip": round(1e3 / rate, 1)}
+                results[name]["by_threads"] = by
     finally:
         T_FRAMES = t_keep
     eager = eager_compare if isinstance(eager_compare, dict) else None
@@ -563,7 +597,12 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=None):
     head = results[head_key]
     # [r6] ... and the same entry at os.cpu_count() threads, as SURVEY 8(d) literally specifies, in a bounded child process (it may not finish: oneDNN thrashes)
     all_threads = {"threads": cores, "value": None, "unit": "clips/s", "note": None}
-    if cores not in cands:
+    if usable < cores and usable in cands:
+        # the container may use `usable` CPUs: THAT is the whole allotment, and it is one of the timed candidates
+        all_threads.update(threads=usable, value=results[head_key].get("by_threads", {}).get(str(usable)), timed_at="usable CPUs",
+                           note="os.cpu_count() = %d, usable = %d (%s): %d threads is the whole allotment; %d runnable threads on it are throttled into minutes per step"
+                                % (cores, usable, usable_why, usable, cores))
+    elif cores not in cands:
         import subprocess
         bound = max(20.0, min(60.0, 1.5 * seconds))
         try:
@@ -582,10 +621,10 @@ def cpu_baseline(depth, seconds, mode, gpu_clips, eager_compare=None):
             all_threads["note"] = "no result"
     else:
         all_threads.update(value=[r_ for r_ in results.values()][-1]["value"], note="one of the candidates")
-    return {"value": head["value"], "unit": "clips/s", "cores": head["threads"], "kind": "port", "host_hw_threads": cores, "cpu_model": cpu_model(),
+    return {"value": head["value"], "unit": "clips/s", "cores": head["threads"], "kind": "port", "host_hw_threads": cores, "usable_cpus": usable, "usable_cpus_limit": usable_why, "cpu_model": cpu_model(),
             "entries": results, "all_hw_threads": all_threads, "torch_eager_gpu": eager,
             "sample": "%s; median of <= 5 runs after 2 warm-ups per entry and thread count, oracle/net_torch.py on torch CPU (oneDNN), best of %s threads "
-                      "(%d hardware threads on the host; all of them at once thrash oneDNN), %.0f s budget" % (head_key, cands, cores, seconds)}
+                      "(%d hardware threads on the host, %d usable: %s), %.0f s budget" % (head_key, cands, cores, usable, usable_why, seconds)}
 
 
 def eager_comparators(depth, clips, frames, size, seconds, engine_value, dtype):
